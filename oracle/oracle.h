@@ -1,0 +1,86 @@
+/* TEST INFRASTRUCTURE -- CPU restatement ("oracle") of deSAMBA's classify hot path.
+ *
+ * This is the checker, not the product: only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  Nothing under desamba_amd/ links it.
+ *
+ * Parity status: PINNED.  The restatement reproduces the reference's own demo
+ * run byte for byte (SAM md5 1da908b61be240c40334b58d3c12ba2a) and
+ * is cross-checked against the compiled reference (oracle/_ref/deSAMBA) on
+ * synthetic reads (tests/test_oracle_vs_ref.py).
+ *
+ * Canonical semantics at the reference's undefined-behaviour sites (SURVEY.md
+ * section 8 a-UB), chosen so the result of a read never depends on earlier reads:
+ *   U1  query bytes left of the forward strand read as 0 ('A'); the forward
+ *       strand is followed by the reverse strand (as in the reference buffer);
+ *       bytes right of the reverse strand never match (0xFE).
+ *   U2  bytes of a reference window that the reference did not load (stale
+ *       stack in src/cly.c:2472,2542,2688) never match (0xFF).
+ *   U3  2-bit reference text beyond its end reads as 0.
+ *   U4  max_read_l (src/cly.c:2958) is the prefix maximum of read length in
+ *       input order (= the reference's `-t 1` behaviour).
+ */
+#ifndef DSB_ORACLE_H
+#define DSB_ORACLE_H
+#include <stdint.h>
+#include <stdio.h>
+
+typedef struct { uint32_t unitig_ID, offset; } ora_sa_t;          /* src/bwt.h:10-13 */
+typedef struct { uint32_t ref_list, length; } ora_unitig_t;       /* src/idx.h:21-25 */
+typedef struct { char name[128]; uint64_t seq_l, seq_offset; } ora_refinfo_t; /* src/idx.h:15-19 */
+
+typedef struct {
+	/* FM index, src/bwt.c:68-104 */
+	uint64_t byteLen; uint8_t *bwt_occ; uint64_t rank[6]; uint64_t *hash_index;
+	uint8_t *acgt[5]; ora_sa_t *sa; uint64_t sa_size; uint64_t dollar_pos;
+	/* exist-kmer filter, src/idx.c:966-982,1112-1118 */
+	uint64_t ek_size, ek_mask; int ek_len, single_base_max; uint8_t *ek0, *ek1;
+	/* unitigs / references, src/idx.c:1123-1159 */
+	uint64_t n_uni; ora_unitig_t *uni;
+	uint64_t n_refbin; uint8_t *refbin;
+	uint64_t n_ref; ora_refinfo_t *ref;
+	uint64_t n_refpos; uint64_t *refpos;   /* bit-field {global_offset:40, ref_ID:23, direction:1} */
+	/* MAPQ tables, src/cly_mt.c:413-437 */
+	int Q_MEM[2000]; int Q_LV[20][20];
+	int filter_min_length, filter_min_score, filter_min_score_LV3;
+} ora_idx_t;
+
+/* one output hit == the fields of chain_item the SAM writer consumes (src/cly.h:69-89) */
+typedef struct {
+	uint32_t ref_ID; uint32_t t_st, t_ed, q_st, q_ed; uint32_t sum_score; uint32_t indel;
+	uint8_t direction, primary, pri_index, pad;
+} ora_hit_t;
+
+typedef struct ora_ctx ora_ctx_t;
+
+/* stage dump of one strand's seed list (a-3), for stage-level parity of the seed-lookup kernel */
+typedef struct { uint32_t offset, len; uint8_t top; } ora_seed_t;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int  ora_idx_load(ora_idx_t *idx, const char *dir, int min_len, int min_score);
+void ora_idx_free(ora_idx_t *idx);
+ora_ctx_t *ora_ctx_new(void);
+void ora_ctx_free(ora_ctx_t *c);
+/* classify one read (ASCII, length len).  Returns number of hits; *hits points into ctx storage
+ * valid until the next call.  max_read_l is carried in the ctx (U4). */
+int  ora_classify(ora_ctx_t *c, const ora_idx_t *idx, const char *seq, uint32_t len, const ora_hit_t **hits);
+void ora_ctx_reset_history(ora_ctx_t *c);
+void ora_ctx_set_history(ora_ctx_t *c, int max_read_l);
+/* stage dumps from the last ora_classify call */
+int  ora_last_seeds(const ora_ctx_t *c, int strand /*1=F,0=R*/, const ora_seed_t **seeds, uint32_t *total_score);
+/* exist-kmer hit bit of every window of a strand (1 byte per window), for the probe kernel's parity */
+void ora_exist_bits(const ora_idx_t *idx, const char *seq, uint32_t len, int strand, uint8_t *out);
+/* work counters of the last call: P0,P1,OCC,SA,RW,MEMS */
+void ora_last_counters(const ora_ctx_t *c, uint64_t out[8]);
+/* SAM record(s) of one read, exactly src/cly_mt.c:245-344 */
+void ora_write_sam(FILE *f, const ora_idx_t *idx, const char *name, const char *seq, const char *qual,
+                   uint32_t len, const ora_hit_t *hits, int n_hits, int max_sec, int full);
+/* whole-file driver: FASTQ/FASTA (plain text) -> SAM; returns number of reads, or <0 */
+long ora_classify_file(const ora_idx_t *idx, const char *reads_path, const char *out_path,
+                       int max_sec, int full, int n_threads, uint64_t *bases);
+uint64_t ora_occ(const ora_idx_t *idx, uint64_t r, uint8_t *c);
+#ifdef __cplusplus
+}
+#endif
+#endif
