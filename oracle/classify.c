@@ -22,6 +22,9 @@
 #define QPAD_R 192       /* U1: never-matching bytes right of the reverse strand */
 #define QPAD_R_VAL 5
 #define TPAD_VAL 4       /* U2 */
+#define LVPAD 8          /* U5: bytes in front of lv_extd's local strings */
+#define LVPAD_Q 0xF1
+#define LVPAD_T 0xF2
 
 /* ---- types (src/cly.h) ---------------------------------------------------------------- */
 typedef struct { uint16_t mtch_len; int16_t score; uint8_t left_len, left_ED, rigt_len, rigt_ED; } amap_t;
@@ -302,11 +305,12 @@ static int32_t lv_extd(uint8_t *ref, int32_t ref_length, uint8_t *query, int32_t
 			}
 			int mn_j = MINV(mn[j], query_length);
 			mn_j = MINV(mn_j, ref_length - j);
-			/* the reference indexes ref[mn_j + j] unguarded; a negative index (stack read there) is
-			   treated as a mismatch */
-			for (; mn_j + j >= 0 && mn_j >= 0 && ref[mn_j + j] == query[mn_j]; mn_j++);
+			/* as in the reference, mn_j (and mn_j + j) can be -1 here: the byte before the string is
+			   read.  For a string inside the read buffer that is the previous base; local buffers
+			   carry LVPAD never-matching bytes on their left (U5). */
+			for (; ref[mn_j + j] == query[mn_j]; mn_j++);
 			mn[j] = mn_j;
-			if ((mn_j >= 0 && query[mn_j] == '$') || (mn_j + j >= 0 && ref[mn_j + j] == '#')) {
+			if (query[mn_j] == '$' || ref[mn_j + j] == '#') {
 				best = MINV(ed[j] - 1, best);
 				if (j <= i + 1) LV_RET(best);
 			}
@@ -404,7 +408,8 @@ static sms_t *push_sms(ora_ctx_t *c)
 static void get_new_ed(ora_ctx_t *c, const ora_idx_t *x, uint32_t *e_d, uint32_t *len_, uint32_t *l_mem_ext,
                        int32_t q_off, uint64_t t_off, uint32_t l_read, uint8_t *q_b, bool is_FWD)
 {
-	uint8_t q_buff[13], *q = q_buff, t_buff[13], *t = t_buff;
+	uint8_t q_buff_[LVPAD + 16], *q_buff = q_buff_ + LVPAD, *q = q_buff, t_buff_[LVPAD + 16], *t_buff = t_buff_ + LVPAD, *t = t_buff;
+	memset(q_buff_, LVPAD_Q, LVPAD); memset(t_buff_, LVPAD_T, LVPAD);
 	uint32_t len, max_len;
 	const uint8_t *t_b = x->refbin;
 	if (is_FWD) {
@@ -443,7 +448,8 @@ static int32_t map_seed(ora_ctx_t *c, const ora_idx_t *x, mem_t *m_r, seedinfo_t
 	uint32_t l_pre, l_suf = 0, d_pre, d_suf = 0; int32_t s = 0, max_s = 0;
 	const int *Q_MEM = x->Q_MEM;
 	do {
-		uint8_t q_pre[13], t_pre[13], *q_suf, t_suf[13];
+		uint8_t q_pre_[LVPAD + 16], *q_pre = q_pre_ + LVPAD, t_pre_[LVPAD + 16], *t_pre = t_pre_ + LVPAD, *q_suf, t_suf_[LVPAD + 16], *t_suf = t_suf_ + LVPAD;
+		memset(q_pre_, LVPAD_Q, LVPAD); memset(t_pre_, LVPAD_T, LVPAD); memset(t_suf_, LVPAD_T, LVPAD);
 		l_pre = MINV(q_off + 1, 12);
 		for (uint8_t k = 0; k < l_pre; k++) q_pre[k] = q_b[q_off - k];
 		int s_l = 0;
@@ -1231,3 +1237,17 @@ int ora_last_seeds(const ora_ctx_t *c, int strand, const ora_seed_t **seeds, uin
 	return (int)sd->l_seed_v;
 }
 void ora_last_counters(const ora_ctx_t *c, uint64_t out[8]) { memcpy(out, c->cnt, sizeof c->cnt); }
+
+/* stage dump: anchors (a-8) of the last call, in emission order (or M3-sorted order when >= 50) */
+int ora_last_anchors(const ora_ctx_t *c, ora_anchor_t *out, int max)
+{
+	int n = (int)c->n_anc < max ? (int)c->n_anc : max;
+	for (int i = 0; i < n; i++) {
+		const anchor_t *a = c->anc + i;
+		out[i].index_in_read = a->index_in_read; out[i].ref_ID = a->ref_ID; out[i].ref_offset = a->ref_offset;
+		out[i].score = a->a_m.score; out[i].mtch_len = a->a_m.mtch_len; out[i].direction = a->direction;
+		out[i].useless = a->anchor_useless; out[i].seed_ID = a->seed_ID;
+		out[i].left_len = a->a_m.left_len; out[i].left_ED = a->a_m.left_ED; out[i].rigt_len = a->a_m.rigt_len; out[i].rigt_ED = a->a_m.rigt_ED;
+	}
+	return (int)c->n_anc;
+}

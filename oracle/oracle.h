@@ -12,10 +12,14 @@
  * section 8 a-UB), chosen so the result of a read never depends on earlier reads:
  *   U1  query bytes left of the forward strand read as 0 ('A'); the forward
  *       strand is followed by the reverse strand (as in the reference buffer);
- *       bytes right of the reverse strand never match (0xFE).
+ *       bytes right of the reverse strand never match (value 5).
  *   U2  bytes of a reference window that the reference did not load (stale
- *       stack in src/cly.c:2472,2542,2688) never match (0xFF).
+ *       stack in src/cly.c:2472,2542,2688) hold the value 4: they match nothing and
+ *       enter 9-mer arithmetic as the literal 4.
  *   U3  2-bit reference text beyond its end reads as 0.
+ *   U5  lv_extd (src/cly.c:594) can read the byte in front of either string: for a
+ *       string inside the read buffer that is the previous base (defined); for
+ *       the local 13-byte buffers of map_seed/get_new_ed it never matches.
  *   U4  max_read_l (src/cly.c:2958) is the prefix maximum of read length in
  *       input order (= the reference's `-t 1` behaviour).
  */
@@ -55,6 +59,8 @@ typedef struct ora_ctx ora_ctx_t;
 /* stage dump of one strand's seed list (a-3), for stage-level parity of the seed-lookup kernel */
 typedef struct { uint32_t offset, len; uint8_t top; } ora_seed_t;
 
+typedef struct { uint32_t index_in_read, ref_ID, ref_offset; int16_t score; uint16_t mtch_len, seed_ID; uint8_t direction, useless, left_len, left_ED, rigt_len, rigt_ED; } ora_anchor_t;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -72,6 +78,7 @@ int  ora_last_seeds(const ora_ctx_t *c, int strand /*1=F,0=R*/, const ora_seed_t
 /* exist-kmer hit bit of every window of a strand (1 byte per window), for the probe kernel's parity */
 void ora_exist_bits(const ora_idx_t *idx, const char *seq, uint32_t len, int strand, uint8_t *out);
 /* work counters of the last call: P0,P1,OCC,SA,RW,MEMS */
+int  ora_last_anchors(const ora_ctx_t *c, ora_anchor_t *out, int max);
 void ora_last_counters(const ora_ctx_t *c, uint64_t out[8]);
 /* SAM record(s) of one read, exactly src/cly_mt.c:245-344 */
 void ora_write_sam(FILE *f, const ora_idx_t *idx, const char *name, const char *seq, const char *qual,
