@@ -1,0 +1,252 @@
+"""desamba_amd -- MI355X-native `deSAMBA classify` hot path.
+
+Thin ctypes binding over the C-ABI in include/desamba_amd.h (libdesamba_amd.so, built in-tree by
+__graft_entry__.build()).  All compute runs in HIP kernels on gfx950; there is no CPU fallback:
+loading fails loudly when the library is missing and Ctx() fails when no gfx950 device is present.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdesamba_amd.so")
+
+DSB_OK, DSB_EIO, DSB_ENODEV, DSB_ENOMEM, DSB_EINVAL, DSB_ECAP = 0, -1, -2, -3, -4, -5
+
+
+class DsbOpts(C.Structure):
+    _fields_ = [("L_min_matching", C.c_int), ("min_score", C.c_int), ("max_sec_N", C.c_int), ("n_slots", C.c_int)]
+
+
+class DsbRead(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("seq", C.c_char_p), ("qual", C.c_char_p), ("len", C.c_uint32)]
+
+
+class DsbHit(C.Structure):
+    _fields_ = [("ref_ID", C.c_uint32), ("t_st", C.c_uint32), ("t_ed", C.c_uint32), ("q_st", C.c_uint32), ("q_ed", C.c_uint32),
+                ("sum_score", C.c_uint32), ("indel", C.c_uint32), ("direction", C.c_uint8), ("primary", C.c_uint8),
+                ("pri_index", C.c_uint8), ("pad", C.c_uint8)]
+
+    def key(self):
+        return (self.ref_ID, self.t_st, self.t_ed, self.q_st, self.q_ed, self.sum_score, self.direction, self.primary, self.pri_index)
+
+
+class DsbReadResult(C.Structure):
+    _fields_ = [("first", C.c_uint32), ("n", C.c_uint32), ("status", C.c_int32), ("fast", C.c_uint32)]
+
+
+class DsbResult(C.Structure):
+    _fields_ = [("reads", C.POINTER(DsbReadResult)), ("hits", C.POINTER(DsbHit)), ("n_hits", C.c_size_t)]
+
+
+class DsbSeed(C.Structure):
+    _fields_ = [("offset", C.c_uint32), ("len", C.c_uint32), ("top", C.c_uint8), ("pad", C.c_uint8 * 3)]
+
+
+class DsbTiming(C.Structure):
+    _fields_ = [("encode_ms", C.c_float), ("seed_probe_ms", C.c_float), ("classify_ms", C.c_float), ("total_ms", C.c_float),
+                ("windows", C.c_uint64), ("probes_t1", C.c_uint64), ("bases", C.c_uint64)]
+
+
+EXPORTS = ["dsb_index_open", "dsb_index_close", "dsb_index_n_ref", "dsb_index_ref_name", "dsb_index_ref_len", "dsb_index_ek_len",
+           "dsb_index_occ_host", "dsb_ctx_create", "dsb_ctx_destroy", "dsb_ctx_reset_history", "dsb_classify_batch",
+           "dsb_batch_upload", "dsb_batch_run", "dsb_batch_fetch", "dsb_batch_timing", "dsb_batch_seeds", "dsb_batch_exist_bits",
+           "dsb_format_sam", "dsb_strerror", "dsb_version"]
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("desamba_amd: %s is missing -- run __graft_entry__.build(); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.dsb_index_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+    L.dsb_index_close.argtypes = [C.c_void_p]
+    L.dsb_index_n_ref.argtypes = [C.c_void_p]; L.dsb_index_n_ref.restype = C.c_uint64
+    L.dsb_index_ref_name.argtypes = [C.c_void_p, C.c_uint32]; L.dsb_index_ref_name.restype = C.c_char_p
+    L.dsb_index_ref_len.argtypes = [C.c_void_p, C.c_uint32]; L.dsb_index_ref_len.restype = C.c_uint64
+    L.dsb_index_ek_len.argtypes = [C.c_void_p]
+    L.dsb_index_occ_host.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint8)]; L.dsb_index_occ_host.restype = C.c_uint64
+    L.dsb_ctx_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(DsbOpts), C.POINTER(C.c_void_p)]
+    L.dsb_ctx_destroy.argtypes = [C.c_void_p]
+    L.dsb_ctx_reset_history.argtypes = [C.c_void_p]
+    L.dsb_classify_batch.argtypes = [C.c_void_p, C.POINTER(DsbRead), C.c_size_t, C.POINTER(DsbResult)]
+    L.dsb_batch_upload.argtypes = [C.c_void_p, C.POINTER(DsbRead), C.c_size_t]
+    L.dsb_batch_run.argtypes = [C.c_void_p]
+    L.dsb_batch_fetch.argtypes = [C.c_void_p, C.POINTER(DsbResult)]
+    L.dsb_batch_timing.argtypes = [C.c_void_p, C.POINTER(DsbTiming)]
+    L.dsb_batch_seeds.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(DsbSeed), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.dsb_batch_exist_bits.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint32)]
+    L.dsb_format_sam.argtypes = [C.c_void_p, C.POINTER(DsbRead), C.POINTER(DsbHit), C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.dsb_format_sam.restype = C.c_long
+    L.dsb_strerror.argtypes = [C.c_int]; L.dsb_strerror.restype = C.c_char_p
+    L.dsb_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+class DsbError(RuntimeError):
+    def __init__(self, code, what):
+        RuntimeError.__init__(self, "%s: %s (%d)" % (what, lib().dsb_strerror(code).decode(), code))
+        self.code = code
+
+
+class Index:
+    """load_idx (src/idx.c:1103): the ten deSAMBA.* files of an index directory."""
+
+    def __init__(self, path):
+        self.h = C.c_void_p()
+        rc = lib().dsb_index_open(os.fsencode(path), C.byref(self.h))
+        if rc != 0:
+            raise DsbError(rc, "dsb_index_open(%s)" % path)
+        self.path = path
+
+    def close(self):
+        if self.h:
+            lib().dsb_index_close(self.h); self.h = C.c_void_p()
+
+    @property
+    def n_ref(self):
+        return lib().dsb_index_n_ref(self.h)
+
+    @property
+    def ek_len(self):
+        return lib().dsb_index_ek_len(self.h)
+
+    def ref_name(self, i):
+        return lib().dsb_index_ref_name(self.h, i).decode()
+
+    def occ_host(self, r, c):
+        cc = C.c_uint8(c)
+        v = lib().dsb_index_occ_host(self.h, r, C.byref(cc))
+        return v, cc.value
+
+
+def make_reads(records):
+    """records: list of (name, seq, qual) of bytes/str -> ctypes array (keeps the buffers alive)."""
+    n = len(records)
+    arr = (DsbRead * n)()
+    keep = []
+    for i, (name, seq, qual) in enumerate(records):
+        name = name if isinstance(name, bytes) else name.encode()
+        seq = seq if isinstance(seq, bytes) else seq.encode()
+        qual = (qual if isinstance(qual, bytes) else qual.encode()) if qual is not None else None
+        keep.append((name, seq, qual))
+        arr[i].name, arr[i].seq, arr[i].qual, arr[i].len = name, seq, qual, len(seq)
+    arr._keep = keep
+    return arr
+
+
+class Ctx:
+    """classify_main's set-up (src/cly_mt.c:518-550) on one GPU."""
+
+    def __init__(self, index, device=0, L_min_matching=170, min_score=64, max_sec_N=5, n_slots=0):
+        self.index = index
+        self.opts = DsbOpts(L_min_matching, min_score, max_sec_N, n_slots)
+        self.h = C.c_void_p()
+        rc = lib().dsb_ctx_create(index.h, device, C.byref(self.opts), C.byref(self.h))
+        if rc != 0:
+            raise DsbError(rc, "dsb_ctx_create(device %d)" % device)
+        self.reads = None
+
+    def close(self):
+        if self.h:
+            lib().dsb_ctx_destroy(self.h); self.h = C.c_void_p()
+
+    def reset_history(self):
+        lib().dsb_ctx_reset_history(self.h)
+
+    def upload(self, reads):
+        self.reads = reads
+        rc = lib().dsb_batch_upload(self.h, reads, len(reads))
+        if rc != 0:
+            raise DsbError(rc, "dsb_batch_upload")
+
+    def run(self):
+        rc = lib().dsb_batch_run(self.h)
+        if rc != 0:
+            raise DsbError(rc, "dsb_batch_run")
+
+    def fetch(self, strict=True):
+        res = DsbResult()
+        rc = lib().dsb_batch_fetch(self.h, C.byref(res))
+        if rc != 0 and (strict or rc != DSB_ECAP):
+            raise DsbError(rc, "dsb_batch_fetch")
+        return res
+
+    def classify(self, reads, strict=True):
+        self.upload(reads); self.run()
+        return self.fetch(strict)
+
+    def timing(self):
+        t = DsbTiming()
+        lib().dsb_batch_timing(self.h, C.byref(t))
+        return t
+
+    def seeds(self, read, strand):
+        cap = (self.reads[read].len >> 1) + 64
+        buf = (DsbSeed * cap)(); n = C.c_uint32(); ts = C.c_uint32()
+        rc = lib().dsb_batch_seeds(self.h, read, strand, buf, cap, C.byref(n), C.byref(ts))
+        if rc != 0:
+            raise DsbError(rc, "dsb_batch_seeds")
+        return [(buf[i].offset, buf[i].len, buf[i].top) for i in range(n.value)], ts.value
+
+    def exist_bits(self, read, strand):
+        cap = self.reads[read].len + 1
+        buf = (C.c_uint8 * cap)(); n = C.c_uint32()
+        rc = lib().dsb_batch_exist_bits(self.h, read, strand, buf, cap, C.byref(n))
+        if rc != 0:
+            raise DsbError(rc, "dsb_batch_exist_bits")
+        return bytes(buf[:n.value])
+
+    def sam(self, res, full=False):
+        """Format a whole batch exactly as output_one_result_sam does (src/cly_mt.c:245-344)."""
+        out = []
+        buf = C.create_string_buffer(1 << 20)
+        for i in range(len(self.reads)):
+            rr = res.reads[i]
+            hits = C.cast(C.byref(res.hits.contents, rr.first * C.sizeof(DsbHit)), C.POINTER(DsbHit)) if rr.n else None
+            cap = len(buf)
+            need = 4096 + 700 * rr.n + (2 * self.reads[i].len if full else 0)
+            if need > cap:
+                buf = C.create_string_buffer(need)
+            n = lib().dsb_format_sam(self.index.h, C.byref(self.reads[i]), hits, rr.n, self.opts.max_sec_N, 1 if full else 0, buf, len(buf))
+            if n < 0:
+                raise DsbError(DSB_EINVAL, "dsb_format_sam")
+            out.append(buf.raw[:n])
+        return b"".join(out)
+
+
+def read_fastq(path, limit=None):
+    """Plain-text FASTQ/FASTA reader with kseq's record rules (src/lib/utils.c:939-977)."""
+    recs = []
+    with open(path, "rb") as f:
+        data = f.read()
+    lines = data.split(b"\n")
+    i = 0
+    while i < len(lines):
+        ln = lines[i]
+        if not ln or ln[0:1] not in (b"@", b">"):
+            i += 1; continue
+        fq = ln[0:1] == b"@"
+        name = ln[1:].split()[0] if len(ln) > 1 and ln[1:].split() else b""
+        i += 1
+        seq = []
+        while i < len(lines) and lines[i][0:1] not in (b">", b"+", b"@"):
+            seq.append(lines[i].rstrip(b"\r")); i += 1
+        seq = b"".join(seq)
+        qual = None
+        if fq and i < len(lines) and lines[i][0:1] == b"+":
+            i += 1
+            q = []
+            ql = 0
+            while i < len(lines) and ql < len(seq):
+                q.append(lines[i].rstrip(b"\r")); ql += len(q[-1]); i += 1
+            qual = b"".join(q)
+        recs.append((name, seq, qual))
+        if limit and len(recs) >= limit:
+            break
+    return recs

@@ -1,0 +1,1318 @@
+// Device side of classify_seq (src/cly.c:3064-3132), one read per 64-lane wavefront.
+//
+// Execution model: every lane of the wave runs the read's control flow redundantly (all
+// values are wave-uniform, loads broadcast, stores coalesce to one transaction), and the
+// data-parallel pieces -- reference-window fetch, 9-mer table build, sort/permute copies --
+// split their iterations over the 64 lanes and meet at wave_sync().  No lane ever waits on
+// another wave, so the grid drains unconditionally.
+//
+// Integer types and expression shapes follow the reference where its results depend on C's
+// signed/unsigned conversions (e.g. src/cly.c:2590-2592); citations are on each function.
+#pragma once
+#include "dsb_device.h"
+
+// DSB_HOST_EMU (tests/emu only): the same functions compiled for the host as a 1-lane wave, so the
+// per-read logic can be run under gdb / sanitizers on a machine without a GPU.  Never part of the product.
+#ifdef DSB_HOST_EMU
+#define DV static inline
+#define DN static
+#define DSB_WAVE 1
+static inline unsigned long long dsb_ballot(int p) { return p ? 1ULL : 0ULL; }
+template <class T> static inline T dsb_shfl(T v, int) { return v; }
+#define __popcll __builtin_popcountll
+#else
+#define DV __device__ __forceinline__
+#define DN __device__ __noinline__
+#define DSB_WAVE 64
+#define dsb_ballot(p) __ballot(p)
+#define dsb_shfl(v, l) __shfl(v, l)
+#endif
+#define MAXV(a,b) (((a) > (b))?(a):(b))
+#define MINV(a,b) (((a) < (b))?(a):(b))
+#define ABSV(a) (((a) > 0)?(a): (- (a)))
+#define ABS_U(a,b) (((a) > (b))?((a) - (b)): ((b) - (a)))
+#define D_FORWARD 1u
+#define D_REVERSE 0u
+#define D_U64MAX 0xffffffffffffffffULL
+#define DSB_STEP_LIMIT 20000000u
+#define SPENT(w) (++(w).steps > DSB_STEP_LIMIT)
+#define MARK(w, code) do { if ((w).dbg && (w).lane == 0) { (w).dbg[0] = (code); (w).dbg[1] = (w).steps; } } while (0)
+
+DV void wave_sync()
+{	// make this wave's earlier stores visible to all of its lanes (same CU, same L1)
+#ifndef DSB_HOST_EMU
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+}
+
+struct SDir { DsbSeed *seed_v; uint32_t l_seed_v; uint8_t *bin_read; const uint64_t *bits; uint32_t direction, total_score; };
+
+struct WCtx {
+	const DsbDevIndex *x;
+	int lane;
+	uint8_t *bin; uint32_t L;
+	DsbSeed *seeds;
+	DsbAnchor *anc, *anc_tmp; uint32_t n_anc;
+	DsbChain *hit, *hit_tmp; uint32_t n_hit;
+	DsbSms *sms; uint32_t n_sms;
+	uint32_t *kh_head[2], *kh_next[2], *kh_kmer[2];
+	DsbScHash *sc;
+	DsbMem *mem_slow;
+	uint64_t *spset;
+	int *score_v;
+	uint64_t *sortkey; uint32_t *sortidx;      // 2 x cap each (ping-pong)
+	uint8_t *win_mid, *win_right, *win_left;
+	int status; int max_read_l;
+	int stage; uint32_t steps; volatile uint32_t *dbg;   // optional host-visible progress words (DSB_DEBUG)
+            // loop-iteration budget: every unbounded loop charges it and bails when exhausted
+	SDir sd[2];
+};
+
+// ---- hashes (src/lib/utils.c:1067-1091) ---------------------------------------------------
+DV uint64_t d_hash64_1(uint64_t key)
+{
+	key = (~key + (key << 21)); key = key ^ key >> 24; key = ((key + (key << 3)) + (key << 8));
+	key = key ^ key >> 14; key = ((key + (key << 2)) + (key << 4)); key = key ^ key >> 28; key = (key + (key << 31));
+	return key;
+}
+DV uint64_t d_hash64_2(uint64_t key)
+{
+	key += ~(key << 32); key ^= (key >> 22); key += ~(key << 13); key ^= (key >> 8);
+	key += (key << 3); key ^= (key >> 15); key += ~(key << 27); key ^= (key >> 31);
+	return key;
+}
+
+// ---- rank query, one 64-B line (reference: occ, src/bwt.c:43-65) ---------------------------
+DV uint64_t fm_occ(const DsbDevIndex *x, uint64_t r, uint32_t &c)
+{
+	const uint4 *bp = reinterpret_cast<const uint4 *>(x->fm + (r >> 7));
+	uint4 a0 = bp[0], a1 = bp[1], a2 = bp[2], a3 = bp[3];
+	uint32_t off = (uint32_t)r & 127u;
+	uint64_t p0[2] = {((uint64_t)a1.y << 32) | a1.x, ((uint64_t)a1.w << 32) | a1.z};
+	uint64_t p1[2] = {((uint64_t)a2.y << 32) | a2.x, ((uint64_t)a2.w << 32) | a2.z};
+	uint64_t sp[2] = {((uint64_t)a3.y << 32) | a3.x, ((uint64_t)a3.w << 32) | a3.z};
+	if (c == 0xffu) {
+		uint32_t w = off >> 6, b = off & 63u;
+		uint32_t s = (uint32_t)(sp[w] >> b) & 1u, q0 = (uint32_t)(p0[w] >> b) & 1u, q1 = (uint32_t)(p1[w] >> b) & 1u;
+		c = s ? (4u + q0) : (q0 | (q1 << 1));
+		if (c == 5u) return x->dollar_pos;
+	}
+	uint64_t m0 = off >= 64u ? ~0ULL : ((1ULL << off) - 1ULL);
+	uint64_t m1 = off > 64u ? ((1ULL << (off - 64u)) - 1ULL) : 0ULL;
+	if (c < 4u) {
+		uint64_t e0 = ~sp[0] & ((c & 1u) ? p0[0] : ~p0[0]) & ((c & 2u) ? p1[0] : ~p1[0]) & m0;
+		uint64_t e1 = ~sp[1] & ((c & 1u) ? p0[1] : ~p0[1]) & ((c & 2u) ? p1[1] : ~p1[1]) & m1;
+		uint32_t base = c == 0 ? a0.x : c == 1 ? a0.y : c == 2 ? a0.z : a0.w;
+		return (uint64_t)base + __popcll(e0) + __popcll(e1);
+	}
+	// c == 4: '#' rows before r
+	uint64_t blk0 = (r >> 7) << 7;
+	uint64_t base = blk0 - ((uint64_t)a0.x + a0.y + a0.z + a0.w) - (x->dollar_row < blk0 ? 1u : 0u);
+	return base + __popcll(sp[0] & ~p0[0] & m0) + __popcll(sp[1] & ~p0[1] & m1);
+}
+
+// ---- get_ref (src/cly.c:435-466); small windows are fetched redundantly by every lane ------
+DV void get_ref_small(const uint8_t *txt, uint8_t *out, int64_t off, int32_t length, bool fwd)
+{
+	if (off < 0) off = 0;
+	if (length < 0) length = 0;
+	uint64_t o = (uint64_t)off >> 2; uint32_t odd = off & 3;
+	if (fwd)
+		for (uint32_t k = 0; k < (uint32_t)length; k++) {
+			out[k] = (txt[o] >> (6 - 2 * odd)) & 3;
+			if (odd == 3) { odd = 0; o++; } else odd++;
+		}
+	else
+		for (uint32_t k = 0; k < (uint32_t)length; k++) {
+			out[k] = (o == ~0ULL) ? 0 : (txt[o] >> (6 - 2 * odd)) & 3;
+			if (odd == 0) { odd = 3; o--; } else odd--;
+		}
+}
+// forward window of any length, lanes split the bases; caller must wave_sync() before reading
+DV void get_ref_wave(const WCtx &w, uint8_t *out, int64_t off, int32_t length)
+{
+	if (off < 0) off = 0;
+	if (length < 0) length = 0;
+	const uint8_t *txt = w.x->refbin;
+	for (int32_t k = w.lane; k < length; k += DSB_WAVE) {
+		uint64_t p = (uint64_t)off + (uint32_t)k;
+		out[k] = (txt[p >> 2] >> (6 - 2 * (p & 3))) & 3;
+	}
+}
+
+// get_uni (src/cly.c:471-496)
+DV int64_t get_uni(const DsbDevIndex *x, uint64_t bwt_pos, int search_l, uint64_t *global_offset, uint32_t *uni_offset_)
+{
+	uint2 sa = x->sa[bwt_pos >> 3];
+	int64_t u = sa.x;
+	uint32_t uni_offset = sa.y + search_l + 1;
+	if (search_l > 0)
+		for (;;) { uint32_t len = x->uni[u].y; if (!(uni_offset >= len)) break; uni_offset -= (len + 1); u++; }
+	uint64_t rp = x->refpos[x->uni[u].x];
+	*global_offset = (rp & 0xFFFFFFFFFFULL) + uni_offset;
+	*uni_offset_ = uni_offset;
+	return u;
+}
+
+// ---- lv_extd (src/cly.c:510-609).  Both strings live in local byte arrays with 8 bytes in
+// front (oracle U5); the sentinels '#'/'$' are placed by the caller at index len.
+DV int32_t lv_extd(const uint8_t *ref, int32_t ref_length, const uint8_t *query, int32_t query_length)
+{
+	if (ref_length == 0 && query_length == 0) return 0;
+	int32_t mn_d[12], ed_d[12];
+	int32_t prev_mn, cur_mn, next_mn, prev_ed, cur_ed, next_ed;
+	int32_t best = query_length;
+#define MN(i) mn_d[(i) + 5]
+#define ED(i) ed_d[(i) + 5]
+#pragma unroll
+	for (int i = -5; i <= 5; i++) { MN(i) = -1; ED(i) = (i > 0) ? i : -i; }
+	MN(6) = -1; ED(6) = 6;
+#pragma unroll
+	for (int i = 0; i <= 4; i++) {
+		prev_mn = -1; cur_mn = i - 1; next_mn = MN(-i + 1);
+		prev_ed = i + 1; cur_ed = i; next_ed = ED(-i + 1);
+#pragma unroll
+		for (int j = -i; j <= 4; j++) {
+			int mnj, edj;
+			if (cur_mn + j < ref_length - 1) {
+				int m = cur_mn + 1 - cur_ed;
+				mnj = cur_mn + 1; edj = cur_ed + 1;
+				if (m < next_mn + 1 - next_ed) { mnj = next_mn + 1; edj = next_ed + 1; m = next_mn - next_ed; }
+				if (m < prev_mn - prev_ed) { mnj = prev_mn + 1; edj = prev_ed + 1; }
+			} else {
+				int m = cur_mn - cur_ed;
+				mnj = cur_mn; edj = cur_ed + 1;
+				if (m < prev_mn - prev_ed) { mnj = prev_mn; edj = prev_ed + 1; m = prev_mn - prev_ed; }
+				if (m < next_mn + 1 - next_ed) { mnj = next_mn + 1; edj = next_ed + 1; }
+			}
+			ED(j) = edj;
+			int mn_j = MINV(mnj, query_length);
+			mn_j = MINV(mn_j, ref_length - j);
+			for (; ref[mn_j + j] == query[mn_j]; mn_j++);
+			MN(j) = mn_j;
+			if (query[mn_j] == '$' || ref[mn_j + j] == '#') {
+				best = MINV(edj - 1, best);
+				if (j <= i + 1) return best;
+			}
+			prev_mn = cur_mn; cur_mn = next_mn; next_mn = MN(j + 2);
+			prev_ed = cur_ed; cur_ed = next_ed; next_ed = ED(j + 2);
+		}
+	}
+	return best;
+#undef MN
+#undef ED
+}
+
+// ---- FM search (src/cly.c:1286-1447) --------------------------------------------------------
+struct SpSet { uint64_t *set; int l, m; };
+DV int sp_set_insert(uint64_t node, SpSet &s)
+{
+	if (s.l == s.m) s.l = 0;
+	int i = 0;
+	for (; i < s.l; i++) if (s.set[i] == node) return 0;
+	s.set[i] = node; s.l++;
+	return 1;
+}
+
+DV void bwt_single_search(const DsbDevIndex *x, uint64_t sp, const uint8_t *string, int max_match_len, SpSet &sp_set, DsbMem &m)
+{
+	uint64_t new_sp, sa_sp = D_U64MAX; int match_len = 0, sa_sp_l = 0;
+	while (1) {
+		if (match_len >= max_match_len) break;
+		if ((sp & 7) == 0) { sa_sp = sp; sa_sp_l = 0; } else sa_sp_l--;
+		uint32_t ch = 0xff;
+		new_sp = fm_occ(x, sp, ch); new_sp += x->rank[ch];
+		if (ch != *string) break;
+		match_len++; string--;
+		if (sp_set_insert(new_sp, sp_set) == 0) { m.match_len = -1000; return; }
+		sp = new_sp;
+	}
+	m.sp = sp; m.match_len = match_len; m.sa_sp = sa_sp; m.sa_sp_l = sa_sp_l;
+}
+
+DV int bwt_MEM_search(const DsbDevIndex *x, const uint8_t *string, uint64_t pre_v, int max_rst, int l_min_mth, int l_max_mth, SpSet &sp_set, DsbMem *mem)
+{
+	int n_rst = 0;
+	uint64_t sp = x->hash_index[pre_v], ep = x->hash_index[pre_v + 1], new_sp, new_ep;
+	string -= 13; int match_len = 13; uint32_t ch;
+	while (1) {
+		ch = *string; string--;
+		new_sp = x->rank[ch] + fm_occ(x, sp, ch);
+		new_ep = x->rank[ch] + fm_occ(x, ep, ch);
+		if (match_len >= l_min_mth - 1) {
+			if (new_sp + max_rst >= new_ep) break;
+			if (match_len >= l_max_mth) return 0;
+		}
+		if (new_sp + 1 >= new_ep) break;
+		match_len++; sp = new_sp; ep = new_ep;
+	}
+	if (new_sp >= new_ep) return 0;
+	if (new_sp + 1 == new_ep) {
+		if (sp_set_insert(new_sp, sp_set) == 0) return 0;
+		bwt_single_search(x, new_sp, string, MAXV(0, l_max_mth - match_len), sp_set, mem[n_rst]);
+		mem[n_rst].match_len += match_len + 1;
+		if (mem[n_rst].match_len >= l_min_mth) n_rst++;
+	} else {
+		for (uint64_t c_sp = new_sp; c_sp < new_ep; c_sp++) {
+			if (sp_set_insert(c_sp, sp_set) == 0) continue;
+			bwt_single_search(x, c_sp, string, MAXV(0, l_max_mth - match_len), sp_set, mem[n_rst]);
+			mem[n_rst].match_len += match_len + 1;
+			if (mem[n_rst].match_len >= l_min_mth) n_rst++;
+		}
+	}
+	return n_rst;
+}
+
+// 13-base prefix value of the k-mer window ending at string_index (= kmer[kmer_index] & PRE_IDX_MASK,
+// src/cly.c:1504; the windows used are always inside an island, so the k-mer is never filtered)
+DV uint64_t prefix13(const uint8_t *bin, int string_index)
+{
+	uint64_t v = 0;
+#pragma unroll
+	for (int i = 12; i >= 0; i--) v = (v << 2) | bin[string_index - i];
+	return v;
+}
+
+struct AMap { uint16_t mtch_len; int16_t score; uint8_t left_len, left_ED, rigt_len, rigt_ED; };
+
+#define LVPAD 8
+#define LVPAD_Q 0xF1
+#define LVPAD_T 0xF2
+struct LvBuf { uint8_t b[LVPAD + 16]; };
+DV void lvbuf_init(LvBuf &v, uint8_t pad) {
+#pragma unroll
+	for (int i = 0; i < LVPAD; i++) v.b[i] = pad;
+}
+
+// get_new_ed (src/cly.c:629-694).  The right-side query is copied out of the read (with its
+// preceding byte) so that lv_extd works on local strings only; the reference's in-place
+// sentinel write is restored before it returns, so this is equivalent.
+DV void get_new_ed(const DsbDevIndex *x, uint32_t *e_d, uint32_t *len_, uint32_t *l_mem_ext,
+                   int32_t q_off, uint64_t t_off, uint32_t l_read, const uint8_t *q_b, bool is_FWD)
+{
+	LvBuf qb, tb; lvbuf_init(qb, LVPAD_Q); lvbuf_init(tb, LVPAD_T);
+	uint8_t *q = qb.b + LVPAD, *t = tb.b + LVPAD;
+	uint32_t len, max_len;
+	const uint8_t *t_b = x->refbin;
+	const uint8_t *qp = q_b;   // right side: current query pointer inside the read
+	if (is_FWD) {
+		if (q_off < 0) q_off = 0;
+		max_len = q_off; len = MINV(12, max_len);
+		for (uint32_t k = 0; k < len; k++) q[k] = q_b[q_off - k];
+	} else {
+		max_len = l_read - q_off; len = MINV(12, max_len);
+		qp = q_b + q_off;
+		for (uint32_t k = 0; k < len; k++) q[k] = qp[k];
+	}
+	get_ref_small(t_b, t, t_off, len, !is_FWD);
+	if (len > 0 && t[0] == q[0]) {
+		int mtc;
+		do {
+			for (mtc = 0; mtc < len; mtc++) if (t[mtc] != q[mtc]) break;
+			if (mtc > 0) {
+				*l_mem_ext += mtc; max_len -= mtc; len = MINV(12, max_len);
+				if (is_FWD) { q_off -= mtc; t_off -= mtc; for (uint32_t k = 0; k < len; k++) q[k] = q_b[q_off - k]; }
+				else { t_off += mtc; qp += mtc; for (uint32_t k = 0; k < len; k++) q[k] = qp[k]; }
+				get_ref_small(t_b, t, t_off, len, !is_FWD);
+			}
+		} while (mtc > 0);
+	}
+	if (!is_FWD) q[-1] = qp[-1];          // the byte in front of a string inside the read is a real base
+	t[len] = '#'; q[len] = '$';
+	*e_d = lv_extd(t, len, q, len);
+	*len_ = len;
+}
+
+DV DsbAnchor *push_anchor(WCtx &w)
+{
+	if (w.n_anc >= DSB_ANC_CAP) { w.status |= DSB_ST_ANC_OVF; return w.anc + DSB_ANC_CAP - 1; }
+	return w.anc + w.n_anc++;
+}
+
+// map_seed (src/cly.c:706-939)
+DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, uint16_t seed_ID, uint8_t direction)
+{
+	const DsbDevIndex *x = w.x;
+	uint64_t b_p = m_r.sp; int32_t q_off = m_r.read_offset; uint32_t l_m = m_r.match_len;
+	const uint8_t *t_b = x->refbin;
+	int64_t uni = -1; uint32_t u_off = 0; uint64_t t_off = 0;
+	uint32_t l_pre, l_suf = 0, d_pre, d_suf = 0; int32_t s = 0, max_s = 0;
+	const int *Q_MEM = x->qmem; const int *Q_LV = x->qlv;
+	do {
+		LvBuf qpre, tpre, qsuf, tsuf;
+		lvbuf_init(qpre, LVPAD_Q); lvbuf_init(tpre, LVPAD_T); lvbuf_init(tsuf, LVPAD_T);
+		uint8_t *q_pre = qpre.b + LVPAD, *t_pre = tpre.b + LVPAD, *t_suf = tsuf.b + LVPAD, *q_sufb = qsuf.b + LVPAD;
+		l_pre = MINV(q_off + 1, 12);
+		for (uint32_t k = 0; k < l_pre; k++) q_pre[k] = q_b[q_off - (int)k];
+		int s_l = 0;
+		if (m_r.sa_sp != D_U64MAX) uni = get_uni(x, m_r.sa_sp, m_r.sa_sp_l, &t_off, &u_off);
+		else {
+			uint32_t ch; uint64_t new_sp;
+			while (1) {
+				if ((b_p & 7) == 0) break;
+				ch = 0xff;
+				new_sp = fm_occ(x, b_p, ch); new_sp += x->rank[ch];
+				if (ch == 4) break;
+				t_pre[s_l++] = ch; b_p = new_sp;
+				if (s_l >= l_pre) break;
+			}
+			if ((b_p & 7) == 0) uni = get_uni(x, b_p, s_l, &t_off, &u_off);
+			else l_pre = s_l;
+		}
+		if (uni >= 0) {
+			if (x->uni[uni].y < 35) break;
+			l_pre = MINV(l_pre, u_off);
+			get_ref_small(t_b, t_pre, t_off - 1, l_pre, false);
+		}
+		t_pre[l_pre] = '#'; q_pre[l_pre] = '$';
+		d_pre = lv_extd(t_pre, l_pre, q_pre, l_pre);
+		s = Q_MEM[l_m] + Q_LV[d_pre * 20 + l_pre];
+		if (s < 12 && l_pre == 12 && uni < 0) { s = 0; break; }
+		if (uni < 0) {
+			while (b_p & 7) { uint32_t ch = 0xff; uint64_t o = fm_occ(x, b_p, ch); b_p = o + x->rank[ch]; s_l++; }
+			uni = get_uni(x, b_p, s_l, &t_off, &u_off);
+			if (x->uni[uni].y < 35) { s = 0; break; }
+		}
+		int32_t q_off_r = q_off + l_m + 1;
+		uint32_t l_max_suf = MINV(x->uni[uni].y - u_off - l_m, read_L - q_off_r);
+		if (l_max_suf != 0) {
+			l_suf = MINV(l_max_suf, 12);
+			const uint8_t *q_suf = q_b + q_off_r;
+			get_ref_small(t_b, t_suf, t_off + l_m, l_suf, true);
+			if (t_suf[0] == q_suf[0]) {
+				int mtc;
+				do {
+					for (mtc = 0; mtc < l_suf; mtc++) if (t_suf[mtc] != q_suf[mtc]) break;
+					if (mtc > 0) {
+						l_m += mtc;
+						s = Q_MEM[l_m] + Q_LV[d_pre * 20 + l_pre];
+						l_max_suf -= mtc; l_suf = MINV(l_max_suf, 12); q_suf += mtc;
+						get_ref_small(t_b, t_suf, t_off + l_m, l_suf, true);
+					}
+				} while (mtc > 0);
+			}
+			for (int k = -1; k < (int)l_suf; k++) q_sufb[k] = q_suf[k];
+			t_suf[l_suf] = '#'; q_sufb[l_suf] = '$';
+			d_suf = lv_extd(t_suf, l_suf, q_sufb, l_suf);
+			s += Q_LV[d_suf * 20 + l_suf];
+		} else l_suf = d_suf = 0;
+		if (s <= 20 && l_suf == 12) { s = 0; break; }
+	} while (0);
+
+	if (s > 0) {
+		AMap a_m = {(uint16_t)l_m, (int16_t)s, (uint8_t)l_pre, (uint8_t)d_pre, (uint8_t)l_suf, (uint8_t)d_suf};
+		uint32_t rp_s = x->uni[uni].x, rp_e = x->uni[uni + 1].x;
+		bool ref_search_l = (l_pre < 12 || d_pre == 0), ref_search_r = (l_suf < 12 || d_suf == 0);
+		if ((int64_t)rp_e - (int64_t)rp_s > 50) { if (!((int64_t)rp_e - (int64_t)rp_s < 1000)) return 50; }
+		for (uint32_t r = rp_s; r < rp_e; r++) {
+			uint64_t rp = x->refpos[r];
+			uint64_t rp_go = rp & 0xFFFFFFFFFFULL; uint32_t rp_ref = (uint32_t)(rp >> 40) & 0x7FFFFF;
+			uint32_t ed_l, ed_r, len_l, len_r, l_m_ext_l = 0, l_m_ext_r;
+			if (ref_search_l || ref_search_r) {
+				if (ref_search_l) {
+					get_new_ed(x, &ed_l, &len_l, &l_m_ext_l, q_off, rp_go + u_off - 1, read_L, q_b, true);
+					a_m.left_len = len_l; a_m.left_ED = ed_l;
+				}
+				a_m.mtch_len = l_m + l_m_ext_l;
+				if (ref_search_r) {
+					l_m_ext_r = 0;
+					get_new_ed(x, &ed_r, &len_r, &l_m_ext_r, q_off + l_m + 1, rp_go + u_off + l_m, read_L, q_b, false);
+					a_m.rigt_len = len_r; a_m.rigt_ED = ed_r; a_m.mtch_len += l_m_ext_r;
+				}
+				a_m.score = Q_MEM[a_m.mtch_len] + Q_LV[a_m.left_ED * 20 + a_m.left_len] + Q_LV[a_m.rigt_ED * 20 + a_m.rigt_len];
+				if (a_m.score < 20) continue;
+			}
+			max_s = MAXV(max_s, a_m.score);
+			DsbAnchor *a = push_anchor(w);
+			a->direction = direction;
+			a->index_in_read = q_off + 1 - l_m_ext_l;
+			a->global_offset = rp_go + u_off - l_m_ext_l;
+			a->ref_ID = rp_ref;
+			a->ref_offset = (uint32_t)(a->global_offset - x->refinfo[rp_ref].seq_offset);
+			a->mtch_len = a_m.mtch_len; a->score = a_m.score; a->left_len = a_m.left_len; a->left_ED = a_m.left_ED;
+			a->rigt_len = a_m.rigt_len; a->rigt_ED = a_m.rigt_ED;
+			a->seed_ID = seed_ID; a->duplicate = 0; a->pre = -1; a->useless = 0; a->chain_id = 0; a->pad0 = 0;
+		}
+	}
+	return max_s;
+}
+
+// ---- seeds from the exist-kmer bit vector (search_exist_kmer_M2 + get_seed_vector_M2,
+// src/cly.c:1071-1234).  The probe kernel has answered get_exist_kmer for every window.
+DV int ebit(const uint64_t *bits, uint32_t i) { return (int)((bits[i >> 6] >> (i & 63)) & 1ULL); }
+
+DN void seed_vector(WCtx &w, uint8_t *bin, const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t direction, SDir *out)
+{
+	uint32_t ns = 0;
+	if (direction == D_FORWARD) {
+		for (uint32_t i = 3 - 1; i < n; i += 3) {
+			if (ebit(bits, i) == 1) {
+				uint32_t offset = i, len = 1;
+				for (int j = 1; j < 3; ++j) { if (ebit(bits, i - j) == 1) { offset--; len++; } else break; }
+				for (int j = 1; i + j < n; ++j) { if (ebit(bits, i + j) == 1) { len++; if (len > 60) break; } else break; }
+				sv[ns].offset = offset; sv[ns].len = len; ns++;
+				i = offset + len;
+			}
+		}
+	} else {
+		for (int i = n - 3; i >= 0; i -= 3) {
+			if (ebit(bits, i) == 1) {
+				uint32_t offset = i, len = 1;
+				for (int j = 1; j < 3; ++j) { if (ebit(bits, i + j) == 1) { offset++; len++; } else break; }
+				for (int j = 1; j <= i; ++j) { if (ebit(bits, i - j) == 1) { len++; if (len > 60) break; } else break; }
+				sv[ns].offset = offset - len + 1; sv[ns].len = len; ns++;
+				i = offset - len;
+			}
+		}
+	}
+	uint32_t total = 0; int max_index = 0; uint32_t max_length = 0, index_end = 100;
+	for (uint32_t m = 0; m < ns; m++) {
+		sv[m].top = 0;
+		uint32_t key = (direction == D_FORWARD) ? sv[m].offset : n - sv[m].offset - sv[m].len;
+		if (key < index_end) {
+			if (max_length < sv[m].len) { max_length = sv[m].len; max_index = m; }
+			sv[max_index].top = 0;
+		} else {
+			sv[max_index].top = 1; index_end += 100; total += max_length;
+			max_index = m; max_length = sv[m].len;
+		}
+	}
+	sv[max_index].top = 1;
+	total += max_length;
+	out->seed_v = sv; out->l_seed_v = ns; out->bin_read = bin; out->bits = bits; out->direction = direction; out->total_score = total;
+}
+
+// fast_classify (src/cly.c:1478-1546)
+DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
+{
+	const DsbDevIndex *x = w.x;
+	int l_ek = x->ek_len, min_index = 21 - l_ek;
+	uint8_t *bin_read = s_d->bin_read;
+	SpSet sp_set = {w.spset, 0, DSB_SPSET_CAP};
+	DsbMem m_r[2];
+	DsbSeed *sv_b = s_d->seed_v, *sv_e = sv_b + s_d->l_seed_v;
+	for (DsbSeed *c_sv = sv_b; c_sv < sv_e; c_sv++) {
+		if (c_sv->top == 0) continue;
+		sp_set.l = 0;
+		uint16_t seed_ID = (uint16_t)(c_sv - sv_b);
+		uint32_t a_b_idx = w.n_anc;
+		uint32_t sv_off = c_sv->offset;
+		for (int j = (int)c_sv->len - 1; j >= min_index;) {
+			if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; return; }
+			int kmer_index = sv_off + j;
+			int string_index = kmer_index + l_ek - 1;
+			uint64_t prefixValue = prefix13(bin_read, string_index);
+			int n = bwt_MEM_search(x, bin_read + string_index, prefixValue, 2, 21 - 1, string_index, sp_set, m_r);
+			if (n == 0) { j -= 2; continue; }
+			j -= 3;
+			int max_score = 0;
+			for (int q = 0; q < n; ++q) {
+				m_r[q].read_offset = string_index - m_r[q].match_len;
+				int sc = map_seed(w, m_r[q], bin_read, read_len, seed_ID, (uint8_t)s_d->direction);
+				max_score = MAXV(sc, max_score);
+			}
+			if (max_score > 35) j -= 7;
+			if (max_score > 256) { if (max_score > 512) c_sv++; break; }
+		}
+		int top_score = 35;
+		for (uint32_t i = a_b_idx; i < w.n_anc; i++) top_score = MAXV(top_score, w.anc[i].score);
+		for (uint32_t i = a_b_idx; i < w.n_anc; i++) w.anc[i].useless = (w.anc[i].score < top_score) ? 1 : 0;
+	}
+}
+
+// stable sort of the slow-path MEMs by match_len, descending (qsort at src/cly.c:1595 with a
+// proper comparator == any stable sort); insertion sort, the list is short
+DV void sort_mems(DsbMem *m, int n)
+{
+	for (int i = 1; i < n; i++) {
+		DsbMem v = m[i]; int j = i - 1;
+		while (j >= 0 && m[j].match_len < v.match_len) { m[j + 1] = m[j]; j--; }
+		m[j + 1] = v;
+	}
+}
+
+// slow_classify (src/cly.c:1550-1611)
+DN void slow_classify(WCtx &w, SDir *sd, uint32_t read_len)
+{
+	const DsbDevIndex *x = w.x;
+	int l_ek = x->ek_len; uint8_t *bin_read = sd->bin_read; DsbSeed *sv_f = sd->seed_v;
+	SpSet sp_set = {w.spset, 0, DSB_SPSET_CAP};
+	DsbMem *mem_rst = w.mem_slow; int mem_rst_num;
+	for (uint32_t i = 0; i < sd->l_seed_v; i++) {
+		if ((int)(sv_f[i].len) < 3 && sv_f->top == 0) continue;
+		int min_match_len = MINV(20 - 1, l_ek + 1);
+		sp_set.l = 0; mem_rst_num = 0;
+		for (int j = (int)sv_f[i].len - 1; j >= 1; j -= 2) {
+			if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; return; }
+			int k_idx = sv_f[i].offset + j;
+			int s_idx = k_idx + l_ek - 1;
+			uint64_t pre_v = prefix13(bin_read, s_idx);
+			int n = bwt_MEM_search(x, bin_read + s_idx, pre_v, 8, min_match_len, s_idx, sp_set, mem_rst + mem_rst_num);
+			for (int q = mem_rst_num; q < mem_rst_num + n; q++) mem_rst[q].read_offset = k_idx + l_ek - 1 - mem_rst[q].match_len;
+			mem_rst_num += n;
+		}
+		if (mem_rst_num == 0) continue;
+		if (mem_rst_num > 1) sort_mems(mem_rst, mem_rst_num);
+		uint32_t a_b_idx = w.n_anc;
+		int max_search = MINV(mem_rst_num, 8);
+		for (int q = 0; q < max_search; ++q) map_seed(w, mem_rst[q], bin_read, read_len, (uint16_t)i, (uint8_t)sd->direction);
+		int top_score = 35;
+		for (uint32_t q = a_b_idx; q < w.n_anc; q++) top_score = MAXV(top_score, w.anc[q].score);
+		for (uint32_t q = a_b_idx; q < w.n_anc; q++) w.anc[q].useless = (w.anc[q].score < top_score) ? 1 : 0;
+	}
+}
+
+// ---- chaining (src/cly.c:72-112,201-349) ------------------------------------------------------
+DV DsbChain *push_hit(WCtx &w)
+{
+	if (w.n_hit >= DSB_HIT_CAP) { w.status |= DSB_ST_HIT_OVF; return w.hit + DSB_HIT_CAP - 1; }
+	DsbChain *h = w.hit + w.n_hit++;
+	h->primary = 0; h->pri_index = 0;
+	return h;
+}
+DV void chain_insert_meta(WCtx &w, int32_t ai, DsbChain *c, bool new_chain, int dis_minus)
+{
+	DsbAnchor *anchor = w.anc + ai;
+	uint32_t ref_l = anchor->ref_offset, ref_r = ref_l + anchor->mtch_len;
+	uint32_t read_l = anchor->index_in_read, read_r = read_l + anchor->mtch_len;
+	if (new_chain) {
+		anchor->chain_id = c->chain_id; anchor->pre = -1;
+		c->ref_ID = anchor->ref_ID; c->direction = anchor->direction;
+		c->q_t_dis = anchor->ref_offset - anchor->index_in_read;
+		c->t_st = ref_l; c->t_ed = ref_r; c->q_st = read_l; c->q_ed = read_r;
+		c->with_top_anchor = !anchor->useless; c->anchor_number = 1;
+		c->sum_score = (anchor->duplicate) ? 1 : anchor->score;
+		c->indel = 0; c->cur = ai;
+	} else {
+		anchor->chain_id = c->chain_id;
+		c->with_top_anchor |= (!anchor->useless);
+		if (c->q_ed >= read_r) return;
+		c->t_ed = MAXV(ref_r, c->t_ed); c->q_ed = read_r;
+		anchor->pre = c->cur; c->cur = ai;
+		c->q_t_dis = anchor->ref_offset - anchor->index_in_read;
+		c->indel += dis_minus; c->anchor_number++;
+		c->sum_score += (anchor->duplicate) ? 1 : anchor->score;
+	}
+}
+DV void chain_insert_M2(WCtx &w, int32_t ai)
+{
+	DsbAnchor *anchor = w.anc + ai;
+	uint8_t direction = anchor->direction; uint32_t ref_ID = anchor->ref_ID;
+	int32_t dis = anchor->ref_offset - anchor->index_in_read; int dis_minus = 0;
+	for (uint32_t i = 0; i < w.n_hit; i++) {
+		DsbChain *c_s = w.hit + i;
+		if (c_s->direction == direction && c_s->ref_ID == ref_ID && (dis_minus = ABSV(dis - c_s->q_t_dis)) < 30 &&
+		    ABS_U(c_s->t_ed, anchor->ref_offset) < 400) { chain_insert_meta(w, ai, c_s, false, dis_minus); return; }
+	}
+	DsbChain *n = push_hit(w);
+	n->chain_id = w.n_hit - 1;
+	chain_insert_meta(w, ai, n, true, dis_minus);
+}
+
+// stable ascending sort of n (key, idx) pairs, bottom-up merge; result index order in the returned buffer.
+// Any stable sort equals glibc's merge sort for a consistent comparator.
+DN uint32_t *stable_sort_keys(WCtx &w, uint32_t n)
+{
+	uint64_t *ka = w.sortkey, *kb = w.sortkey + DSB_ANC_CAP;
+	uint32_t *ia = w.sortidx, *ib = w.sortidx + DSB_ANC_CAP;
+	for (uint32_t width = 1; width < n; width <<= 1) {
+		// lanes take whole merges; each merge is independent
+		uint32_t n_merge = (n + 2 * width - 1) / (2 * width);
+		for (uint32_t mi = w.lane; mi < n_merge; mi += DSB_WAVE) {
+			uint32_t lo = mi * 2 * width, mid = MINV(lo + width, n), hi = MINV(lo + 2 * width, n);
+			uint32_t i = lo, j = mid, o = lo;
+			while (i < mid && j < hi) {
+				if (ka[i] <= ka[j]) { kb[o] = ka[i]; ib[o] = ia[i]; i++; } else { kb[o] = ka[j]; ib[o] = ia[j]; j++; }
+				o++;
+			}
+			while (i < mid) { kb[o] = ka[i]; ib[o] = ia[i]; i++; o++; }
+			while (j < hi) { kb[o] = ka[j]; ib[o] = ia[j]; j++; o++; }
+		}
+		wave_sync();
+		uint64_t *tk = ka; ka = kb; kb = tk; uint32_t *ti = ia; ia = ib; ib = ti;
+	}
+	return ia;
+}
+
+// chain_insert_M3 (src/cly.c:238-323): stable sort by (ref_ID, direction, ref_offset), then sparse DP per group
+DN void chain_insert_M3(WCtx &w)
+{
+	DsbAnchor *A = w.anc; int32_t n = w.n_anc;
+	for (int32_t i = w.lane; i < n; i += DSB_WAVE) {
+		w.sortkey[i] = ((uint64_t)A[i].ref_ID << 33) | ((uint64_t)A[i].direction << 32) | A[i].ref_offset;
+		w.sortidx[i] = i;
+	}
+	wave_sync();
+	uint32_t *ord = stable_sort_keys(w, n);
+	for (int32_t i = w.lane; i < n; i += DSB_WAVE) w.anc_tmp[i] = A[ord[i]];
+	wave_sync();
+	for (int32_t i = w.lane; i < n; i += DSB_WAVE) A[i] = w.anc_tmp[i];
+	wave_sync();
+	int *score_v = w.score_v;
+	for (int32_t st = 0; st < n;) {
+		int32_t ed = st + 1;
+		uint32_t ref_ID = A[st].ref_ID, direction = A[st].direction;
+		for (; ed < n && A[ed].ref_ID == ref_ID && A[ed].direction == direction && A[ed].ref_offset - A[ed - 1].ref_offset < 2000; ed++);
+		if (ed - st > 1024) ed = st + 1024;
+		int32_t max_anchor = -1; int max_score = 0, ams;
+		for (int32_t ca = st; ca < ed; ca++) {
+			int32_t best_pre = -1; ams = A[ca].score;
+			uint32_t max_t = A[ca].ref_offset + 3, max_q = A[ca].index_in_read + 3; uint32_t ca_ml = A[ca].mtch_len;
+			for (int32_t p = ca - 1; p >= st; p--) {
+				uint32_t p_q = A[p].index_in_read, p_t = A[p].ref_offset, p_ml = A[p].mtch_len;
+				if (p_q + p_ml > max_q) continue;
+				if (p_t + p_ml > max_t) continue;
+				if (p_q + 1000 < max_q) break;
+				if (p_t + 1000 < max_t) break;
+				int indel = p_q - p_t - (max_q - max_t);
+				int ai = ABSV(indel);
+				if (ai > 200) continue;
+				int ns = score_v[p - st] + ca_ml - (ai >> 4) - ((max_q - p_q) >> 8);
+				if (ns > ams) { ams = ns; best_pre = p; }
+			}
+			A[ca].pre = best_pre;
+			score_v[ca - st] = ams;
+			if (max_score < ams) { max_score = ams; max_anchor = ca; }
+		}
+		int sum_INDEL = 0, anchor_number = 1; int32_t pre = max_anchor;
+		int sum_score = (A[max_anchor].duplicate) ? 1 : A[max_anchor].score;
+		bool with_top = !A[max_anchor].useless;
+		for (; A[pre].pre != -1; anchor_number++) {
+			int32_t pre_ = A[pre].pre;
+			sum_INDEL += (A[pre].index_in_read - A[pre_].index_in_read) - (A[pre].ref_offset - A[pre_].ref_offset);
+			with_top |= (!A[pre].useless);
+			sum_score += (A[pre].duplicate) ? 1 : A[pre].score;
+			pre = pre_;
+		}
+		DsbChain *nc = push_hit(w);
+		nc->chain_id = w.n_hit - 1; nc->ref_ID = ref_ID; nc->direction = direction;
+		nc->q_t_dis = A[max_anchor].ref_offset - A[max_anchor].index_in_read;
+		nc->t_st = A[pre].ref_offset; nc->t_ed = A[max_anchor].ref_offset + A[max_anchor].mtch_len;
+		nc->q_st = A[pre].index_in_read; nc->q_ed = A[max_anchor].index_in_read + A[max_anchor].mtch_len;
+		nc->with_top_anchor = with_top; nc->anchor_number = anchor_number; nc->sum_score = sum_score;
+		nc->indel = sum_INDEL; nc->cur = max_anchor;
+		st = ed;
+	}
+}
+
+// comparators on chains
+DV int chain_cmp_by_score(const DsbChain *a, const DsbChain *b)
+{	// src/cly.c:38-52
+	if (a->with_top_anchor != b->with_top_anchor) return (a->with_top_anchor) ? (-1) : (1);
+	int sa = a->sum_score + ((a->q_ed - a->q_st) << 1); sa -= (a->indel << 2);
+	int sb = b->sum_score + ((b->q_ed - b->q_st) << 1); sb -= (b->indel << 2);
+	if (sa < sb) return 1;
+	if (sa > sb) return -1;
+	return 0;
+}
+DV int chain_cmp_by_pos(const DsbChain *a, const DsbChain *b)
+{	// src/cly.c:2853-2870
+	if (a->ref_ID > b->ref_ID) return 1;
+	if (a->ref_ID < b->ref_ID) return -1;
+	if (a->t_st > b->t_st) return 1;
+	if (a->t_st < b->t_st) return -1;
+	if (a->sum_score < b->sum_score) return 1;
+	if (a->sum_score > b->sum_score) return -1;
+	return 0;
+}
+DV int chain_cmp_by_MEM_score(const DsbChain *a, const DsbChain *b)
+{	// src/cly.c:54-64: the tie-break is not symmetric, so the merge tree below must be glibc's
+	int sa = (a->sum_score << 5), sb = (b->sum_score << 5);
+	if (sa < sb) return 1;
+	if (sa > sb) return -1;
+	return (a->sum_score % 2);
+}
+
+// glibc qsort == top-down merge sort: n1 = n/2, merge takes left when cmp(l,r) <= 0.
+// Iterative post-order walk of exactly that tree; chains are moved through hit_tmp.
+template <int WHICH>
+DN void glibc_sort_chains(WCtx &w, uint32_t n)
+{
+	if (n <= 1) return;
+	DsbChain *b = w.hit, *t = w.hit_tmp;
+	struct Fr { uint32_t lo, n; uint32_t st; } stk[16];
+	int sp = 0;
+	stk[0].lo = 0; stk[0].n = n; stk[0].st = 0; sp = 1;
+	while (sp > 0) {
+		Fr &f = stk[sp - 1];
+		if (f.n <= 1) { sp--; continue; }
+		uint32_t n1 = f.n / 2, n2 = f.n - n1;
+		if (f.st == 0) { f.st = 1; stk[sp].lo = f.lo; stk[sp].n = n1; stk[sp].st = 0; sp++; continue; }
+		if (f.st == 1) { f.st = 2; stk[sp].lo = f.lo + n1; stk[sp].n = n2; stk[sp].st = 0; sp++; continue; }
+		// merge
+		uint32_t i = f.lo, j = f.lo + n1, ie = f.lo + n1, je = f.lo + f.n, o = 0;
+		while (i < ie && j < je) {
+			int c = WHICH == 0 ? chain_cmp_by_score(b + i, b + j) : WHICH == 1 ? chain_cmp_by_pos(b + i, b + j) : chain_cmp_by_MEM_score(b + i, b + j);
+			if (c <= 0) t[o++] = b[i++]; else t[o++] = b[j++];
+		}
+		while (i < ie) t[o++] = b[i++];
+		// the rest of the right half is already in place
+		for (uint32_t q = 0; q < o; q++) b[f.lo + q] = t[q];
+		sp--;
+	}
+}
+
+// resolve_tree (src/cly.c:326-349)
+DN void resolve_tree(WCtx &w)
+{
+	w.n_hit = 0;
+	if (w.n_anc < 50) for (uint32_t i = 0; i < w.n_anc; i++) chain_insert_M2(w, i);
+	else chain_insert_M3(w);
+	if (w.n_hit > 1) glibc_sort_chains<0>(w, w.n_hit);
+	int rst_num = MINV(5, w.n_hit);
+	while (rst_num < w.n_hit && w.hit[rst_num].with_top_anchor == 1) rst_num++;
+	w.n_hit = rst_num;
+}
+
+// ---- sc_hash_idx / combine_chain (src/cly.c:1691-1710,1763-1808) -------------------------------
+DV void sc_hash_idx(DsbScHash *sc, DsbChain *hit, uint32_t n_hit)
+{
+	for (int i = 0; i < 256; i++) { sc[i].next = 0; sc[i].seed_ID = 0; }
+	int con = 256;
+	for (uint32_t h = 0; h < n_hit; h++)
+		for (int i = 1; i >= 0; i--) {
+			uint16_t key = ((i == 1) ? (hit[h].t_st - hit[h].q_st) : (hit[h].t_ed - hit[h].q_ed)) & 0xff;
+			while (sc[key].next != 0) key = sc[key].next;
+			sc[key].seed_ID = (uint16_t)((h + 1) | (i << 15)); sc[key].next = con;
+			sc[con++].next = 0;
+		}
+}
+DV bool combine_chain(DsbChain *c_st, int chain_ID, DsbScHash *sc, int dis, bool isleft, int c_q_pos, DsbChain **combined)
+{
+	uint16_t key = (dis) & 0xff;
+	DsbChain *c, *c_h = c_st + chain_ID;
+	while (sc[key].next != 0) {
+		uint16_t seed_ID = sc[key].seed_ID & 0x7fff; int s_or_e = sc[key].seed_ID >> 15;
+		c = c_st + seed_ID - 1;
+		int dis_con = (isleft) ? (c->t_ed - c->q_ed) : (c->t_st - c->q_st);
+		int q_pos_con = (!isleft) ? (c->q_st) : (c->q_ed - 9);
+		if (dis == dis_con && c_h != c && (int)isleft != s_or_e && ABS_U(c_q_pos, q_pos_con) < 8 &&
+		    c_h->ref_ID == c->ref_ID && c_h->direction == c->direction && c->sum_score != 0 && seed_ID - 1 > chain_ID) {
+			c_h->sum_score += c->sum_score; c_h->anchor_number += c->anchor_number; c_h->indel += c->indel;
+			c_h->q_st = MINV(c_h->q_st, c->q_st); c_h->t_st = MINV(c_h->t_st, c->t_st);
+			c_h->q_ed = MAXV(c_h->q_ed, c->q_ed); c_h->t_ed = MAXV(c_h->t_ed, c->t_ed);
+			c->sum_score = 0; c->t_st = c->t_ed = c->q_st = c->q_ed = 0;
+			*combined = c;
+			return true;
+		}
+		key = sc[key].next;
+	}
+	return false;
+}
+
+// ---- per-read 9-mer table (build_hash_table_M2, src/cly.c:2173-2224).
+// Same contents as the reference's chained hash -- for every key the read positions in ascending
+// order -- in a layout the wave can build in parallel: head[key] / next[pos] hold pos+1 (0 = end),
+// kmer[pos] the 18-bit 9-mer.  Positions are inserted 64 at a time from the end of the read; lanes
+// with equal keys inside a group are linked in lane order, the lowest becomes the new head.
+DN int build_hash_table_M2(WCtx &w, SDir *sd, int q_len)
+{
+	int both_dir = 0;
+	for (uint32_t i = 0; i < w.n_hit; i++) { both_dir |= (w.hit[i].direction == D_FORWARD) ? 0x2 : 0x1; if (both_dir == 3) break; }
+	int key_len = 10;
+	for (; key_len < 18; key_len++) if ((1u << key_len) >= (uint32_t)q_len) break;
+	uint32_t KEY_MASK = (1u << key_len) - 1u;
+	int n9 = q_len - 9 + 1;
+	for (int c_dir = 2; c_dir >= 1; c_dir--) {
+		if ((c_dir & both_dir) == 0) continue;
+		uint32_t direction = (c_dir == 1) ? D_REVERSE : D_FORWARD;
+		SDir *csd = ((sd->direction == direction) ? 0 : 1) + sd;
+		int t = (c_dir == 2) ? 0 : 1;
+		uint32_t *head = w.kh_head[t], *next = w.kh_next[t], *km = w.kh_kmer[t];
+		const uint8_t *q = csd->bin_read;
+		for (uint32_t i = w.lane; i < (1u << key_len); i += DSB_WAVE) head[i] = 0;
+		for (int pos = w.lane; pos < n9; pos += DSB_WAVE) {
+			uint32_t k = 0;
+#pragma unroll
+			for (int b = 0; b < 9; b++) k = (k << 2) | q[pos + b];
+			km[pos] = k;
+		}
+		wave_sync();
+		for (int base = ((n9 - 1) / DSB_WAVE) * DSB_WAVE; base >= 0; base -= DSB_WAVE) {
+			int pos = base + w.lane; bool valid = pos < n9;
+			uint32_t key = valid ? (km[pos] & KEY_MASK) : 0xffffffffu;
+			uint64_t todo = dsb_ballot(valid);
+			int nxt_lane = -1; bool lowest = false;
+			while (todo) {
+				int leader = __builtin_ctzll(todo);
+				uint32_t lk = dsb_shfl(key, leader);
+				uint64_t m = dsb_ballot(valid && key == lk);
+				if (valid && key == lk) {
+					uint64_t hi = (w.lane == 63) ? 0ULL : (m & ~((2ULL << w.lane) - 1ULL));
+					nxt_lane = hi ? __builtin_ctzll(hi) : -1;
+					lowest = (__builtin_ctzll(m) == w.lane);
+				}
+				todo &= ~m;
+			}
+			if (valid) {
+				next[pos] = (nxt_lane >= 0) ? (uint32_t)(base + nxt_lane + 1) : head[key];
+			}
+			wave_sync();
+			if (valid && lowest) head[key] = pos + 1;
+			wave_sync();
+		}
+	}
+	return key_len;
+}
+
+DV int MEM_search(const uint8_t *q, const uint8_t *t, bool forward, int max)
+{	// src/cly.c:1810-1818
+	int len = 0;
+	if (forward) for (; len < max && *q++ == *t++; len++);
+	else for (; len < max && *q-- == *t--; len++);
+	return len;
+}
+DV DsbSms *push_sms(WCtx &w)
+{
+	if (w.n_sms >= DSB_SMS_CAP) { w.status |= DSB_ST_SMS_OVF; return w.sms + DSB_SMS_CAP - 1; }
+	return w.sms + w.n_sms++;
+}
+DV uint64_t bin2kmer9(const uint8_t *s) { uint64_t v = 0;
+#pragma unroll
+	for (int i = 0; i < 9; i++) v = (v << 2) | s[i];
+	return v; }
+
+// sdp_match (src/cly.c:2335-2440)
+DN void sdp_match(WCtx &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len, int key_len,
+                  int tbl, uint32_t t_st, bool isForward)
+{
+	const uint32_t *head = w.kh_head[tbl], *nextv = w.kh_next[tbl], *km = w.kh_kmer[tbl];
+	uint64_t KEY_MASK = (1ULL << key_len) - 1;
+	uint32_t t_kmer_num = t_len - 9 + 1;
+	if (isForward) {
+		uint64_t MASK = (1ULL << 18) - 1;
+		const uint8_t *c_t = t_str + 4;
+		uint64_t kmer = bin2kmer9(c_t) >> 2;
+		for (int i = 4; (uint32_t)i < t_kmer_num; i++, c_t++) {
+			kmer = ((kmer << 2) | c_t[8]) & MASK;
+			if ((i & 3) != 0) continue;
+			uint32_t next = head[kmer & KEY_MASK];
+			while (next != 0) {
+				if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; return; }
+				uint32_t q_pos = next - 1;
+				if (km[q_pos] == kmer) {
+					if (q_pos >= q_bg && q_pos <= q_ed) {
+						int back_len = MEM_search(q_str + q_pos - 1, c_t - 1, false, 4);
+						if (back_len < 4 || i == 4) {
+							uint32_t max_search = q_ed - q_pos - 1;
+							max_search = MINV(max_search, t_len - i - 1) + 50;
+							int fwd = MEM_search(q_str + q_pos + 9, c_t + 9, true, max_search);
+							int total = back_len + fwd + 1;
+							if (total >= 4) { DsbSms *p = push_sms(w); p->len = total; p->q_pos = q_pos - back_len; p->t_pos = i - back_len + t_st; }
+						}
+					}
+				}
+				next = nextv[q_pos];
+			}
+		}
+	} else {
+		const uint8_t *c_t = t_str + t_len - 9 - 4;
+		uint64_t kmer = bin2kmer9(c_t) << 2;
+		for (int i = 4; (uint32_t)i < t_kmer_num; i++, c_t--) {
+			kmer = (kmer >> 2) | ((uint64_t)c_t[0] << 16);
+			if ((i & 3) != 0) continue;
+			uint32_t next = head[kmer & KEY_MASK];
+			while (next != 0) {
+				if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; return; }
+				uint32_t q_pos = next - 1;
+				if (km[q_pos] == kmer) {
+					if (q_pos >= q_bg && q_pos <= q_ed) {
+						int fwd = MEM_search(q_str + q_pos + 9, c_t + 9, true, 4);
+						if (fwd < 4 || i == 4) {
+							uint32_t max_search = q_pos;
+							max_search = MINV((long)max_search, (long)(c_t - t_str)) + 50;
+							int back_len = MEM_search(q_str + q_pos - 1, c_t - 1, false, max_search);
+							int total = back_len + fwd + 1;
+							if (total >= 4) { DsbSms *p = push_sms(w); p->len = total; p->q_pos = q_pos - back_len; p->t_pos = (uint32_t)((long)(c_t - t_str) - back_len + t_st); }
+						}
+					}
+				}
+				next = nextv[q_pos];
+			}
+		}
+	}
+}
+
+DV void fill_window(const WCtx &w, uint8_t *win, int n)
+{
+	for (int i = w.lane; i < n; i += DSB_WAVE) win[i] = DSB_TPAD_VAL;
+}
+
+// sdp_middle_M2 (src/cly.c:2444-2530)
+DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int key_len)
+{
+	const DsbDevIndex *x = w.x;
+	int score = 10000;
+	const DsbAnchor *A = w.anc;
+	uint64_t t_offset = x->refinfo[A[c_a].ref_ID].seq_offset;
+	int32_t pre_a = -1;
+	while (c_a != -1) {
+		pre_a = A[c_a].pre;
+		if (pre_a != -1) {
+			int pre_mch = A[pre_a].mtch_len;
+			int pre_refoffset = A[pre_a].ref_offset - 3;
+			int total_ref_len = A[c_a].ref_offset - (pre_refoffset + pre_mch) + 3;
+			w.n_sms = 0;
+			DsbSms *p = push_sms(w);
+			p->score = score; p->q_pos = A[pre_a].index_in_read; p->t_pos = A[pre_a].ref_offset; p->len = A[pre_a].mtch_len - 9 + 1;
+			if (total_ref_len > 12) {
+				uint8_t *ref = w.win_mid;
+				fill_window(w, ref, 2000 + 128);
+				wave_sync();
+				uint64_t ref_offset = pre_refoffset + t_offset + pre_mch;
+				get_ref_wave(w, ref, ref_offset, total_ref_len);
+				wave_sync();
+				sdp_match(w, A[pre_a].index_in_read + pre_mch - 8, A[c_a].index_in_read - 1, q_str, ref, total_ref_len, key_len, tbl,
+				          pre_refoffset + pre_mch, true);
+			}
+			p = push_sms(w);
+			p->q_pos = A[c_a].index_in_read; p->t_pos = A[c_a].ref_offset; p->len = A[c_a].mtch_len - 9 + 1;
+			if (w.n_sms > 1) {
+				DsbSms *S = w.sms;
+				for (uint32_t ci = 1; ci < w.n_sms; ci++) {
+					DsbSms cs = S[ci];
+					int max_score = cs.len;
+					uint32_t max_q = cs.q_pos + 6, max_t = cs.t_pos + 6;
+					for (int32_t pi = (int32_t)ci - 1; pi >= 0; pi--) {
+						DsbSms ps = S[pi];
+						int pre_q_ed = ps.q_pos + ps.len + 9 - 1, pre_t_ed = ps.t_pos + ps.len + 9 - 1;
+						if ((uint32_t)pre_q_ed > max_q) continue;
+						if ((uint32_t)pre_t_ed > max_t) continue;
+						int indel = ps.q_pos - ps.t_pos - (max_q - max_t);
+						int ai = ABSV(indel);
+						if (ai > 200) continue;
+						int ns = ps.score + cs.len - (ai >> 3);
+						if ((uint32_t)pre_q_ed > cs.q_pos || (uint32_t)pre_t_ed > cs.t_pos) {
+							int oq = pre_q_ed - cs.q_pos, ot = pre_t_ed - cs.t_pos;
+							ns -= MAXV(oq, ot);
+						}
+						max_score = MAXV(max_score, ns);
+					}
+					score = MAXV(max_score, score);
+					S[ci].score = max_score;
+				}
+			}
+		} else score += A[c_a].mtch_len - 9 + 1;
+		c_a = pre_a;
+	}
+	return score - 10000;
+}
+
+// sdp_right_M2 (src/cly.c:2532-2677)
+DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain *c_st, int chain_ID, uint32_t l_read, DsbScHash *sc_hash, int score_ori)
+{
+	const DsbDevIndex *x = w.x;
+	score_ori += 10000;
+	int total_max_score = score_ori, max_sms_id = 0;
+	DsbChain *c_h = c_st + chain_ID, *combined;
+	w.n_sms = 0;
+	uint8_t *ref = w.win_right;
+	fill_window(w, ref, 1000 + 128);
+	wave_sync();
+	DsbSms *p = push_sms(w);
+	p->score = score_ori; p->q_pos = c_h->q_ed; p->t_pos = c_h->t_ed; p->len = 1 - 9;
+	uint32_t current_sms = 1;
+	uint64_t t_offset_global = x->refinfo[c_h->ref_ID].seq_offset, t_length = x->refinfo[c_h->ref_ID].seq_l;
+	uint32_t c_t_offset = c_h->t_ed - 3;
+	int last_search = false;
+	while (1) {
+		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
+		if (w.n_sms == current_sms) {
+			uint32_t next_step = t_length - c_t_offset;
+			if (next_step < 12) break;
+			uint32_t max_search_ref;
+			if (l_read - c_h->q_ed < 600) {
+				if (last_search == true) break;
+				last_search = true;
+				max_search_ref = l_read - c_h->q_ed + 60;
+			} else max_search_ref = t_length - c_t_offset;
+			max_search_ref = MINV(600u, max_search_ref);
+			get_ref_wave(w, ref, c_t_offset + t_offset_global, max_search_ref + 50);
+			wave_sync();
+			int search_q_ed = (int)w.sms[max_sms_id].q_pos + 1000;
+			search_q_ed = MINV((uint32_t)search_q_ed, l_read);
+			int search_q_st = MAXV((uint32_t)(search_q_ed - 2000), c_h->q_st - 8);
+			sdp_match(w, search_q_st, search_q_ed, q_str, ref, max_search_ref, key_len, tbl, c_t_offset, true);
+			c_t_offset += max_search_ref - 9 - 3;
+			if (w.n_sms == current_sms) break;
+			if (w.sms[current_sms].t_pos > w.sms[max_sms_id].t_pos + 1000) break;
+		}
+		DsbSms *c_sms = w.sms + current_sms++;
+		DsbSms cs = *c_sms;
+		int max_score = cs.len;
+		uint32_t max_pre_q = cs.q_pos + 6, max_pre_t = cs.t_pos + 6;
+		w.steps += current_sms >> 3;
+		for (int32_t pi = (int32_t)current_sms - 2; pi >= 0; pi--) {
+			DsbSms ps = w.sms[pi];
+			int pre_q_ed = ps.q_pos + ps.len + 9 - 1, pre_t_ed = ps.t_pos + ps.len + 9 - 1;
+			if ((uint32_t)pre_q_ed > max_pre_q) continue;
+			if ((uint32_t)pre_t_ed > max_pre_t) continue;
+			if (ps.t_pos + 600 < max_pre_t) break;
+			int indel = ps.q_pos - ps.t_pos - (max_pre_q - max_pre_t);
+			int ai = ABSV(indel);
+			if (ai > 200) continue;
+			int ns = ps.score + cs.len - (ai >> 3);
+			if ((uint32_t)pre_q_ed > cs.q_pos || (uint32_t)pre_t_ed > cs.t_pos) {
+				int oq = pre_q_ed - cs.q_pos, ot = pre_t_ed - cs.t_pos;
+				ns -= MAXV(oq, ot);
+			}
+			max_score = MAXV(max_score, ns);
+		}
+		c_sms->score = max_score;
+		if ((int)cs.len >= 8 && combine_chain(c_st, chain_ID, sc_hash, cs.t_pos - cs.q_pos, false, cs.q_pos, &combined) == true) {
+			int c_len = cs.len;
+			total_max_score = MAXV(score_ori, max_score) - c_len + sdp_middle_M2(w, combined->cur, q_str, tbl, key_len);
+			score_ori = total_max_score; max_sms_id = 0;
+			w.n_sms = 0;
+			p = push_sms(w);
+			p->score = total_max_score; p->q_pos = c_h->q_ed; p->t_pos = c_h->t_ed; p->len = -9;
+			current_sms = 1;
+			c_t_offset = c_h->t_ed;
+			continue;
+		}
+		if (total_max_score < max_score) { total_max_score = max_score; max_sms_id = current_sms - 1; }
+		if (cs.t_pos > w.sms[max_sms_id].t_pos + 1000) break;
+	}
+	c_h->q_ed = w.sms[max_sms_id].q_pos + w.sms[max_sms_id].len + 9;
+	c_h->t_ed = w.sms[max_sms_id].t_pos + w.sms[max_sms_id].len + 9;
+	return total_max_score - 10000;
+}
+
+// sdp_left_M2 (src/cly.c:2679-2819)
+DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain *c_st, int chain_ID, uint32_t l_read, DsbScHash *sc_hash, int score_ori)
+{
+	const DsbDevIndex *x = w.x;
+	score_ori += 10000;
+	int total_max_score = score_ori, max_sms_id = 0;
+	DsbChain *c_h = c_st + chain_ID, *combined;
+	w.n_sms = 0;
+	uint8_t *ref = w.win_left;
+	fill_window(w, ref, 1000 + 128);
+	wave_sync();
+	DsbSms *p = push_sms(w);
+	p->score = score_ori; p->q_pos = c_h->q_st; p->t_pos = c_h->t_st;
+	uint32_t current_sms = 1;
+	uint64_t t_offset_global = x->refinfo[c_h->ref_ID].seq_offset;
+	uint32_t c_t_offset = c_h->t_st + 3;
+	int last_search = false;
+	while (1) {
+		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
+		if (w.n_sms == current_sms) {
+			uint32_t next_step = c_t_offset;
+			if (next_step < 12) break;
+			uint32_t max_search_ref;
+			if (c_h->q_st < 600) {
+				if (last_search == true) break;
+				last_search = true;
+				max_search_ref = c_h->q_st + 60;
+			} else max_search_ref = c_t_offset;
+			max_search_ref = MINV(600u, max_search_ref);
+			if (t_offset_global == 0 && c_t_offset < 50 + max_search_ref)
+				get_ref_wave(w, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref), max_search_ref);
+			else
+				get_ref_wave(w, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref - 50), max_search_ref + 50);
+			wave_sync();
+			int search_q_st = (int)w.sms[max_sms_id].q_pos - 1000;
+			search_q_st = MAXV(search_q_st, 0);
+			int search_q_ed = MINV((uint32_t)(search_q_st + 2000), c_h->q_st - 1);
+			sdp_match(w, search_q_st, search_q_ed, q_str, ref + 50, max_search_ref, key_len, tbl, c_t_offset - max_search_ref, false);
+			c_t_offset = c_t_offset - max_search_ref + 9 + 3;
+			if (w.n_sms == current_sms) break;
+			if (w.sms[current_sms].t_pos + 1000 < w.sms[max_sms_id].t_pos) break;
+		}
+		DsbSms *c_sms = w.sms + current_sms++;
+		DsbSms cs = *c_sms;
+		int max_score = cs.len;
+		uint32_t min_pre_q = cs.q_pos + cs.len - 6 + 9 - 1, min_pre_t = cs.t_pos + cs.len - 6 + 9 - 1;
+		w.steps += current_sms >> 3;
+		for (int32_t pi = (int32_t)current_sms - 2; pi >= 0; pi--) {
+			DsbSms ps = w.sms[pi];
+			if (ps.q_pos < min_pre_q) continue;
+			if (ps.t_pos < min_pre_t) continue;
+			if (min_pre_t + 600 < ps.t_pos) break;
+			int indel = ps.q_pos - ps.t_pos - (min_pre_q - min_pre_t);
+			int ai = ABSV(indel);
+			if (ai > 200) continue;
+			int ns = ps.score + cs.len - (ai >> 3);
+			if (min_pre_q + 6 > ps.q_pos || min_pre_t + 6 > ps.t_pos) {
+				int oq = min_pre_q + 6 - ps.q_pos, ot = min_pre_t + 6 - ps.t_pos;
+				ns -= MAXV(oq, ot);
+			}
+			max_score = MAXV(max_score, ns);
+		}
+		c_sms->score = max_score;
+		if ((int)cs.len >= 8 && combine_chain(c_st, chain_ID, sc_hash, cs.t_pos - cs.q_pos, true, cs.q_pos + cs.len, &combined) == true) {
+			int c_len = cs.len;
+			total_max_score = MAXV(score_ori, max_score) - c_len + sdp_middle_M2(w, combined->cur, q_str, tbl, key_len);
+			score_ori = total_max_score; max_sms_id = 0;
+			w.n_sms = 0;
+			p = push_sms(w);
+			p->score = total_max_score; p->q_pos = c_h->q_st; p->t_pos = c_h->t_st;
+			current_sms = 1;
+			c_t_offset = c_h->t_st;
+			continue;
+		}
+		if (total_max_score < max_score) { total_max_score = max_score; max_sms_id = current_sms - 1; }
+		if (cs.t_pos + 1000 < w.sms[max_sms_id].t_pos) break;
+	}
+	c_h->q_st = w.sms[max_sms_id].q_pos;
+	c_h->t_st = w.sms[max_sms_id].t_pos;
+	return total_max_score - 10000;
+}
+
+// get_score_M2 (src/cly.c:2821-2849)
+DN void get_score_M2(WCtx &w, SDir *sd, uint32_t l_read, DsbScHash *sc_hash)
+{
+	MARK(w, 50);
+	int key_len = build_hash_table_M2(w, sd, l_read);
+	MARK(w, 51);
+	DsbChain *H = w.hit;
+	for (uint32_t i = 0; i < w.n_hit; i++) {
+		if (H[i].sum_score == 0) continue;
+		SDir *csd = ((sd->direction == H[i].direction) ? 0 : 1) + sd;
+		int tbl = (H[i].direction == D_FORWARD) ? 0 : 1;
+		MARK(w, 52);
+		int score = sdp_middle_M2(w, H[i].cur, csd->bin_read, tbl, key_len);
+		MARK(w, 53);
+		score = sdp_right_M2(w, csd->bin_read, tbl, key_len, H, i, l_read, sc_hash, score);
+		MARK(w, 54);
+		score = sdp_left_M2(w, csd->bin_read, tbl, key_len, H, i, l_read, sc_hash, score);
+		MARK(w, 55);
+		H[i].sum_score = score;
+	}
+}
+
+// delete_small_score_rst (src/cly.c:2883-2993)
+DN void delete_small_score_rst(WCtx &w, SDir *sd, uint32_t l_read)
+{
+	const DsbDevIndex *x = w.x;
+	if (w.n_hit == 0) return;
+	if (w.n_hit > 200) {
+		uint32_t r = 200;
+		for (; r < w.n_hit && w.hit[r].sum_score > 50; r++);
+		w.n_hit = r;
+	}
+	w.n_hit = MINV(400u, w.n_hit);
+	sc_hash_idx(w.sc, w.hit, w.n_hit);
+	get_score_M2(w, sd, l_read, w.sc);
+	DsbChain *st_c = w.hit, *ed_c = st_c + w.n_hit, *c_c;
+	if (w.n_hit > 1) glibc_sort_chains<1>(w, w.n_hit);
+	for (c_c = st_c; c_c < ed_c - 1; c_c++) {
+		if (c_c->sum_score == 0) continue;
+		DsbChain *nx = c_c + 1;
+		for (; nx < ed_c; nx++) {
+			if (c_c->ref_ID == nx->ref_ID) {
+				if (c_c->direction != nx->direction) continue;
+				if (nx->sum_score == 0) continue;
+				if (nx->t_st < c_c->t_st + 5 && nx->q_st < c_c->q_st + 5 && nx->sum_score < c_c->sum_score + 5) {
+					nx->sum_score = 0; nx->q_ed = nx->q_st; nx->t_ed = nx->t_st;
+					continue;
+				}
+				int dis_t = nx->t_st - c_c->t_ed, dis_q = nx->q_st - c_c->q_ed;
+				int dis_t_q = ABSV(dis_t - dis_q);
+				if ((dis_t > -20 && dis_t < 1000 && dis_q > -20 && dis_q < 1000) && dis_t_q < 200) {
+					c_c->t_ed = MAXV(c_c->t_ed, nx->t_ed); c_c->q_ed = MAXV(c_c->q_ed, nx->q_ed);
+					c_c->sum_score += nx->sum_score;
+					nx->sum_score = 0; nx->q_ed = nx->q_st; nx->t_ed = nx->t_st;
+				}
+			} else break;
+		}
+	}
+	w.max_read_l = MAXV((uint32_t)w.max_read_l, l_read);
+	if (w.max_read_l < 510) {
+		for (c_c = st_c; c_c < ed_c; c_c++) { int s = c_c->sum_score + ((c_c->q_ed - c_c->q_st) >> 5); if (s < 26) c_c->sum_score = 0; }
+	} else if (l_read < 310) {
+		for (c_c = st_c; c_c < ed_c; c_c++) { int s = c_c->sum_score + ((c_c->q_ed - c_c->q_st) >> 5); if (s < 30) c_c->sum_score = 0; }
+	} else {
+		for (c_c = st_c; c_c < ed_c; c_c++) {
+			int s = c_c->sum_score + ((c_c->q_ed - c_c->q_st) >> 5);
+			if (s < (x->filter_min_score_LV3) && (c_c->q_ed - c_c->q_st < (uint32_t)x->filter_min_length || s < x->filter_min_score)) c_c->sum_score = 0;
+		}
+	}
+	if (w.n_hit > 1) glibc_sort_chains<2>(w, w.n_hit);
+	for (c_c = st_c; c_c < ed_c; c_c++) if (c_c->sum_score == 0) break;
+	w.n_hit = c_c - st_c;
+}
+
+// detect_primary (src/cly.c:2995-3058); the primary list lives in score_v (ints) / spset (bytes)
+DN void detect_primary(WCtx &w, uint32_t read_len)
+{
+	DsbChain *hit = w.hit; uint32_t n_hit = w.n_hit;
+	if (n_hit == 0) return;
+	int *primary_v = w.score_v; uint8_t *primary_v_idx = reinterpret_cast<uint8_t *>(w.spset); int n_primary_v = 1;
+	hit->pri_index = primary_v_idx[0] = 0; primary_v[0] = 0; hit->primary = 1;
+	DsbChain *ed_hit = hit + n_hit;
+	for (DsbChain *c = hit; c < ed_hit; c++) if (c->q_st > 4294960000u) c->q_st = 0;
+	for (DsbChain *c_hit = hit + 1; c_hit < ed_hit; c_hit++) {
+		bool overlap = false;
+		for (int i = 0; i < n_primary_v; i++) {
+			int primary_st, primary_ed;
+			DsbChain *ph = hit + primary_v[i];
+			if (ph->direction == c_hit->direction) { primary_st = ph->q_st; primary_ed = ph->q_ed; }
+			else { primary_st = read_len - ph->q_ed; primary_ed = read_len - ph->q_st; }
+			uint32_t overlap_st = MAXV(c_hit->q_st, (uint32_t)primary_st);
+			uint32_t overlap_ed = MINV(c_hit->q_ed, (uint32_t)primary_ed);
+			if ((overlap_st < overlap_ed) && (((overlap_ed - overlap_st) << 1) >= (c_hit->q_ed - c_hit->q_st))) overlap = true;
+			if (overlap) {
+				c_hit->primary = 2;
+				c_hit->pri_index = ++primary_v_idx[i];
+				int max_gap = MAXV((int)(ph->sum_score >> 6), 5);
+				if (c_hit->sum_score + max_gap > ph->sum_score) c_hit->pri_index = 1;
+				if (primary_v_idx[i] == 255) primary_v_idx[i] = 254;
+				break;
+			}
+		}
+		if (overlap == false) {
+			c_hit->primary = 3;
+			c_hit->pri_index = primary_v_idx[n_primary_v] = 0;
+			primary_v[n_primary_v++] = c_hit - hit;
+			if (n_primary_v > 750) n_primary_v = 750;
+		}
+	}
+}
+
+// classify_seq (src/cly.c:3064-3132) for one read; returns cly_r.fast_classify
+DN uint32_t classify_read(WCtx &w, const uint64_t *bitsF, const uint64_t *bitsR)
+{
+	uint32_t read_len = w.L;
+	w.n_anc = 0; w.n_hit = 0; w.n_sms = 0; w.steps = 0;
+	uint32_t fast = 1;
+	if (read_len < 40) return fast;
+	SDir *sd = w.sd;
+	uint32_t n = read_len - w.x->ek_len + 1;
+	w.stage = 1; MARK(w, 1);
+	seed_vector(w, w.bin, bitsF, n, w.seeds, D_FORWARD, sd);
+	seed_vector(w, w.bin + read_len, bitsR, n, w.seeds + (read_len >> 2), D_REVERSE, sd + 1);
+	if (sd[0].total_score < sd[1].total_score) { SDir t = sd[0]; sd[0] = sd[1]; sd[1] = t; }
+	bool both_direction = ((sd[0].total_score - sd[1].total_score) <= (sd[0].total_score >> 3));
+	int super_repeat = 0;
+	w.stage = 2; MARK(w, 2);
+	fast_classify(w, sd, read_len);
+	if (both_direction) fast_classify(w, sd + 1, read_len);
+	w.stage = 3; MARK(w, 3);
+	resolve_tree(w);
+	w.stage = 4; MARK(w, 4);
+	int run_slow_mode = false;
+	if (w.n_hit <= 0) run_slow_mode = true;
+	else if (w.hit[0].anchor_number < 5 && super_repeat < 3) {
+		run_slow_mode = true;
+		if (read_len <= 300 && w.hit[0].sum_score > 200) run_slow_mode = false;
+	}
+	if (run_slow_mode) {
+		w.n_anc = 0; fast = 0;
+		slow_classify(w, sd, read_len);
+		resolve_tree(w);
+		if (both_direction || w.n_hit <= 0 || (w.hit[0].anchor_number < 5 && super_repeat < 3)) {
+			slow_classify(w, sd + 1, read_len);
+			resolve_tree(w);
+		}
+	}
+	w.stage = 5; MARK(w, 5);
+	delete_small_score_rst(w, sd, read_len);
+	w.stage = 6; MARK(w, 6);
+	detect_primary(w, read_len);
+	w.stage = 7; MARK(w, 7);
+	return fast;
+}

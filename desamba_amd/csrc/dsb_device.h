@@ -1,0 +1,80 @@
+// Shared host/device data layout of the MI355X classify path.
+//
+// HBM layout (all arrays 256-B aligned, staged once per ctx):
+//   ek0/ek1      exist-kmer bit tables, byte-identical to the on-disk .exk0/.exk1 (src/idx.c:1115-1118)
+//   fm           rank structure re-laid-out for one 64-B line per occ(): per 128 BWT symbols
+//                {u32 cnt[A,C,G,T]; u64 p0[2]; u64 p1[2]; u64 sp[2]}  (reference: 168 B per 256
+//                symbols, src/bwt.c:43-65; answers are identical, tests/test_fm_layout.py)
+//   hash_index   (4^13+1) x u64, as on disk (src/bwt.c:84-85)
+//   sa           {unitig_ID, offset} per 8 BWT rows (src/bwt.h:10-13)
+//   uni          {ref_list, length} + sentinel (src/idx.c:1123-1129)
+//   refpos       u64 bit-field {global_offset:40, ref_ID:23, direction:1} (src/idx.h:33-39)
+//   refbin       2-bit text, 4 bases per byte MSB first (+4 KiB zero pad, oracle U3)
+//   refinfo      {seq_l, seq_offset} per reference
+//   qmem/qlv     MAPQ tables computed on the host with the reference's expression (src/cly_mt.c:413-437)
+#pragma once
+#include <stdint.h>
+#ifdef DSB_HOST_EMU
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+struct DsbFmBlock {            // 64 bytes, 128 symbols
+	uint32_t cnt[4];           // A,C,G,T before this block
+	uint64_t p0[2], p1[2];     // 2-bit symbol code planes (bit i of word w = symbol 64*w+i)
+	uint64_t sp[2];            // special: p0 bit 0 -> '#'(4), 1 -> '$'(5)
+};
+
+struct DsbRefInfo { uint64_t seq_l, seq_offset; };
+
+struct DsbDevIndex {
+	const uint8_t *ek0, *ek1; uint64_t ek_mask; int ek_len, single_base_max;
+	const DsbFmBlock *fm; uint64_t bwt_len; uint64_t rank[6]; uint64_t dollar_pos; uint64_t dollar_row;
+	const uint64_t *hash_index;
+	const uint2 *sa; const uint2 *uni; const uint64_t *refpos; const uint8_t *refbin; const DsbRefInfo *refinfo;
+	const int *qmem;           // [2000]
+	const int *qlv;            // [20][20]
+	int filter_min_length, filter_min_score, filter_min_score_LV3;
+};
+
+// ---- per-read records produced on the device -------------------------------------------------
+struct DsbSeed { uint32_t offset, len; uint32_t top; };                 // CLY_seed, src/cly.h:28-33
+
+struct DsbAnchor {                                                       // Anchor, src/cly.h:44-61
+	uint16_t mtch_len; int16_t score; uint8_t left_len, left_ED, rigt_len, rigt_ED;
+	uint8_t direction, useless, duplicate, pad0; uint16_t seed_ID, chain_id;
+	uint32_t ref_ID, ref_offset, index_in_read; int32_t pre;
+	uint64_t global_offset;
+};
+struct DsbChain {                                                        // chain_item, src/cly.h:69-89
+	uint32_t ref_ID; int32_t q_t_dis; uint32_t sum_score, anchor_number;
+	uint8_t direction, with_top_anchor, primary, pri_index;
+	uint32_t t_st, t_ed, q_st, q_ed, indel, chain_id; int32_t cur;
+};
+struct DsbSms { uint32_t t_pos, q_pos, len, score; };                    // spd_match, src/cly.h:129-135
+struct DsbMem { int match_len; int sa_sp_l; uint64_t sp, sa_sp; int read_offset; int pad; };
+struct DsbScHash { uint16_t next; uint16_t seed_ID; };                   // bit 15 of seed_ID = s_or_e
+
+struct DsbHitOut { uint32_t ref_ID, t_st, t_ed, q_st, q_ed, sum_score, indel; uint8_t direction, primary, pri_index, pad; };
+struct DsbReadOut { uint32_t first, n; int32_t status; uint32_t fast; };
+
+// ---- arena sizes (per wave slot) ---------------------------------------------------------------
+#define DSB_QPAD_L 64
+#define DSB_QPAD_R 192
+#define DSB_QPAD_R_VAL 5
+#define DSB_TPAD_VAL 4
+#define DSB_ANC_CAP 8192
+#define DSB_HIT_CAP 4096
+#define DSB_SMS_CAP 16384
+#define DSB_MEMSLOW_CAP (8 * 800 + 1 + 16)
+#define DSB_SPSET_CAP 500
+#define DSB_REFWIN 2176
+
+// status bits
+#define DSB_ST_ANC_OVF 1
+#define DSB_ST_HIT_OVF 2
+#define DSB_ST_SMS_OVF 4
+#define DSB_ST_OUT_OVF 8
+#define DSB_ST_TIMEOUT 16   // the per-read loop budget ran out (guards the grid against a spinning wave)

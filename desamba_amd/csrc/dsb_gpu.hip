@@ -1,0 +1,469 @@
+// HIP kernels and the device-side batch driver of the MI355X classify path (gfx950 only).
+//
+//   k_encode      ASCII -> per-read byte strands [64 x 0][F][R][192 x 5] + 2-bit packed strands
+//                 (getIsland's encode loops, src/cly.c:1250-1259)
+//   k_seed_probe  the seed-lookup kernel: one lane per k-mer window, both strands, every window:
+//                 rolling-free k-mer from the packed strand, low-complexity filter (store_kmers,
+//                 src/cly.c:360-398), two hashed 1-bit probes (get_exist_kmer, src/cly.c:956-972),
+//                 one ballot -> one 64-bit word of hit bits per wave iteration.  HBM/L3-bound gather.
+//   k_classify    persistent, one read per wavefront, everything after the probes (dsb_classify_dev.h)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include <vector>
+#include <unistd.h>
+#include "dsb_device.h"
+#include "dsb_probe.h"
+#include "dsb_classify_dev.h"
+#include "dsb_host.h"
+
+#define HIPCHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "[desamba_amd] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return DSB_ENODEV; } } while (0)
+
+// ---- batch descriptors ----------------------------------------------------------------------
+struct DsbReadDesc {
+	uint64_t seq_off;      // into the ASCII blob
+	uint64_t bin_off;      // into the byte-strand blob (points at the 64-byte left pad)
+	uint64_t pk_off;       // into the packed blob, in u64 words: F words then R words (+1 pad word each)
+	uint64_t bit_off;      // into the hit-bit blob, in u64 words: F words then R words
+	uint32_t len;
+	uint32_t n_win;        // len - k + 1 (0 if len < 40)
+	uint32_t n_words;      // ceil(n_win / 64)
+	int32_t  hist_max;     // max read length over the reads before this one (oracle U4)
+};
+struct DsbWordDesc { uint32_t read; uint32_t word; };   // word: bit 31 = strand R, low bits = word index
+
+__device__ __forceinline__ uint32_t d_code(uint8_t ch)
+{	// CLY_Bit, src/cly.c:17-35: anything that is not A/G/T is C
+	return (ch == 'A' || ch == 'a') ? 0u : (ch == 'G' || ch == 'g') ? 2u : (ch == 'T' || ch == 't') ? 3u : 1u;
+}
+
+// one block per read; byte strands
+__global__ void __launch_bounds__(256) k_encode_bytes(const DsbReadDesc *rd, const char *ascii, uint8_t *bin)
+{
+	DsbReadDesc d = rd[blockIdx.x];
+	const char *s = ascii + d.seq_off;
+	uint8_t *base = bin + d.bin_off, *F = base + DSB_QPAD_L, *R = F + d.len;
+	uint32_t L = d.len;
+	if (threadIdx.x < DSB_QPAD_L) base[threadIdx.x] = 0;
+	if (threadIdx.x < DSB_QPAD_R) R[L + threadIdx.x] = DSB_QPAD_R_VAL;
+	for (uint32_t i = threadIdx.x; i < L; i += 256) {
+		uint32_t c = d_code((uint8_t)s[i]);
+		F[i] = (uint8_t)c; R[L - 1 - i] = (uint8_t)(3u - c);
+	}
+}
+// one thread per packed word (32 bases, first base in the top bits); F words then R words, one zero pad word after each
+__global__ void __launch_bounds__(256) k_encode_pack(const DsbReadDesc *rd, const uint8_t *bin, uint64_t *pk)
+{
+	DsbReadDesc d = rd[blockIdx.x];
+	uint32_t L = d.len, nw = (L + 31) / 32 + 1;
+	const uint8_t *F = bin + d.bin_off + DSB_QPAD_L;
+	for (uint32_t t = threadIdx.x; t < 2 * nw; t += 256) {
+		uint32_t strand_r = t >= nw, wi = strand_r ? t - nw : t;
+		const uint8_t *S = strand_r ? F + L : F;
+		uint64_t v = 0;
+		for (uint32_t b = 0; b < 32; b++) { uint32_t p = wi * 32 + b; v = (v << 2) | (p < L ? S[p] : 0u); }
+		pk[d.pk_off + t] = v;
+	}
+}
+
+// seed-lookup kernel.  Each wave takes word descriptors (64 windows of one read strand) in a grid-stride loop.
+__global__ void __launch_bounds__(256) k_seed_probe(DsbDevIndex x, const DsbReadDesc *rd, const DsbWordDesc *wd, uint64_t n_words_total,
+                                                    const uint64_t *pk, uint64_t *bits, unsigned long long *probe_counters)
+{
+	const int lane = threadIdx.x & 63;
+	const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+	const int k = x.ek_len; const int sbm = x.single_base_max;
+	const uint64_t kmask = k >= 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+	unsigned long long p1_local = 0;
+	for (uint64_t wI = wave; wI < n_words_total; wI += n_waves) {
+		DsbWordDesc w = wd[wI];
+		DsbReadDesc d = rd[w.read];
+		uint32_t strand_r = w.word >> 31, wi = w.word & 0x7fffffffu;
+		uint32_t nwp = (d.len + 31) / 32 + 1;
+		const uint64_t *P = pk + d.pk_off + (strand_r ? nwp : 0);
+		uint32_t p = wi * 64 + lane;
+		int hit = 0;
+		if (p < d.n_win) {
+			int went_t1 = 0;
+			hit = dsb_probe_window(P, p, k, kmask, sbm, x.ek0, x.ek1, x.ek_mask, &went_t1);
+			p1_local += went_t1;
+		}
+		uint64_t word = __ballot(hit);
+		if (lane == 0) bits[d.bit_off + (strand_r ? d.n_words : 0) + wi] = word;
+	}
+	if (probe_counters) {
+		// wave-reduce, one atomic per wave
+		for (int o = 32; o > 0; o >>= 1) p1_local += __shfl_down(p1_local, o);
+		if (lane == 0 && p1_local) atomicAdd(probe_counters, p1_local);
+	}
+}
+
+// ---- classify kernel: persistent waves, one read each ------------------------------------------
+struct DsbSlotArena {
+	uint8_t *base; size_t stride;                 // per-slot bytes
+	size_t off_seeds, off_anc, off_anc_tmp, off_hit, off_hit_tmp, off_sms, off_kh, off_sc, off_mem, off_spset, off_scorev,
+	       off_sortkey, off_sortidx, off_win;
+	uint32_t max_len;                             // longest read the arena was sized for
+};
+
+__global__ void __launch_bounds__(64) k_classify(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_reads, uint8_t *bin, const uint64_t *bits,
+                                                 DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout, DsbHitOut *hout,
+                                                 unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg)
+{
+	const int lane = threadIdx.x;
+	uint8_t *slot = ar.base + (size_t)blockIdx.x * ar.stride;
+	WCtx w;
+	w.x = &x; w.lane = lane; w.dbg = dbg ? dbg + 4 * blockIdx.x : nullptr;
+	w.seeds = (DsbSeed *)(slot + ar.off_seeds);
+	w.anc = (DsbAnchor *)(slot + ar.off_anc); w.anc_tmp = (DsbAnchor *)(slot + ar.off_anc_tmp);
+	w.hit = (DsbChain *)(slot + ar.off_hit); w.hit_tmp = (DsbChain *)(slot + ar.off_hit_tmp);
+	w.sms = (DsbSms *)(slot + ar.off_sms);
+	uint32_t *kh = (uint32_t *)(slot + ar.off_kh);
+	size_t kh_strand = (size_t)(1u << 18) + 2 * (size_t)ar.max_len;
+	w.kh_head[0] = kh; w.kh_next[0] = kh + (1u << 18); w.kh_kmer[0] = w.kh_next[0] + ar.max_len;
+	w.kh_head[1] = kh + kh_strand; w.kh_next[1] = w.kh_head[1] + (1u << 18); w.kh_kmer[1] = w.kh_next[1] + ar.max_len;
+	w.sc = (DsbScHash *)(slot + ar.off_sc);
+	w.mem_slow = (DsbMem *)(slot + ar.off_mem);
+	w.spset = (uint64_t *)(slot + ar.off_spset);
+	w.score_v = (int *)(slot + ar.off_scorev);
+	w.sortkey = (uint64_t *)(slot + ar.off_sortkey); w.sortidx = (uint32_t *)(slot + ar.off_sortidx);
+	w.win_mid = slot + ar.off_win; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
+	if (w.dbg && lane == 0) w.dbg[0] = 300;
+	for (;;) {
+		unsigned int r = 0;
+		if (lane == 0) r = atomicAdd(work_counter, 1u);
+		r = __shfl(r, 0);
+		if (r >= n_reads) { if (w.dbg && lane == 0) w.dbg[0] = 999; break; }   // every wave reaches this: the grid always drains
+		DsbReadDesc d = rd[r];
+		if (w.dbg && lane == 0) { w.dbg[2] = r; w.dbg[0] = 100; }
+		w.bin = bin + d.bin_off + DSB_QPAD_L; w.L = d.len; w.status = 0; w.max_read_l = d.hist_max;
+		uint32_t fast = classify_read(w, bits + d.bit_off, bits + d.bit_off + d.n_words);
+		// publish the hits of this read
+		unsigned int first = 0;
+		if (lane == 0 && w.n_hit) first = atomicAdd(hout_counter, w.n_hit);
+		first = __shfl(first, 0);
+		uint32_t n_out = w.n_hit;
+		if (first + n_out > hout_cap) { w.status |= DSB_ST_OUT_OVF; n_out = 0; }
+		for (uint32_t i = lane; i < n_out; i += 64) {
+			DsbChain h = w.hit[i]; DsbHitOut o;
+			o.ref_ID = h.ref_ID; o.t_st = h.t_st; o.t_ed = h.t_ed; o.q_st = h.q_st; o.q_ed = h.q_ed; o.sum_score = h.sum_score; o.indel = h.indel;
+			o.direction = h.direction; o.primary = h.primary; o.pri_index = h.pri_index; o.pad = 0;
+			hout[first + i] = o;
+		}
+		if (w.dbg && lane == 0) w.dbg[0] = 200;
+		if (lane == 0) { DsbReadOut ro; ro.first = first; ro.n = n_out; ro.status = w.status | (w.status ? (w.stage << 8) : 0); ro.fast = fast; rout[r] = ro; }
+	}
+}
+
+// ================================== host side ====================================================
+struct dsb_ctx {
+	dsb_index *idx; int device; hipStream_t stream;
+	DsbDevIndex dx;
+	std::vector<void *> dev_allocs;
+	// batch buffers (grown on demand)
+	DsbReadDesc *d_rd; DsbWordDesc *d_wd; char *d_ascii; uint8_t *d_bin; uint64_t *d_pk; uint64_t *d_bits;
+	size_t cap_rd, cap_wd, cap_ascii, cap_bin, cap_pk, cap_bits;
+	DsbReadOut *d_rout; DsbHitOut *d_hout; size_t cap_rout, cap_hout;
+	unsigned int *d_counters;                      // [0] work, [1] hits; +8: u64 p1 counter
+	DsbSlotArena arena; size_t arena_bytes; int n_slots;
+	// host mirrors
+	std::vector<DsbReadDesc> h_rd; std::vector<DsbWordDesc> h_wd;
+	std::vector<DsbReadOut> h_rout; std::vector<DsbHitOut> h_hout;
+	std::vector<dsb_read_result> res_reads; std::vector<dsb_hit> res_hits;
+	size_t n_reads; uint64_t n_words_total, total_bases, total_windows; uint32_t max_len;
+	int hist_max;
+	hipEvent_t ev[4]; dsb_timing timing; unsigned long long p1;
+	uint32_t *dbg_host, *dbg_dev;
+	dsb_opts opts;
+};
+
+template <class T> static int dev_upload(dsb_ctx *c, const T *src, size_t n, const T **dst)
+{
+	void *p = nullptr;
+	if (hipMalloc(&p, n * sizeof(T) + 256) != hipSuccess) return DSB_ENOMEM;
+	if (hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return DSB_ENODEV;
+	c->dev_allocs.push_back(p);
+	*dst = (const T *)p;
+	return 0;
+}
+
+extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opts, dsb_ctx **out)
+{
+	if (!idx || !out) return DSB_EINVAL;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fprintf(stderr, "[desamba_amd] no HIP device: this library has no CPU path\n"); return DSB_ENODEV; }
+	if (device_id < 0 || device_id >= ndev) return DSB_EINVAL;
+	HIPCHK(hipSetDevice(device_id));
+	hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device_id));
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { fprintf(stderr, "[desamba_amd] device %d is %s, kernels are built for gfx950 only\n", device_id, prop.gcnArchName); return DSB_ENODEV; }
+	dsb_ctx *c = new dsb_ctx();
+	c->idx = idx; c->device = device_id;
+	c->opts.L_min_matching = opts ? opts->L_min_matching : 170; c->opts.min_score = opts ? opts->min_score : 64;
+	c->opts.max_sec_N = opts ? opts->max_sec_N : 5; c->opts.n_slots = opts ? opts->n_slots : 0;
+	HIPCHK(hipStreamCreate(&c->stream));
+	for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
+	// stage the index into HBM once
+	const DsbHostIndex *h = dsb_index_host(idx);
+	DsbDevIndex &dx = c->dx; memset(&dx, 0, sizeof dx);
+	int rc;
+	if ((rc = dev_upload(c, h->ek0, h->ek_size, &dx.ek0))) return rc;
+	if ((rc = dev_upload(c, h->ek1, h->ek_size, &dx.ek1))) return rc;
+	dx.ek_mask = h->ek_mask; dx.ek_len = h->ek_len; dx.single_base_max = h->single_base_max;
+	if ((rc = dev_upload(c, h->fm, h->n_fm, &dx.fm))) return rc;
+	dx.bwt_len = h->bwt_len; memcpy(dx.rank, h->rank, sizeof dx.rank); dx.dollar_pos = h->dollar_pos; dx.dollar_row = h->dollar_row;
+	if ((rc = dev_upload(c, h->hash_index, ((size_t)1 << 26) + 1, &dx.hash_index))) return rc;
+	if ((rc = dev_upload(c, (const uint2 *)h->sa, h->sa_size, &dx.sa))) return rc;
+	if ((rc = dev_upload(c, (const uint2 *)h->uni, h->n_uni + 1, &dx.uni))) return rc;
+	if ((rc = dev_upload(c, h->refpos, h->n_refpos + 1, &dx.refpos))) return rc;
+	if ((rc = dev_upload(c, h->refbin, h->n_refbin + 4096, &dx.refbin))) return rc;
+	if ((rc = dev_upload(c, h->refinfo, h->n_ref, &dx.refinfo))) return rc;
+	if ((rc = dev_upload(c, h->Q_MEM, (size_t)2000, &dx.qmem))) return rc;
+	if ((rc = dev_upload(c, &h->Q_LV[0][0], (size_t)400, &dx.qlv))) return rc;
+	dx.filter_min_length = c->opts.L_min_matching; dx.filter_min_score = c->opts.min_score; dx.filter_min_score_LV3 = c->opts.min_score + 10;
+	HIPCHK(hipMalloc((void **)&c->d_counters, 64));
+	c->dbg_host = c->dbg_dev = nullptr;
+	if (getenv("DSB_DEBUG")) {
+		HIPCHK(hipHostMalloc((void **)&c->dbg_host, 4 * 65536 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+		memset(c->dbg_host, 0, 4 * 65536 * sizeof(uint32_t));
+		HIPCHK(hipHostGetDevicePointer((void **)&c->dbg_dev, c->dbg_host, 0));
+	}
+	c->n_slots = c->opts.n_slots > 0 ? c->opts.n_slots : 0;
+	*out = c;
+	return DSB_OK;
+}
+
+extern "C" void dsb_ctx_destroy(dsb_ctx *c)
+{
+	if (!c) return;
+	hipSetDevice(c->device);
+	for (void *p : c->dev_allocs) hipFree(p);
+	hipFree(c->d_rd); hipFree(c->d_wd); hipFree(c->d_ascii); hipFree(c->d_bin); hipFree(c->d_pk); hipFree(c->d_bits);
+	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base);
+	for (int i = 0; i < 4; i++) hipEventDestroy(c->ev[i]);
+	hipStreamDestroy(c->stream);
+	delete c;
+}
+extern "C" void dsb_ctx_reset_history(dsb_ctx *c) { if (c) c->hist_max = 0; }
+
+template <class T> static int grow(T **p, size_t *cap, size_t need)
+{
+	if (need <= *cap) return 0;
+	if (*p) hipFree(*p);
+	size_t n = need + need / 8 + 1024;
+	if (hipMalloc((void **)p, n * sizeof(T)) != hipSuccess) { *p = nullptr; *cap = 0; return DSB_ENOMEM; }
+	*cap = n;
+	return 0;
+}
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int size_arena(dsb_ctx *c, uint32_t max_len, int n_slots)
+{
+	if (c->arena.base && c->arena.max_len >= max_len && c->n_slots >= n_slots) return 0;
+	if (c->arena.base) { hipFree(c->arena.base); c->arena.base = nullptr; }
+	DsbSlotArena &a = c->arena; size_t o = 0;
+	a.max_len = max_len;
+	a.off_seeds = o;   o += al256(((size_t)(max_len >> 1) + 64) * sizeof(DsbSeed));
+	a.off_anc = o;     o += al256((size_t)DSB_ANC_CAP * sizeof(DsbAnchor));
+	a.off_anc_tmp = o; o += al256((size_t)DSB_ANC_CAP * sizeof(DsbAnchor));
+	a.off_hit = o;     o += al256((size_t)DSB_HIT_CAP * sizeof(DsbChain));
+	a.off_hit_tmp = o; o += al256((size_t)DSB_HIT_CAP * sizeof(DsbChain));
+	a.off_sms = o;     o += al256((size_t)DSB_SMS_CAP * sizeof(DsbSms));
+	a.off_kh = o;      o += al256(2 * ((size_t)(1u << 18) + 2 * (size_t)max_len) * sizeof(uint32_t));
+	a.off_sc = o;      o += al256((size_t)(256 + 2 * 400 + 64) * sizeof(DsbScHash));
+	a.off_mem = o;     o += al256((size_t)DSB_MEMSLOW_CAP * sizeof(DsbMem));
+	a.off_spset = o;   o += al256((size_t)DSB_SPSET_CAP * 8);
+	a.off_scorev = o;  o += al256((size_t)1024 * sizeof(int));
+	a.off_sortkey = o; o += al256((size_t)2 * DSB_ANC_CAP * sizeof(uint64_t));
+	a.off_sortidx = o; o += al256((size_t)2 * DSB_ANC_CAP * sizeof(uint32_t));
+	a.off_win = o;     o += al256((size_t)3 * DSB_REFWIN);
+	a.stride = al256(o);
+	c->n_slots = n_slots;
+	c->arena_bytes = a.stride * (size_t)n_slots;
+	if (hipMalloc((void **)&a.base, c->arena_bytes) != hipSuccess) { a.base = nullptr; return DSB_ENOMEM; }
+	return 0;
+}
+
+extern "C" int dsb_batch_upload(dsb_ctx *c, const dsb_read *reads, size_t n)
+{
+	if (!c || (!reads && n)) return DSB_EINVAL;
+	HIPCHK(hipSetDevice(c->device));
+	const int k = c->dx.ek_len;
+	c->h_rd.resize(n); c->h_wd.clear();
+	uint64_t seq_off = 0, bin_off = 0, pk_off = 0, bit_off = 0, windows = 0; uint32_t max_len = 64; int hist = c->hist_max;
+	for (size_t i = 0; i < n; i++) {
+		DsbReadDesc &d = c->h_rd[i];
+		d.len = reads[i].len; d.seq_off = seq_off; d.bin_off = bin_off; d.pk_off = pk_off; d.bit_off = bit_off;
+		d.n_win = d.len >= 40 ? d.len - k + 1 : 0; d.n_words = (d.n_win + 63) / 64;
+		d.hist_max = hist; if ((int)d.len > hist) hist = d.len;
+		seq_off += d.len; bin_off += al256(DSB_QPAD_L + 2 * (size_t)d.len + DSB_QPAD_R);
+		pk_off += 2 * ((d.len + 31) / 32 + 1); bit_off += 2 * (size_t)d.n_words;
+		if (d.len > max_len) max_len = d.len;
+		windows += 2 * (uint64_t)d.n_win;
+		for (uint32_t s = 0; s < 2; s++) for (uint32_t wI = 0; wI < d.n_words; wI++) { DsbWordDesc wdsc; wdsc.read = (uint32_t)i; wdsc.word = wI | (s << 31); c->h_wd.push_back(wdsc); }
+	}
+	c->hist_max = hist;
+	c->n_reads = n; c->n_words_total = c->h_wd.size(); c->total_bases = seq_off; c->total_windows = windows; c->max_len = max_len;
+	int rc;
+	if ((rc = grow(&c->d_rd, &c->cap_rd, n + 1))) return rc;
+	if ((rc = grow(&c->d_wd, &c->cap_wd, c->h_wd.size() + 1))) return rc;
+	if ((rc = grow(&c->d_ascii, &c->cap_ascii, (size_t)seq_off + 64))) return rc;
+	if ((rc = grow(&c->d_bin, &c->cap_bin, (size_t)bin_off + 256))) return rc;
+	if ((rc = grow(&c->d_pk, &c->cap_pk, (size_t)pk_off + 8))) return rc;
+	if ((rc = grow(&c->d_bits, &c->cap_bits, (size_t)bit_off + 8))) return rc;
+	if ((rc = grow(&c->d_rout, &c->cap_rout, n + 1))) return rc;
+	if ((rc = grow(&c->d_hout, &c->cap_hout, 16 * n + 4096))) return rc;
+	// reads in flight: one wavefront each; default 8 waves per SIMD's worth, bounded by the batch
+	int want = c->opts.n_slots > 0 ? c->opts.n_slots : 256 * 4 * 4;
+	if ((size_t)want > n) want = (int)(n ? n : 1);
+	if ((rc = size_arena(c, max_len, want > c->n_slots ? want : c->n_slots))) return rc;
+	if (n) {
+		HIPCHK(hipMemcpyAsync(c->d_rd, c->h_rd.data(), n * sizeof(DsbReadDesc), hipMemcpyHostToDevice, c->stream));
+		if (!c->h_wd.empty()) HIPCHK(hipMemcpyAsync(c->d_wd, c->h_wd.data(), c->h_wd.size() * sizeof(DsbWordDesc), hipMemcpyHostToDevice, c->stream));
+		// sequences: copied read by read out of the caller's buffers (caller owns read memory)
+		std::vector<char> stage((size_t)seq_off);
+		for (size_t i = 0; i < n; i++) memcpy(stage.data() + c->h_rd[i].seq_off, reads[i].seq, reads[i].len);
+		HIPCHK(hipMemcpy(c->d_ascii, stage.data(), (size_t)seq_off, hipMemcpyHostToDevice));
+	}
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return DSB_OK;
+}
+
+extern "C" int dsb_batch_run(dsb_ctx *c)
+{
+	if (!c) return DSB_EINVAL;
+	HIPCHK(hipSetDevice(c->device));
+	size_t n = c->n_reads;
+	memset(&c->timing, 0, sizeof c->timing);
+	if (n == 0) return DSB_OK;
+	HIPCHK(hipMemsetAsync(c->d_counters, 0, 64, c->stream));
+	HIPCHK(hipEventRecord(c->ev[0], c->stream));
+	hipLaunchKernelGGL(k_encode_bytes, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_rd, c->d_ascii, c->d_bin);
+	hipLaunchKernelGGL(k_encode_pack, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_rd, c->d_bin, c->d_pk);
+	HIPCHK(hipEventRecord(c->ev[1], c->stream));
+	const bool dbg = getenv("DSB_DEBUG") != NULL;
+	if (dbg) { HIPCHK(hipStreamSynchronize(c->stream)); fprintf(stderr, "[dsb] encode done\n"); }
+	if (c->n_words_total) {
+		uint64_t waves = c->n_words_total; unsigned blocks = (unsigned)((waves + 3) / 4);
+		if (blocks > 256u * 32u) blocks = 256u * 32u;       // >= 8 blocks of 4 waves per CU, grid-stride beyond
+		hipLaunchKernelGGL(k_seed_probe, dim3(blocks), dim3(256), 0, c->stream, c->dx, c->d_rd, c->d_wd, c->n_words_total, c->d_pk, c->d_bits,
+		                   (unsigned long long *)(c->d_counters + 2));
+	}
+	HIPCHK(hipEventRecord(c->ev[2], c->stream));
+	if (dbg) { HIPCHK(hipStreamSynchronize(c->stream)); fprintf(stderr, "[dsb] seed probe done\n"); }
+	{
+		unsigned slots = (unsigned)c->n_slots; if (slots > n) slots = (unsigned)n;
+		hipLaunchKernelGGL(k_classify, dim3(slots), dim3(64), 0, c->stream, c->dx, c->d_rd, (uint32_t)n, c->d_bin, c->d_bits, c->arena,
+		                   c->d_counters, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, dbg ? c->dbg_dev : nullptr);
+		if (dbg) {
+			// watchdog: poll the stream; dump the progress words of every slot if the kernel runs long
+			for (int sec = 0; sec < 60; sec++) {
+				if (hipStreamQuery(c->stream) == hipSuccess) break;
+				usleep(1000000);
+				if (sec % 5 == 4) {
+					fprintf(stderr, "[dsb] classify still running after %d s; slot: code steps read\n", sec + 1);
+					for (unsigned sI = 0; sI < slots && sI < 24; sI++) fprintf(stderr, "   slot %u: %u %u %u\n", sI, c->dbg_host[4 * sI], c->dbg_host[4 * sI + 1], c->dbg_host[4 * sI + 2]);
+				}
+			}
+		}
+	}
+	HIPCHK(hipEventRecord(c->ev[3], c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipGetLastError());
+	hipEventElapsedTime(&c->timing.encode_ms, c->ev[0], c->ev[1]);
+	hipEventElapsedTime(&c->timing.seed_probe_ms, c->ev[1], c->ev[2]);
+	hipEventElapsedTime(&c->timing.classify_ms, c->ev[2], c->ev[3]);
+	hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[3]);
+	HIPCHK(hipMemcpy(&c->p1, c->d_counters + 2, 8, hipMemcpyDeviceToHost));
+	c->timing.windows = c->total_windows; c->timing.probes_t1 = c->p1; c->timing.bases = c->total_bases;
+	return DSB_OK;
+}
+
+extern "C" int dsb_batch_fetch(dsb_ctx *c, dsb_result *out)
+{
+	if (!c || !out) return DSB_EINVAL;
+	HIPCHK(hipSetDevice(c->device));
+	size_t n = c->n_reads;
+	c->h_rout.resize(n); c->res_reads.resize(n);
+	unsigned int cnt[2] = {0, 0};
+	if (n) {
+		HIPCHK(hipMemcpy(cnt, c->d_counters, 8, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(c->h_rout.data(), c->d_rout, n * sizeof(DsbReadOut), hipMemcpyDeviceToHost));
+	}
+	size_t nh = cnt[1] < c->cap_hout ? cnt[1] : c->cap_hout;
+	c->h_hout.resize(nh);
+	if (nh) HIPCHK(hipMemcpy(c->h_hout.data(), c->d_hout, nh * sizeof(DsbHitOut), hipMemcpyDeviceToHost));
+	// pack hits in read order
+	c->res_hits.clear(); c->res_hits.reserve(nh);
+	int worst = DSB_OK;
+	for (size_t i = 0; i < n; i++) {
+		const DsbReadOut &r = c->h_rout[i];
+		dsb_read_result &o = c->res_reads[i];
+		o.first = (uint32_t)c->res_hits.size(); o.n = r.n; o.fast = r.fast;
+		o.status = r.status ? (DSB_ECAP * 256 - r.status) : 0;
+		if (r.status) worst = DSB_ECAP;
+		for (uint32_t k = 0; k < r.n; k++) {
+			const DsbHitOut &h = c->h_hout[r.first + k]; dsb_hit q;
+			q.ref_ID = h.ref_ID; q.t_st = h.t_st; q.t_ed = h.t_ed; q.q_st = h.q_st; q.q_ed = h.q_ed; q.sum_score = h.sum_score; q.indel = h.indel;
+			q.direction = h.direction; q.primary = h.primary; q.pri_index = h.pri_index; q.pad = 0;
+			c->res_hits.push_back(q);
+		}
+	}
+	out->reads = c->res_reads.data(); out->hits = c->res_hits.data(); out->n_hits = c->res_hits.size();
+	return worst;
+}
+
+extern "C" int dsb_classify_batch(dsb_ctx *c, const dsb_read *reads, size_t n, dsb_result *out)
+{
+	int rc;
+	if ((rc = dsb_batch_upload(c, reads, n))) return rc;
+	if ((rc = dsb_batch_run(c))) return rc;
+	return dsb_batch_fetch(c, out);
+}
+
+extern "C" int dsb_batch_timing(const dsb_ctx *c, dsb_timing *t) { if (!c || !t) return DSB_EINVAL; *t = c->timing; return DSB_OK; }
+
+extern "C" int dsb_batch_exist_bits(dsb_ctx *c, size_t read, int strand, uint8_t *out, size_t cap, uint32_t *n_out)
+{
+	if (!c || read >= c->n_reads) return DSB_EINVAL;
+	HIPCHK(hipSetDevice(c->device));
+	const DsbReadDesc &d = c->h_rd[read];
+	if (n_out) *n_out = d.n_win;
+	if (cap < d.n_win) return DSB_EINVAL;
+	std::vector<uint64_t> wv(d.n_words);
+	if (d.n_words) HIPCHK(hipMemcpy(wv.data(), c->d_bits + d.bit_off + (strand ? 0 : d.n_words), d.n_words * 8, hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < d.n_win; i++) out[i] = (uint8_t)((wv[i >> 6] >> (i & 63)) & 1);
+	return DSB_OK;
+}
+
+// seeds are a by-product of k_classify; recomputed here on the device for one read strand (stage dump for tests)
+__global__ void __launch_bounds__(64) k_seed_dump(DsbDevIndex x, DsbReadDesc d, uint8_t *bin, const uint64_t *bits, int strand, DsbSeed *out, uint32_t *n_out)
+{
+	WCtx w; w.x = &x; w.lane = threadIdx.x; w.L = d.len; w.status = 0;
+	SDir sd;
+	uint32_t n = d.len - x.ek_len + 1;
+	if (strand) seed_vector(w, bin + d.bin_off + DSB_QPAD_L, bits + d.bit_off, n, out, D_FORWARD, &sd);
+	else seed_vector(w, bin + d.bin_off + DSB_QPAD_L + d.len, bits + d.bit_off + d.n_words, n, out, D_REVERSE, &sd);
+	if (threadIdx.x == 0) { n_out[0] = sd.l_seed_v; n_out[1] = sd.total_score; }
+}
+extern "C" int dsb_batch_seeds(dsb_ctx *c, size_t read, int strand, dsb_seed *out, size_t cap, uint32_t *n, uint32_t *total_score)
+{
+	if (!c || read >= c->n_reads) return DSB_EINVAL;
+	HIPCHK(hipSetDevice(c->device));
+	const DsbReadDesc &d = c->h_rd[read];
+	if (d.len < 40) { if (n) *n = 0; if (total_score) *total_score = 0; return DSB_OK; }
+	DsbSeed *ds; uint32_t *dn; size_t m = (d.len >> 1) + 64;
+	HIPCHK(hipMalloc((void **)&ds, m * sizeof(DsbSeed))); HIPCHK(hipMalloc((void **)&dn, 8));
+	hipLaunchKernelGGL(k_seed_dump, dim3(1), dim3(64), 0, c->stream, c->dx, d, c->d_bin, c->d_bits, strand, ds, dn);
+	HIPCHK(hipStreamSynchronize(c->stream));
+	uint32_t hn[2]; HIPCHK(hipMemcpy(hn, dn, 8, hipMemcpyDeviceToHost));
+	std::vector<DsbSeed> hs(hn[0] ? hn[0] : 1);
+	if (hn[0]) HIPCHK(hipMemcpy(hs.data(), ds, hn[0] * sizeof(DsbSeed), hipMemcpyDeviceToHost));
+	hipFree(ds); hipFree(dn);
+	if (n) *n = hn[0]; if (total_score) *total_score = hn[1];
+	if (cap < hn[0]) return DSB_EINVAL;
+	for (uint32_t i = 0; i < hn[0]; i++) { out[i].offset = hs[i].offset; out[i].len = hs[i].len; out[i].top = (uint8_t)hs[i].top; out[i].pad[0] = out[i].pad[1] = out[i].pad[2] = 0; }
+	return DSB_OK;
+}

@@ -1,0 +1,120 @@
+/* desamba_amd -- C-ABI of the MI355X-native `deSAMBA classify` hot path.
+ *
+ * The reference has no plugin/FFI interface; its in-process seam for this path is the
+ * kt_for call in classify_pipeline (src/cly_mt.c:389): a batch of kseq_t in, a batch of
+ * cly_r out, of which the SAM writer consumes only cly_r.hit (chain_item, src/cly.h:69-89).
+ * This header is that seam as a C ABI: plain pointers and sizes, no torch / HIP types.
+ * Every entry point returns 0 on success or a negative DSB_E* code; nothing here calls
+ * exit() (the reference's print-and-exit convention, src/lib/utils.c:144-176, lives only
+ * in the CLI).  One dsb_ctx per host thread and GPU; batches run in submission order.
+ *
+ * There is NO CPU fallback: every compute stage runs as a HIP kernel on gfx950, and
+ * dsb_ctx_create fails with DSB_ENODEV when no such device is present.
+ */
+#ifndef DESAMBA_AMD_H
+#define DESAMBA_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSB_OK        0
+#define DSB_EIO      -1   /* index file missing / short (reference: xread/xopen abort, src/lib/utils.h:112) */
+#define DSB_ENODEV   -2   /* no gfx950 device, or HIP runtime error */
+#define DSB_ENOMEM   -3
+#define DSB_EINVAL   -4
+#define DSB_ECAP     -5   /* a per-read device arena overflowed; the read's status says which */
+
+typedef struct dsb_index dsb_index;   /* replaces DA_IDX (src/idx.h:68-91) */
+typedef struct dsb_ctx dsb_ctx;       /* replaces Classify_buff_pool + MAP_opt (src/cly.h:139-158,17-26) */
+
+/* replaces MAP_opt's classify-relevant fields, defaults {170, 64, 5} (src/cly_mt.c:486) */
+typedef struct {
+	int L_min_matching;   /* -l, idx.filter_min_length   (src/cly_mt.c:521) */
+	int min_score;        /* -s, idx.filter_min_score    (src/cly_mt.c:522) */
+	int max_sec_N;        /* -r, used by the SAM writer only */
+	int n_slots;          /* 0 = default: reads in flight on the device (one wavefront each) */
+} dsb_opts;
+
+/* replaces kseq_t as consumed by classify_seq (src/cly.c:3064): only seq/len reach the kernel */
+typedef struct {
+	const char *name;
+	const char *seq;
+	const char *qual;
+	uint32_t len;
+} dsb_read;
+
+/* replaces chain_item as consumed by output_one_result_sam (src/cly_mt.c:245-344) */
+typedef struct {
+	uint32_t ref_ID, t_st, t_ed, q_st, q_ed, sum_score, indel;
+	uint8_t direction, primary, pri_index, pad;
+} dsb_hit;
+
+/* replaces cly_r.hit (src/cly.h:93-100): hits of read i are hits[first .. first+n) in final order */
+typedef struct {
+	uint32_t first, n;
+	int32_t status;       /* 0, or DSB_ECAP with the overflowing arena in the low bits */
+	uint32_t fast;        /* cly_r.fast_classify */
+} dsb_read_result;
+
+typedef struct {
+	const dsb_read_result *reads;   /* n entries */
+	const dsb_hit *hits;            /* owned by the ctx, valid until the next batch on it */
+	size_t n_hits;
+} dsb_result;
+
+/* stage dump of the seed-lookup kernels (src/cly.c:1071-1234), used by the parity tests */
+typedef struct { uint32_t offset, len; uint8_t top; uint8_t pad[3]; } dsb_seed;
+
+/* per-batch device timings (HIP events on the ctx's stream), milliseconds */
+typedef struct {
+	float encode_ms, seed_probe_ms, classify_ms, total_ms;
+	uint64_t windows;      /* exist-kmer windows probed in table 0 (= P0 of SURVEY.md 8d) */
+	uint64_t probes_t1;    /* probes that continued to table 1 (= P1) */
+	uint64_t bases;
+} dsb_timing;
+
+/* load_idx (src/idx.c:1103-1160, src/bwt.c:68-104): read <dir>/deSAMBA.* into host memory */
+int  dsb_index_open(const char *dir, dsb_index **idx);
+void dsb_index_close(dsb_index *idx);
+/* reference names / lengths for the SAM writer (REF_INFO, src/idx.h:15-19) */
+uint64_t    dsb_index_n_ref(const dsb_index *idx);
+const char *dsb_index_ref_name(const dsb_index *idx, uint32_t ref_ID);
+uint64_t    dsb_index_ref_len(const dsb_index *idx, uint32_t ref_ID);
+int         dsb_index_ek_len(const dsb_index *idx);
+/* host mirror of the device rank structure, for layout tests without a GPU (occ, src/bwt.c:43-65) */
+uint64_t dsb_index_occ_host(const dsb_index *idx, uint64_t r, uint8_t *c);
+
+/* classify_main's set-up (src/cly_mt.c:518-550): stage the index into HBM, allocate arenas */
+int  dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opts, dsb_ctx **ctx);
+void dsb_ctx_destroy(dsb_ctx *ctx);
+/* reset the running max_read_l (src/cly.c:2958) -- start of a new input file */
+void dsb_ctx_reset_history(dsb_ctx *ctx);
+
+/* the kt_for seam (src/cly_mt.c:389): classify n reads; results valid until the next call */
+int  dsb_classify_batch(dsb_ctx *ctx, const dsb_read *reads, size_t n, dsb_result *out);
+
+/* the same, split so that a benchmark can time the device part with inputs resident in HBM */
+int  dsb_batch_upload(dsb_ctx *ctx, const dsb_read *reads, size_t n);
+int  dsb_batch_run(dsb_ctx *ctx);                       /* all kernels, synchronous */
+int  dsb_batch_fetch(dsb_ctx *ctx, dsb_result *out);
+int  dsb_batch_timing(const dsb_ctx *ctx, dsb_timing *t);
+/* stage dumps of the last run: seeds of one read strand (1 = forward, 0 = reverse) */
+int  dsb_batch_seeds(dsb_ctx *ctx, size_t read, int strand, dsb_seed *out, size_t cap, uint32_t *n, uint32_t *total_score);
+/* exist-kmer hit bits of one read strand, one byte per window */
+int  dsb_batch_exist_bits(dsb_ctx *ctx, size_t read, int strand, uint8_t *out, size_t cap, uint32_t *n);
+
+/* output_one_result_sam (src/cly_mt.c:245-344): format the records of one read into buf;
+ * returns the number of bytes written (excluding the NUL), or -1 if cap is too small */
+long dsb_format_sam(const dsb_index *idx, const dsb_read *read, const dsb_hit *hits, uint32_t n_hits,
+                    int max_sec_N, int full, char *buf, size_t cap);
+
+const char *dsb_strerror(int code);
+const char *dsb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -401,6 +401,7 @@ static chain_t *push_hit(ora_ctx_t *c)
 static sms_t *push_sms(ora_ctx_t *c)
 {
 	if (c->n_sms == c->m_sms) { c->m_sms = c->m_sms ? c->m_sms << 1 : 64; c->sms = realloc(c->sms, c->m_sms * sizeof(sms_t)); }
+	if (c->n_sms + 1 > c->cnt[6]) c->cnt[6] = c->n_sms + 1;
 	return c->sms + c->n_sms++;     /* not cleared: the reference leaves fields stale too (src/lib/kvec.h:103-109) */
 }
 

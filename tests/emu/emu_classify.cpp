@@ -1,0 +1,140 @@
+// TEST INFRASTRUCTURE: runs the DEVICE code of desamba_amd (dsb_classify_dev.h, dsb_probe.h) on the
+// host as a 1-lane wave (-DDSB_HOST_EMU), so the per-read logic can be checked against the oracle
+// with `pytest -m "not gpu"`, gdb and sanitizers.  Not linked into libdesamba_amd.so.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "dsb_device.h"
+#include "dsb_probe.h"
+#include "dsb_classify_dev.h"
+#include "dsb_host.h"
+
+struct EmuCtx {
+	DsbDevIndex dx; std::vector<uint8_t> arena; uint32_t max_len; WCtx w;
+	std::vector<uint8_t> bin; std::vector<uint64_t> pk, bits;
+	std::vector<DsbSeed> seedsF, seedsR;
+};
+
+static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+extern "C" void *emu_new(dsb_index *idx, int min_len, int min_score)
+{
+	const DsbHostIndex *h = dsb_index_host(idx);
+	EmuCtx *e = new EmuCtx();
+	DsbDevIndex &dx = e->dx; memset(&dx, 0, sizeof dx);
+	dx.ek0 = h->ek0; dx.ek1 = h->ek1; dx.ek_mask = h->ek_mask; dx.ek_len = h->ek_len; dx.single_base_max = h->single_base_max;
+	dx.fm = h->fm; dx.bwt_len = h->bwt_len; memcpy(dx.rank, h->rank, sizeof dx.rank); dx.dollar_pos = h->dollar_pos; dx.dollar_row = h->dollar_row;
+	dx.hash_index = h->hash_index; dx.sa = (const uint2 *)h->sa; dx.uni = (const uint2 *)h->uni; dx.refpos = h->refpos; dx.refbin = h->refbin;
+	dx.refinfo = h->refinfo; dx.qmem = h->Q_MEM; dx.qlv = &h->Q_LV[0][0];
+	dx.filter_min_length = min_len; dx.filter_min_score = min_score; dx.filter_min_score_LV3 = min_score + 10;
+	e->max_len = 0;
+	return e;
+}
+extern "C" void emu_free(void *p) { delete (EmuCtx *)p; }
+
+static void setup_arena(EmuCtx *e, uint32_t L)
+{
+	if (L <= e->max_len) return;
+	e->max_len = L + L / 4 + 1024;
+	size_t o = 0, off[16]; int k = 0;
+	auto add = [&](size_t n) { off[k++] = o; o += al(n); };
+	add(((size_t)(e->max_len >> 1) + 64) * sizeof(DsbSeed));            // 0 seeds
+	add((size_t)DSB_ANC_CAP * sizeof(DsbAnchor)); add((size_t)DSB_ANC_CAP * sizeof(DsbAnchor));  // 1,2
+	add((size_t)DSB_HIT_CAP * sizeof(DsbChain)); add((size_t)DSB_HIT_CAP * sizeof(DsbChain));    // 3,4
+	add((size_t)DSB_SMS_CAP * sizeof(DsbSms));                           // 5
+	add(2 * ((size_t)(1u << 18) + 2 * (size_t)e->max_len) * 4);          // 6 kh
+	add((size_t)(256 + 2 * 400 + 64) * sizeof(DsbScHash));               // 7
+	add((size_t)DSB_MEMSLOW_CAP * sizeof(DsbMem));                       // 8
+	add((size_t)DSB_SPSET_CAP * 8); add(1024 * sizeof(int));             // 9,10
+	add((size_t)2 * DSB_ANC_CAP * 8); add((size_t)2 * DSB_ANC_CAP * 4);  // 11,12
+	add(3 * DSB_REFWIN);                                                 // 13
+	e->arena.assign(o + 256, 0xCD);
+	uint8_t *s = e->arena.data(); WCtx &w = e->w;
+	w.x = &e->dx; w.lane = 0; w.dbg = nullptr;
+	w.seeds = (DsbSeed *)(s + off[0]); w.anc = (DsbAnchor *)(s + off[1]); w.anc_tmp = (DsbAnchor *)(s + off[2]);
+	w.hit = (DsbChain *)(s + off[3]); w.hit_tmp = (DsbChain *)(s + off[4]); w.sms = (DsbSms *)(s + off[5]);
+	uint32_t *kh = (uint32_t *)(s + off[6]); size_t st = (size_t)(1u << 18) + 2 * (size_t)e->max_len;
+	w.kh_head[0] = kh; w.kh_next[0] = kh + (1u << 18); w.kh_kmer[0] = w.kh_next[0] + e->max_len;
+	w.kh_head[1] = kh + st; w.kh_next[1] = w.kh_head[1] + (1u << 18); w.kh_kmer[1] = w.kh_next[1] + e->max_len;
+	w.sc = (DsbScHash *)(s + off[7]); w.mem_slow = (DsbMem *)(s + off[8]); w.spset = (uint64_t *)(s + off[9]); w.score_v = (int *)(s + off[10]);
+	w.sortkey = (uint64_t *)(s + off[11]); w.sortidx = (uint32_t *)(s + off[12]);
+	w.win_mid = s + off[13]; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
+}
+
+// returns n_hits (or -status when a cap/timeout status was raised); hits as DsbHitOut
+extern "C" int emu_classify(void *p, const char *seq, uint32_t L, int hist_max, DsbHitOut *out, int max_out, uint8_t *bitsF_out, uint8_t *bitsR_out)
+{
+	EmuCtx *e = (EmuCtx *)p; const DsbDevIndex &dx = e->dx;
+	setup_arena(e, L);
+	// k_encode_bytes
+	e->bin.assign(DSB_QPAD_L + 2 * (size_t)L + DSB_QPAD_R, 0);
+	uint8_t *F = e->bin.data() + DSB_QPAD_L, *R = F + L;
+	for (uint32_t i = 0; i < L; i++) { unsigned char ch = seq[i]; uint32_t c = (ch == 'A' || ch == 'a') ? 0u : (ch == 'G' || ch == 'g') ? 2u : (ch == 'T' || ch == 't') ? 3u : 1u; F[i] = c; R[L - 1 - i] = 3 - c; }
+	memset(R + L, DSB_QPAD_R_VAL, DSB_QPAD_R);
+	// k_encode_pack
+	uint32_t nw = (L + 31) / 32 + 1;
+	e->pk.assign(2 * (size_t)nw, 0);
+	for (uint32_t t = 0; t < 2 * nw; t++) {
+		uint32_t sr = t >= nw, wi = sr ? t - nw : t; const uint8_t *S = sr ? R : F; uint64_t v = 0;
+		for (uint32_t b = 0; b < 32; b++) { uint32_t q = wi * 32 + b; v = (v << 2) | (q < L ? S[q] : 0u); }
+		e->pk[t] = v;
+	}
+	// k_seed_probe
+	uint32_t n_win = L >= 40 ? L - dx.ek_len + 1 : 0, n_words = (n_win + 63) / 64;
+	e->bits.assign(2 * (size_t)n_words + 2, 0);
+	uint64_t kmask = dx.ek_len >= 32 ? ~0ULL : ((1ULL << (2 * dx.ek_len)) - 1ULL);
+	for (int s = 0; s < 2; s++)
+		for (uint32_t q = 0; q < n_win; q++) {
+			int t1 = 0;
+			int hit = dsb_probe_window(e->pk.data() + (s ? nw : 0), q, dx.ek_len, kmask, dx.single_base_max, dx.ek0, dx.ek1, dx.ek_mask, &t1);
+			if (hit) e->bits[(s ? n_words : 0) + (q >> 6)] |= 1ULL << (q & 63);
+			uint8_t *bo = s ? bitsR_out : bitsF_out;
+			if (bo) bo[q] = (uint8_t)hit;
+		}
+	WCtx &w = e->w;
+	w.bin = F; w.L = L; w.status = 0; w.max_read_l = hist_max;
+	classify_read(w, e->bits.data(), e->bits.data() + n_words);
+	if (w.status) return -(w.status | (w.stage << 8));
+	int n = (int)w.n_hit < max_out ? (int)w.n_hit : max_out;
+	for (int i = 0; i < n; i++) {
+		DsbChain h = w.hit[i]; DsbHitOut o;
+		o.ref_ID = h.ref_ID; o.t_st = h.t_st; o.t_ed = h.t_ed; o.q_st = h.q_st; o.q_ed = h.q_ed; o.sum_score = h.sum_score; o.indel = h.indel;
+		o.direction = h.direction; o.primary = h.primary; o.pri_index = h.pri_index; o.pad = 0;
+		out[i] = o;
+	}
+	return (int)w.n_hit;
+}
+
+extern "C" int emu_seeds(void *p, int strand, DsbSeed *out, int max_out, uint32_t *total)
+{
+	EmuCtx *e = (EmuCtx *)p; WCtx &w = e->w;
+	SDir *sd = (w.sd[0].direction == (uint32_t)strand) ? &w.sd[0] : &w.sd[1];
+	int n = (int)sd->l_seed_v < max_out ? (int)sd->l_seed_v : max_out;
+	for (int i = 0; i < n; i++) out[i] = sd->seed_v[i];
+	if (total) *total = sd->total_score;
+	return (int)sd->l_seed_v;
+}
+
+#ifdef EMU_MAIN
+int main(int argc, char **argv)
+{
+	dsb_index *idx; if (dsb_index_open(argv[1], &idx)) return 1;
+	void *e = emu_new(idx, 170, 64);
+	FILE *f = fopen(argv[2], "r"); static char line[1 << 20]; long n = 0; int hist = 0; int limit = argc > 3 ? atoi(argv[3]) : 1 << 30;
+	DsbHitOut hits[512];
+	while (fgets(line, sizeof line, f)) {
+		if (n % 4 == 1) {
+			size_t l = strlen(line); if (l && line[l - 1] == '\n') line[--l] = 0;
+			int nh = emu_classify(e, line, (uint32_t)l, hist, hits, 512, NULL, NULL);
+			if ((int)l > hist) hist = (int)l;
+			printf("read %ld len %zu nh %d", n / 4, l, nh);
+			for (int i = 0; i < nh && i < 3; i++) printf(" [%u %u %u %u %u AS %u d%u p%u/%u]", hits[i].ref_ID, hits[i].t_st, hits[i].t_ed, hits[i].q_st, hits[i].q_ed, hits[i].sum_score, hits[i].direction, hits[i].primary, hits[i].pri_index);
+			printf("\n");
+			if (n / 4 + 1 >= limit) break;
+		}
+		n++;
+	}
+	return 0;
+}
+#endif
