@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/synth/* from the REFERENCE itself (needs /root/reference, i.e. this
+container): small deterministic read sets (tools/readsim) and the SAM that the reference's
+UB-pinned build (oracle/_ref/deSAMBA_ubfree, see oracle/Makefile) writes for them, plus the stock
+reference's SAM for comparison.  Fixtures are data (inputs + expected outputs), no source."""
+import hashlib
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.join(ROOT, "tests", "golden", "synth")
+REF = os.path.join(ROOT, "oracle", "_ref")
+DEMO = os.path.join(ROOT, "data", "demo")
+
+
+def run(cmd):
+    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+
+
+def main():
+    subprocess.check_call([os.path.join(ROOT, "tools", "make_demo_index.sh"), DEMO])
+    idx = os.path.join(DEMO, "index")
+    sim = os.path.join(ROOT, "tools", "readsim")
+    sets = [("ont20k", 12, 20000, 0.15, 11, "ont"), ("ngs150", 400, 150, 0.01, 12, "ngs"), ("pb", 24, 0, 0.13, 13, "pacbio"),
+            ("ont5k_e25", 30, 5000, 0.25, 14, "ont")]
+    for name, n, L, e, seed, prof in sets:
+        fq = os.path.join(OUT, name + ".fq")
+        run([sim, idx, fq, str(n), str(L), str(e), str(seed), prof])
+        run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx, fq, "-o", os.path.join(OUT, name + ".ubfree.sam")])
+        run([os.path.join(REF, "deSAMBA"), "classify", "-t", "1", idx, fq, "-o", os.path.join(OUT, name + ".stock.sam")])
+    # the smallest reproducer of the stock reference's history dependence
+    appc = os.path.join(OUT, "appc.fq")
+    with open(appc, "w") as f:
+        f.write("@r57271\nTTTATGTTTTATTTTTGGAATTGAAACTGATAGTGATTCTTTTGATGAATCATCATGTTTATGTTCATCAGATTTAGATCTGATTGAGTGTGAGAAGATTACTGTAAATGAAGCACCTAAATGTTTTGCAGAGTTTGAAAGACAGTGGGA\n+\n" + "5" * 150 + "\n")
+        f.write("@r57290\nAATGCTCAGGTGGAGGAGGTCAGAGTGTATGATGGTACGGAGGAACTACCAGGGGATCCAGATATGATGAGATACATTGATAGATATGGTCAACACCAAACAAAAGATGCTGTAGAACAGGTGCTGCTTTATTAAGATGCTGTAGAACAGG\n+\n" + "5" * 151 + "\n")
+    run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx, appc, "-o", os.path.join(OUT, "appc.ubfree.sam")])
+    run([os.path.join(REF, "deSAMBA"), "classify", "-t", "1", idx, appc, "-o", os.path.join(OUT, "appc.stock.sam")])
+    # demo: the reference's own quick-start output (README.md:30-42): md5 + first 60 lines
+    demo_sam = os.path.join(DEMO, "ref_demo.sam")
+    run([os.path.join(REF, "deSAMBA"), "classify", "-t", "4", idx, os.path.join(DEMO, "ERR1050068.fastq"), "-o", demo_sam])
+    data = open(demo_sam, "rb").read()
+    with open(os.path.join(ROOT, "tests", "golden", "demo_sam.md5"), "w") as f:
+        f.write(hashlib.md5(data).hexdigest() + "\n")
+    with open(os.path.join(ROOT, "tests", "golden", "demo_head60.sam"), "wb") as f:
+        f.write(b"".join(data.splitlines(True)[:60]))
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,48 @@
+"""The DEVICE code (desamba_amd/csrc/dsb_classify_dev.h, dsb_probe.h) compiled for the host as a 1-lane
+wave (tests/emu) against the oracle: seed-probe bits, seed lists, final hits.  Runs without a GPU."""
+import os
+
+import pytest
+
+from conftest import GOLDEN
+
+
+@pytest.fixture(scope="module")
+def emu(demo):
+    import emu_lib
+    return emu_lib.Emu(demo["index"])
+
+
+def _cmp(emu, oracle, recs, check_stages=False):
+    hist = 0
+    for name, seq, q in recs:
+        exp = oracle.classify(seq, hist)
+        if check_stages:
+            got, bF, bR = emu.classify(seq, hist, want_bits=True)
+            if len(seq) >= 40:
+                n = len(seq) - 16 + 1
+                assert bytes(bF[:n]) == bytes(oracle.exist_bits(seq, 1)[:n])
+                assert bytes(bR[:n]) == bytes(oracle.exist_bits(seq, 0)[:n])
+                for s in (1, 0):
+                    assert emu.seeds(s) == oracle.seeds(s)
+        else:
+            got = emu.classify(seq, hist)
+        assert got == exp, name
+        hist = max(hist, len(seq))
+
+
+def test_demo_reads(emu, oracle, demo):
+    import desamba_amd as D
+    _cmp(emu, oracle, D.read_fastq(demo["fastq"], 400), check_stages=True)
+
+
+@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc"])
+def test_synthetic(emu, oracle, name):
+    import desamba_amd as D
+    _cmp(emu, oracle, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")), check_stages=(name in ("ngs150", "appc")))
+
+
+def test_edge_cases(emu, oracle):
+    recs = [(b"short", b"ACGT" * 9, None), (b"min", b"ACGTTGCA" * 5, None), (b"polyA", b"A" * 300, None),
+            (b"allN", b"N" * 200, None), (b"lower", b"acgtnnacgt" * 30, None), (b"l39", b"A" * 39, None), (b"empty", b"", None)]
+    _cmp(emu, oracle, recs, check_stages=True)

@@ -1,0 +1,129 @@
+"""GPU parity tests proper: everything goes through the C-ABI of libdesamba_amd.so on a real MI355X and is
+compared bit for bit with the oracle / the committed golden SAM."""
+import hashlib
+import os
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(demo):
+    import desamba_amd as D
+    idx = D.Index(demo["index"])
+    ctx = D.Ctx(idx, 0)
+    yield D, idx, ctx
+    ctx.close(); idx.close()
+
+
+def classify_all(D, ctx, recs, chunk=None):
+    """-> (list of hit-key lists, SAM bytes); history is reset like a new input file"""
+    ctx.reset_history()
+    out, sam = [], []
+    chunk = chunk or len(recs) or 1
+    for s in range(0, max(len(recs), 1), chunk):
+        part = recs[s:s + chunk]
+        reads = D.make_reads(part)
+        res = ctx.classify(reads)
+        for i in range(len(part)):
+            rr = res.reads[i]
+            assert rr.status == 0
+            out.append([res.hits[rr.first + k].key() for k in range(rr.n)])
+        sam.append(ctx.sam(res))
+    return out, b"".join(sam)
+
+
+def test_demo_sam_md5(gpu, demo, golden_md5):
+    """config 1: the reference's quick-start run, byte-identical SAM"""
+    D, idx, ctx = gpu
+    hits, sam = classify_all(D, ctx, D.read_fastq(demo["fastq"]))
+    assert hashlib.md5(sam).hexdigest() == golden_md5
+
+
+@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc"])
+def test_synthetic_golden_sam(gpu, name):
+    D, idx, ctx = gpu
+    hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))
+    assert sam == open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read()
+
+
+def test_stage_parity_seed_lookup(gpu, demo, oracle):
+    """exist-kmer bits of every window and the seed lists (a-3) of both strands"""
+    D, idx, ctx = gpu
+    recs = D.read_fastq(demo["fastq"], 64) + D.read_fastq(os.path.join(GOLDEN, "synth", "ngs150.fq"), 64)
+    reads = D.make_reads(recs)
+    ctx.reset_history(); ctx.classify(reads)
+    hist = 0
+    for i, (nm, seq, q) in enumerate(recs):
+        oracle.classify(seq, hist); hist = max(hist, len(seq))
+        n = len(seq) - 16 + 1
+        for s in (1, 0):
+            assert ctx.exist_bits(i, s) == bytes(oracle.exist_bits(seq, s)[:n])
+            assert ctx.seeds(i, s) == oracle.seeds(s)
+
+
+def test_long_reads_vs_oracle(gpu, demo, oracle, tmp_path):
+    """full-size reads (50 kbp ONT-15%), fresh seed, checked hit by hit against the oracle"""
+    import subprocess
+    D, idx, ctx = gpu
+    fq = tmp_path / "ont50k.fq"
+    subprocess.check_call([os.path.join(ROOT, "tools", "readsim"), demo["index"], str(fq), "96", "50000", "0.15", "4242", "ont"])
+    recs = D.read_fastq(str(fq))
+    hits, _ = classify_all(D, ctx, recs)
+    hist = 0
+    for (nm, seq, q), got in zip(recs, hits):
+        assert got == oracle.classify(seq, hist), nm
+        hist = max(hist, len(seq))
+
+
+def test_edge_cases(gpu, oracle):
+    D, idx, ctx = gpu
+    recs = [(b"short", b"ACGT" * 9, None), (b"min", b"ACGTTGCA" * 5, None), (b"polyA", b"A" * 300, None),
+            (b"allN", b"N" * 200, None), (b"lower", b"acgtnnacgt" * 30, None), (b"l39", b"A" * 39, None), (b"empty", b"", None)]
+    hits, sam = classify_all(D, ctx, recs)
+    hist = 0
+    for (nm, seq, q), got in zip(recs, hits):
+        assert got == oracle.classify(seq, hist), nm
+        hist = max(hist, len(seq))
+    assert sam.count(b"\t4\t*\t0\t0\t*\t*\t0\t0\t*\t*\t\n") >= 4
+    # empty batch
+    res = ctx.classify(D.make_reads([]))
+    assert res.n_hits == 0
+
+
+def test_batch_split_invariance(gpu, demo):
+    """results do not depend on how the input is cut into batches or on the number of reads in flight:
+    the running max_read_l (oracle U4) is carried across batches"""
+    D, idx, ctx = gpu
+    recs = D.read_fastq(os.path.join(GOLDEN, "synth", "pb.fq")) + D.read_fastq(os.path.join(GOLDEN, "synth", "ngs150.fq"), 100)
+    whole, sam_whole = classify_all(D, ctx, recs)
+    split, sam_split = classify_all(D, ctx, recs, chunk=7)
+    assert whole == split and sam_whole == sam_split
+    ctx2 = D.Ctx(idx, 0, n_slots=3)
+    few, sam_few = classify_all(D, ctx2, recs)
+    ctx2.close()
+    assert few == whole
+
+
+def test_idempotent_rerun(gpu, demo):
+    D, idx, ctx = gpu
+    recs = D.read_fastq(demo["fastq"], 200)
+    reads = D.make_reads(recs)
+    ctx.reset_history(); ctx.upload(reads)
+    ctx.run(); a = ctx.sam(ctx.fetch())
+    ctx.run(); b = ctx.sam(ctx.fetch())
+    assert a == b
+
+
+def test_cli_drop_in(gpu, demo, golden_md5, tmp_path):
+    """the `deSAMBA classify` CLI: same command line, byte-identical output file"""
+    import subprocess
+    out = tmp_path / "cli.sam"
+    cli = os.path.join(ROOT, "desamba_amd", "bin", "deSAMBA")
+    p = subprocess.run([cli, "classify", "-t", "4", demo["index"], demo["fastq"], "-o", str(out)], stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr
+    assert b"1237 sequences processed in" in p.stderr and b"loading index" in p.stderr
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == golden_md5

@@ -1,0 +1,69 @@
+"""The oracle (oracle/*.c) against the reference's own outputs: the demo quick-start SAM (md5),
+golden SAM of synthetic sets written by the reference's UB-pinned build, and SURVEY.md Appendix C."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT, md5_file, sam_lines
+
+SETS = ["ont20k", "ngs150", "pb", "ont5k_e25", "appc"]
+
+
+def test_demo_md5(demo, oracle, golden_md5, tmp_path):
+    out = tmp_path / "demo.sam"
+    n, bases = oracle.classify_file(demo["fastq"], str(out), threads=4)
+    assert n == 1237 and bases == 2153923
+    assert md5_file(str(out)) == golden_md5 == "1da908b61be240c40334b58d3c12ba2a"
+    assert sam_lines(str(out))[:60] == sam_lines(os.path.join(GOLDEN, "demo_head60.sam"))
+
+
+@pytest.mark.parametrize("name", SETS)
+def test_synthetic_golden(demo, oracle, name, tmp_path):
+    """bit-exact against the reference built with its UB pinned (oracle.h U1-U5)"""
+    out = tmp_path / (name + ".sam")
+    oracle.classify_file(os.path.join(GOLDEN, "synth", name + ".fq"), str(out), threads=2)
+    assert sam_lines(str(out)) == sam_lines(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"))
+
+
+@pytest.mark.parametrize("name", SETS)
+def test_distance_to_stock_reference(name):
+    """the stock binary differs from the UB-free build only in AS / POS / CIGAR digits, never in the
+    per-read list of (flag, reference) -- SURVEY.md 8a-UB"""
+    a = sam_lines(os.path.join(GOLDEN, "synth", name + ".stock.sam"))
+    b = sam_lines(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"))
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        fx, fy = x.split(b"\t"), y.split(b"\t")
+        assert fx[:3] == fy[:3]
+
+
+def test_appendix_c_history_independence(demo, oracle):
+    """r57290 must score AS:i:125 whether or not r57271 precedes it (the stock reference gives 110 then)"""
+    import desamba_amd as D
+    recs = D.read_fastq(os.path.join(GOLDEN, "synth", "appc.fq"))
+    alone = oracle.classify(recs[1][1], 0)
+    oracle.classify(recs[0][1], 0)
+    after = oracle.classify(recs[1][1], len(recs[0][1]))
+    assert alone == after
+    assert alone[0][5] == 125
+
+
+def test_thread_invariance(demo, oracle, tmp_path):
+    a, b = tmp_path / "t1.sam", tmp_path / "t4.sam"
+    fq = os.path.join(GOLDEN, "synth", "pb.fq")
+    oracle.classify_file(fq, str(a), threads=1); oracle.classify_file(fq, str(b), threads=4)
+    assert md5_file(str(a)) == md5_file(str(b))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "deSAMBA_ubfree")), reason="reference build absent")
+def test_against_live_reference(demo, oracle, tmp_path):
+    """run the compiled reference (UB-pinned build) here and compare on a fresh synthetic set"""
+    fq = tmp_path / "live.fq"
+    subprocess.check_call([os.path.join(ROOT, "tools", "readsim"), demo["index"], str(fq), "60", "8000", "0.15", "77", "ont"])
+    ref_out, ora_out = tmp_path / "ref.sam", tmp_path / "ora.sam"
+    subprocess.check_call([os.path.join(ROOT, "oracle", "_ref", "deSAMBA_ubfree"), "classify", "-t", "2", demo["index"], str(fq), "-o", str(ref_out)],
+                          stderr=subprocess.DEVNULL)
+    oracle.classify_file(str(fq), str(ora_out), threads=2)
+    assert sam_lines(str(ora_out)) == sam_lines(str(ref_out))
