@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=50000)
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slots", type=int, default=0, help="reads in flight per GPU (0 = library default)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -110,7 +111,7 @@ def main():
     gen_reads(index_dir, fq, a.reads_per_gpu, a.read_len, 1 + rank)
     recs = D.read_fastq(fq)
     idx = D.Index(index_dir)
-    ctx = D.Ctx(idx, local)
+    ctx = D.Ctx(idx, local, n_slots=a.slots)
     reads = D.make_reads(recs)
     bases = sum(len(r[1]) for r in recs)
     ctx.upload(reads)                       # inputs resident in HBM before the timed region

@@ -31,7 +31,7 @@ class DsbHit(C.Structure):
 
 
 class DsbReadResult(C.Structure):
-    _fields_ = [("first", C.c_uint32), ("n", C.c_uint32), ("status", C.c_int32), ("fast", C.c_uint32)]
+    _fields_ = [("first", C.c_uint32), ("n", C.c_uint32), ("status", C.c_int32), ("fast", C.c_uint32), ("device_us", C.c_uint32)]
 
 
 class DsbResult(C.Structure):

@@ -36,6 +36,13 @@ template <class T> static inline T dsb_shfl(T v, int) { return v; }
 #define D_U64MAX 0xffffffffffffffffULL
 #define DSB_STEP_LIMIT 20000000u
 #define SPENT(w) (++(w).steps > DSB_STEP_LIMIT)
+#ifdef DSB_HOST_EMU
+#define DSB_CLOCK() 0ULL
+#else
+#define DSB_CLOCK() wall_clock64()
+#endif
+// stage timers (100 MHz ticks), accumulated per slot when DSB_DEBUG is set
+#define TICK(w, k) do { if ((w).dbg) { uint64_t _t = DSB_CLOCK(); (w).tacc[k] += _t - (w).tlast; (w).tlast = _t; } } while (0)
 #define MARK(w, code) do { if ((w).dbg && (w).lane == 0) { (w).dbg[0] = (code); (w).dbg[1] = (w).steps; } } while (0)
 
 DV void wave_sync()
@@ -47,6 +54,27 @@ DV void wave_sync()
 #endif
 }
 
+// wave-level helpers (1-lane versions in the host emulation)
+#ifdef DSB_HOST_EMU
+DV int wave_max_i(int v) { return v; }
+DV uint32_t wave_excl_scan_u(uint32_t v, uint32_t *total) { *total = v; return 0; }
+#else
+DV int wave_max_i(int v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { int u = __shfl_xor(v, o); v = u > v ? u : v; }
+	return v;
+}
+DV uint32_t wave_excl_scan_u(uint32_t v, uint32_t *total)
+{
+	uint32_t inc = v; const int lane = __lane_id();
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+	*total = __shfl(inc, 63);
+	return inc - v;
+}
+#endif
+
 struct SDir { DsbSeed *seed_v; uint32_t l_seed_v; uint8_t *bin_read; const uint64_t *bits; uint32_t direction, total_score; };
 
 struct WCtx {
@@ -54,7 +82,8 @@ struct WCtx {
 	int lane;
 	uint8_t *bin; uint32_t L;
 	DsbSeed *seeds;
-	DsbAnchor *anc, *anc_tmp; uint32_t n_anc;
+	DsbAnchor *anc, *anc_tmp; uint32_t n_anc, anc_cap;
+	DsbAnchor *lane_anc; uint64_t *lane_spset; uint32_t *top_idx;   // per-lane scratch of the island-parallel fast_classify
 	DsbChain *hit, *hit_tmp; uint32_t n_hit;
 	DsbSms *sms; uint32_t n_sms;
 	uint32_t *kh_head[2], *kh_next[2], *kh_kmer[2];
@@ -64,8 +93,9 @@ struct WCtx {
 	int *score_v;
 	uint64_t *sortkey; uint32_t *sortidx;      // 2 x cap each (ping-pong)
 	uint8_t *win_mid, *win_right, *win_left;
+	uint32_t *lds_tab;         // 256 words of LDS scratch (conflict filter of the 9-mer table build)
 	int status; int max_read_l;
-	int stage; uint32_t steps; volatile uint32_t *dbg;   // optional host-visible progress words (DSB_DEBUG)
+	int stage; uint32_t steps; volatile uint32_t *dbg; uint64_t tacc[10], tlast;   // optional host-visible progress words (DSB_DEBUG)
             // loop-iteration budget: every unbounded loop charges it and bails when exhausted
 	SDir sd[2];
 };
@@ -327,7 +357,7 @@ DV void get_new_ed(const DsbDevIndex *x, uint32_t *e_d, uint32_t *len_, uint32_t
 
 DV DsbAnchor *push_anchor(WCtx &w)
 {
-	if (w.n_anc >= DSB_ANC_CAP) { w.status |= DSB_ST_ANC_OVF; return w.anc + DSB_ANC_CAP - 1; }
+	if (w.n_anc >= w.anc_cap) { w.status |= DSB_ST_ANC_OVF; return w.anc + w.anc_cap - 1; }
 	return w.anc + w.n_anc++;
 }
 
@@ -443,28 +473,73 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 // src/cly.c:1071-1234).  The probe kernel has answered get_exist_kmer for every window.
 DV int ebit(const uint64_t *bits, uint32_t i) { return (int)((bits[i >> 6] >> (i & 63)) & 1ULL); }
 
+// number of consecutive set bits at positions start, start+1, ... (< n), at most maxc
+DV uint32_t run_ones_up(const uint64_t *bits, uint32_t n, uint32_t start, uint32_t maxc)
+{
+	uint32_t c = 0;
+	while (c < maxc && start < n) {
+		uint32_t b = start & 63;
+		uint64_t x = ~(bits[start >> 6] >> b);              // zeros where the run continues
+		uint32_t avail = 64 - b, r = x ? (uint32_t)__builtin_ctzll(x) : 64u;
+		if (r > avail) r = avail;
+		if (r > n - start) r = n - start;
+		if (r > maxc - c) r = maxc - c;
+		c += r; start += r;
+		if (r < avail && c < maxc) break;                    // hit a zero (or n) inside the word
+	}
+	return c;
+}
+// consecutive set bits at positions start, start-1, ... (>= 0), at most maxc
+DV uint32_t run_ones_down(const uint64_t *bits, int start, uint32_t maxc)
+{
+	uint32_t c = 0;
+	while (c < maxc && start >= 0) {
+		uint32_t b = (uint32_t)start & 63;
+		uint64_t x = ~(bits[start >> 6] << (63 - b));
+		uint32_t avail = b + 1, r = x ? (uint32_t)__builtin_clzll(x) : 64u;
+		if (r > avail) r = avail;
+		if (r > maxc - c) r = maxc - c;
+		c += r; start -= (int)r;
+		if (r < avail && c < maxc) break;
+	}
+	return c;
+}
+#define DSB_M3 0x9249249249249249ULL      /* bits 0,3,6,...,63 */
+
 DN void seed_vector(WCtx &w, uint8_t *bin, const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t direction, SDir *out)
 {
+	// Same scan as search_exist_kmer_M2 (probe every 3rd window, extend back <= 2, forward to len 61,
+	// resume 3 past the seed), but 64 windows per load: the next probe hit is a ctz over the word
+	// masked to the probe phase, the extensions are run-length counts.
 	uint32_t ns = 0;
 	if (direction == D_FORWARD) {
-		for (uint32_t i = 3 - 1; i < n; i += 3) {
-			if (ebit(bits, i) == 1) {
-				uint32_t offset = i, len = 1;
-				for (int j = 1; j < 3; ++j) { if (ebit(bits, i - j) == 1) { offset--; len++; } else break; }
-				for (int j = 1; i + j < n; ++j) { if (ebit(bits, i + j) == 1) { len++; if (len > 60) break; } else break; }
-				sv[ns].offset = offset; sv[ns].len = len; ns++;
-				i = offset + len;
-			}
+		uint32_t i = 3 - 1;
+		while (i < n) {
+			uint32_t b = i & 63;
+			uint64_t x = (bits[i >> 6] >> b) & DSB_M3;
+			if (!x) { i += ((64 - b + 2) / 3) * 3; continue; }
+			i += (uint32_t)__builtin_ctzll(x);
+			if (i >= n) break;
+			uint32_t back = 0;
+			if (ebit(bits, i - 1)) { back = 1; if (ebit(bits, i - 2)) back = 2; }
+			uint32_t offset = i - back, len = 1 + back;
+			len += run_ones_up(bits, n, i + 1, 61 - len);
+			sv[ns].offset = offset; sv[ns].len = len; ns++;
+			i = offset + len + 3;
 		}
 	} else {
-		for (int i = n - 3; i >= 0; i -= 3) {
-			if (ebit(bits, i) == 1) {
-				uint32_t offset = i, len = 1;
-				for (int j = 1; j < 3; ++j) { if (ebit(bits, i + j) == 1) { offset++; len++; } else break; }
-				for (int j = 1; j <= i; ++j) { if (ebit(bits, i - j) == 1) { len++; if (len > 60) break; } else break; }
-				sv[ns].offset = offset - len + 1; sv[ns].len = len; ns++;
-				i = offset - len;
-			}
+		int i = (int)n - 3;
+		while (i >= 0) {
+			uint32_t b = (uint32_t)i & 63;
+			uint64_t x = (bits[i >> 6] << (63 - b)) & DSB_M3;
+			if (!x) { i -= (int)(((b + 1 + 2) / 3) * 3); continue; }
+			i -= (int)__builtin_clzll(x);
+			uint32_t fwd = 0;
+			if (ebit(bits, i + 1)) { fwd = 1; if (ebit(bits, i + 2)) fwd = 2; }
+			uint32_t offset = (uint32_t)i + fwd, len = 1 + fwd;
+			len += run_ones_down(bits, i - 1, 61 - len);
+			sv[ns].offset = offset - len + 1; sv[ns].len = len; ns++;
+			i = (int)(offset - len) - 3;
 		}
 	}
 	uint32_t total = 0; int max_index = 0; uint32_t max_length = 0, index_end = 100;
@@ -484,41 +559,81 @@ DN void seed_vector(WCtx &w, uint8_t *bin, const uint64_t *bits, uint32_t n, Dsb
 	out->seed_v = sv; out->l_seed_v = ns; out->bin_read = bin; out->bits = bits; out->direction = direction; out->total_score = total;
 }
 
-// fast_classify (src/cly.c:1478-1546)
-DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
+// One top island of fast_classify (src/cly.c:1494-1543): the backward MEM walk over the island, the
+// anchors of each MEM, and the "useless" marking among this island's anchors.  Appends to w.anc.
+// Returns 1 when the reference would also skip the following seed (max_score > 512, src/cly.c:1530-1531).
+DV int fast_island(WCtx &w, SDir *s_d, uint32_t read_len, uint32_t seed_idx)
 {
 	const DsbDevIndex *x = w.x;
 	int l_ek = x->ek_len, min_index = 21 - l_ek;
 	uint8_t *bin_read = s_d->bin_read;
 	SpSet sp_set = {w.spset, 0, DSB_SPSET_CAP};
 	DsbMem m_r[2];
-	DsbSeed *sv_b = s_d->seed_v, *sv_e = sv_b + s_d->l_seed_v;
-	for (DsbSeed *c_sv = sv_b; c_sv < sv_e; c_sv++) {
-		if (c_sv->top == 0) continue;
-		sp_set.l = 0;
-		uint16_t seed_ID = (uint16_t)(c_sv - sv_b);
-		uint32_t a_b_idx = w.n_anc;
-		uint32_t sv_off = c_sv->offset;
-		for (int j = (int)c_sv->len - 1; j >= min_index;) {
-			if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; return; }
-			int kmer_index = sv_off + j;
-			int string_index = kmer_index + l_ek - 1;
-			uint64_t prefixValue = prefix13(bin_read, string_index);
-			int n = bwt_MEM_search(x, bin_read + string_index, prefixValue, 2, 21 - 1, string_index, sp_set, m_r);
-			if (n == 0) { j -= 2; continue; }
-			j -= 3;
-			int max_score = 0;
-			for (int q = 0; q < n; ++q) {
-				m_r[q].read_offset = string_index - m_r[q].match_len;
-				int sc = map_seed(w, m_r[q], bin_read, read_len, seed_ID, (uint8_t)s_d->direction);
-				max_score = MAXV(sc, max_score);
-			}
-			if (max_score > 35) j -= 7;
-			if (max_score > 256) { if (max_score > 512) c_sv++; break; }
+	DsbSeed sv = s_d->seed_v[seed_idx];
+	int skip_next = 0;
+	uint32_t a_b_idx = w.n_anc;
+	for (int j = (int)sv.len - 1; j >= min_index;) {
+		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
+		int kmer_index = sv.offset + j;
+		int string_index = kmer_index + l_ek - 1;
+		uint64_t prefixValue = prefix13(bin_read, string_index);
+		int n = bwt_MEM_search(x, bin_read + string_index, prefixValue, 2, 21 - 1, string_index, sp_set, m_r);
+		if (n == 0) { j -= 2; continue; }
+		j -= 3;
+		int max_score = 0;
+		for (int q = 0; q < n; ++q) {
+			m_r[q].read_offset = string_index - m_r[q].match_len;
+			int sc = map_seed(w, m_r[q], bin_read, read_len, (uint16_t)seed_idx, (uint8_t)s_d->direction);
+			max_score = MAXV(sc, max_score);
 		}
-		int top_score = 35;
-		for (uint32_t i = a_b_idx; i < w.n_anc; i++) top_score = MAXV(top_score, w.anc[i].score);
-		for (uint32_t i = a_b_idx; i < w.n_anc; i++) w.anc[i].useless = (w.anc[i].score < top_score) ? 1 : 0;
+		if (max_score > 35) j -= 7;
+		if (max_score > 256) { if (max_score > 512) skip_next = 1; break; }
+	}
+	int top_score = 35;
+	for (uint32_t i = a_b_idx; i < w.n_anc; i++) top_score = MAXV(top_score, w.anc[i].score);
+	for (uint32_t i = a_b_idx; i < w.n_anc; i++) w.anc[i].useless = (w.anc[i].score < top_score) ? 1 : 0;
+	return skip_next;
+}
+
+// fast_classify (src/cly.c:1478-1546).  Top islands are independent of each other except for the
+// skip-next rule and the order in which their anchors are appended, so 64 islands are walked at once,
+// one per lane, each into its own scratch (anchors, visited-row set); the results are then committed in
+// island order exactly as the reference would have produced them.  An island whose anchors do not fit
+// its lane scratch is redone by the whole wave straight into the anchor array.
+#define DSB_LANE_ANC_CAP 64
+DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
+{
+	DsbSeed *sv_b = s_d->seed_v; uint32_t n_seed = s_d->l_seed_v;
+	uint32_t n_top = 0;
+	for (uint32_t i = 0; i < n_seed; i++) if (sv_b[i].top) w.top_idx[n_top++] = i;
+	uint32_t skip_seed = 0xffffffffu;
+	DsbAnchor *main_anc = w.anc; uint64_t *main_sp = w.spset;
+	for (uint32_t base = 0; base < n_top; base += DSB_WAVE) {
+		uint32_t t = base + w.lane; bool valid = t < n_top;
+		uint32_t main_n = w.n_anc; int st_before = w.status;
+		w.anc = w.lane_anc + (size_t)w.lane * DSB_LANE_ANC_CAP; w.n_anc = 0; w.anc_cap = DSB_LANE_ANC_CAP;
+		w.spset = w.lane_spset + (size_t)w.lane * 512;
+		int flag = valid ? fast_island(w, s_d, read_len, w.top_idx[t]) : 0;
+		int ovf = ((w.status & DSB_ST_ANC_OVF) && !(st_before & DSB_ST_ANC_OVF)) ? 1 : 0;
+		if (ovf) w.status &= ~DSB_ST_ANC_OVF;
+		uint32_t my_n = w.n_anc;
+		w.anc = main_anc; w.n_anc = main_n; w.anc_cap = DSB_ANC_CAP; w.spset = main_sp;
+		wave_sync();
+		uint32_t n_round = MINV((uint32_t)DSB_WAVE, n_top - base);
+		for (uint32_t l = 0; l < n_round; l++) {
+			uint32_t sidx = w.top_idx[base + l];
+			uint32_t n_l = dsb_shfl(my_n, (int)l); int f_l = dsb_shfl(flag, (int)l); int ovf_l = dsb_shfl(ovf, (int)l);
+			if (sidx == skip_seed) continue;
+			if (ovf_l) f_l = fast_island(w, s_d, read_len, sidx);
+			else {
+				if (w.n_anc + n_l > DSB_ANC_CAP) { w.status |= DSB_ST_ANC_OVF; n_l = 0; }
+				const DsbAnchor *src = w.lane_anc + (size_t)l * DSB_LANE_ANC_CAP;
+				for (uint32_t k = w.lane; k < n_l; k += DSB_WAVE) main_anc[w.n_anc + k] = src[k];
+				w.n_anc += n_l;
+			}
+			if (f_l) skip_seed = sidx + 1;
+		}
+		wave_sync();
 	}
 }
 
@@ -833,8 +948,25 @@ DN int build_hash_table_M2(WCtx &w, SDir *sd, int q_len)
 		for (int base = ((n9 - 1) / DSB_WAVE) * DSB_WAVE; base >= 0; base -= DSB_WAVE) {
 			int pos = base + w.lane; bool valid = pos < n9;
 			uint32_t key = valid ? (km[pos] & KEY_MASK) : 0xffffffffu;
-			uint64_t todo = dsb_ballot(valid);
-			int nxt_lane = -1; bool lowest = false;
+			// Lanes whose key is unique in this group need no ordering.  A 128-entry LDS table finds the
+			// (rare) lanes that may share a key; only those go through the pairwise ballot loop.
+			int nxt_lane = -1; bool lowest = valid;
+			uint64_t todo;
+#ifdef DSB_HOST_EMU
+			todo = 0;
+#else
+			{
+				uint32_t slot = (key ^ (key >> 7)) & 127u;
+				if (valid) { w.lds_tab[slot] = (uint32_t)w.lane; w.lds_tab[128 + slot] = 0; }
+				wave_sync();
+				bool loser = valid && w.lds_tab[slot] != (uint32_t)w.lane;
+				if (loser) w.lds_tab[128 + slot] = 1;
+				wave_sync();
+				bool involved = valid && (loser || w.lds_tab[128 + slot] != 0);
+				todo = dsb_ballot(involved);
+				wave_sync();
+			}
+#endif
 			while (todo) {
 				int leader = __builtin_ctzll(todo);
 				uint32_t lk = dsb_shfl(key, leader);
@@ -874,65 +1006,138 @@ DV uint64_t bin2kmer9(const uint8_t *s) { uint64_t v = 0;
 	for (int i = 0; i < 9; i++) v = (v << 2) | s[i];
 	return v; }
 
-// sdp_match (src/cly.c:2335-2440)
+// sdp_match (src/cly.c:2335-2440), lanes over the probed reference positions.
+// The reference walks the window one base at a time with a rolling 9-mer and looks up every 4th
+// position; here lane l of group g owns position i = 4 + 4*(64 g + l), builds that 9-mer directly
+// (bit-identical to the rolling value, including what unloaded pad bytes (value 4) leak into it),
+// walks the read's chain for it and evaluates the two exact-match extensions.  Nodes must come out in
+// the reference's order (i ascending, chain order within i): a first pass counts them per lane, an
+// exclusive wave scan gives each lane its slice of the node array, a second pass writes.
+struct SdpArgs { uint32_t q_bg, q_ed; const uint8_t *q_str, *t_str; uint32_t t_len, t_st; const uint32_t *head, *nextv, *km; uint64_t KEY_MASK; };
+
+template <bool FWD, bool WRITE>
+DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out)
+{
+	uint32_t cnt = 0;
+	const uint8_t *c_t; uint64_t kmer = 0;
+	if (FWD) {
+		c_t = a.t_str + i;
+#pragma unroll
+		for (int j = 0; j < 9; j++) kmer |= (uint64_t)c_t[j] << (16 - 2 * j);
+		kmer &= 0x3FFFFULL;
+	} else {
+		c_t = a.t_str + (a.t_len - 9 - 4) - (i - 4);
+#pragma unroll
+		for (int j = 0; j < 9; j++) kmer |= (uint64_t)c_t[j] << (16 - 2 * j);
+		if (i > 4) kmer |= (uint64_t)(c_t[9] >> 2);
+	}
+	uint32_t next = a.head[kmer & a.KEY_MASK];
+	while (next != 0) {
+		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
+		uint32_t q_pos = next - 1;
+		if (a.km[q_pos] == kmer && q_pos >= a.q_bg && q_pos <= a.q_ed) {
+			if (FWD) {
+				int back_len = MEM_search(a.q_str + q_pos - 1, c_t - 1, false, 4);
+				if (back_len < 4 || i == 4) {
+					uint32_t max_search = a.q_ed - q_pos - 1;
+					max_search = MINV(max_search, a.t_len - i - 1) + 50;
+					int fwd = MEM_search(a.q_str + q_pos + 9, c_t + 9, true, max_search);
+					int total = back_len + fwd + 1;
+					if (total >= 4) {
+						if (WRITE) { DsbSms *p = out + cnt; p->len = total; p->q_pos = q_pos - back_len; p->t_pos = i - back_len + a.t_st; }
+						cnt++;
+					}
+				}
+			} else {
+				int fwd = MEM_search(a.q_str + q_pos + 9, c_t + 9, true, 4);
+				if (fwd < 4 || i == 4) {
+					uint32_t max_search = q_pos;
+					max_search = MINV((long)max_search, (long)(c_t - a.t_str)) + 50;
+					int back_len = MEM_search(a.q_str + q_pos - 1, c_t - 1, false, max_search);
+					int total = back_len + fwd + 1;
+					if (total >= 4) {
+						if (WRITE) { DsbSms *p = out + cnt; p->len = total; p->q_pos = q_pos - back_len; p->t_pos = (uint32_t)((long)(c_t - a.t_str) - back_len + a.t_st); }
+						cnt++;
+					}
+				}
+			}
+		}
+		next = a.nextv[q_pos];
+	}
+	return cnt;
+}
+
+template <bool FWD>
+DN void sdp_match_t(WCtx &w, const SdpArgs &a)
+{
+	uint32_t t_kmer_num = a.t_len - 9 + 1;
+	if (t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return;       // the reference's loop does not run either (t_len >= 13 at every call site)
+	uint32_t n_pos = (t_kmer_num - 4 + 3) / 4;                      // i = 4, 8, ... < t_kmer_num
+	for (uint32_t g = 0; g < n_pos; g += DSB_WAVE) {
+		uint32_t pI = g + w.lane; bool valid = pI < n_pos; int i = 4 + 4 * (int)pI;
+		uint32_t cnt = valid ? sdp_visit<FWD, false>(w, a, i, nullptr) : 0;
+		uint32_t total, off = wave_excl_scan_u(cnt, &total);
+		if (total == 0) continue;
+		if (w.n_sms + total > DSB_SMS_CAP) { w.status |= DSB_ST_SMS_OVF; return; }
+		if (cnt) sdp_visit<FWD, true>(w, a, i, w.sms + w.n_sms + off);
+		w.n_sms += total;
+		wave_sync();
+	}
+}
+
 DN void sdp_match(WCtx &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len, int key_len,
                   int tbl, uint32_t t_st, bool isForward)
 {
-	const uint32_t *head = w.kh_head[tbl], *nextv = w.kh_next[tbl], *km = w.kh_kmer[tbl];
-	uint64_t KEY_MASK = (1ULL << key_len) - 1;
-	uint32_t t_kmer_num = t_len - 9 + 1;
-	if (isForward) {
-		uint64_t MASK = (1ULL << 18) - 1;
-		const uint8_t *c_t = t_str + 4;
-		uint64_t kmer = bin2kmer9(c_t) >> 2;
-		for (int i = 4; (uint32_t)i < t_kmer_num; i++, c_t++) {
-			kmer = ((kmer << 2) | c_t[8]) & MASK;
-			if ((i & 3) != 0) continue;
-			uint32_t next = head[kmer & KEY_MASK];
-			while (next != 0) {
-				if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; return; }
-				uint32_t q_pos = next - 1;
-				if (km[q_pos] == kmer) {
-					if (q_pos >= q_bg && q_pos <= q_ed) {
-						int back_len = MEM_search(q_str + q_pos - 1, c_t - 1, false, 4);
-						if (back_len < 4 || i == 4) {
-							uint32_t max_search = q_ed - q_pos - 1;
-							max_search = MINV(max_search, t_len - i - 1) + 50;
-							int fwd = MEM_search(q_str + q_pos + 9, c_t + 9, true, max_search);
-							int total = back_len + fwd + 1;
-							if (total >= 4) { DsbSms *p = push_sms(w); p->len = total; p->q_pos = q_pos - back_len; p->t_pos = i - back_len + t_st; }
-						}
-					}
+	SdpArgs a; a.q_bg = q_bg; a.q_ed = q_ed; a.q_str = q_str; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st;
+	a.head = w.kh_head[tbl]; a.nextv = w.kh_next[tbl]; a.km = w.kh_kmer[tbl]; a.KEY_MASK = (1ULL << key_len) - 1;
+	if (isForward) sdp_match_t<true>(w, a); else sdp_match_t<false>(w, a);
+}
+
+// best predecessor score of a new node among nodes [0, cur): the sparse-DP inner loops of
+// sdp_middle_M2 / sdp_right_M2 / sdp_left_M2 (src/cly.c:2495-2517, 2612-2638, 2759-2783), lanes over
+// predecessors (newest first), wave max at the end.  MODE 0 = middle (no distance cut), 1 = right, 2 = left.
+template <int MODE>
+DV int sdp_best_pred(WCtx &w, const DsbSms &cs, int32_t cur)
+{
+	int best = (int)cs.len;
+	uint32_t lim_q, lim_t;
+	if (MODE == 2) { lim_q = cs.q_pos + cs.len - 6 + 9 - 1; lim_t = cs.t_pos + cs.len - 6 + 9 - 1; }
+	else { lim_q = cs.q_pos + 6; lim_t = cs.t_pos + 6; }
+	for (int32_t hi = cur - 1; hi >= 0; hi -= DSB_WAVE) {
+		int32_t pi = hi - w.lane; bool valid = pi >= 0;
+		DsbSms ps; if (valid) ps = w.sms[pi]; else { ps.t_pos = ps.q_pos = ps.len = ps.score = 0; }
+		bool skip, brk = false; int ns = 0;
+		if (MODE == 2) {
+			skip = (ps.q_pos < lim_q) || (ps.t_pos < lim_t);
+			if (!skip) brk = (lim_t + 600 < ps.t_pos);
+			if (!skip && !brk) {
+				int indel = ps.q_pos - ps.t_pos - (lim_q - lim_t); int ai = ABSV(indel);
+				if (ai > 200) skip = true;
+				else {
+					ns = ps.score + cs.len - (ai >> 3);
+					if (lim_q + 6 > ps.q_pos || lim_t + 6 > ps.t_pos) { int oq = lim_q + 6 - ps.q_pos, ot = lim_t + 6 - ps.t_pos; ns -= MAXV(oq, ot); }
 				}
-				next = nextv[q_pos];
+			}
+		} else {
+			int pre_q_ed = ps.q_pos + ps.len + 9 - 1, pre_t_ed = ps.t_pos + ps.len + 9 - 1;
+			skip = ((uint32_t)pre_q_ed > lim_q) || ((uint32_t)pre_t_ed > lim_t);
+			if (MODE == 1 && !skip) brk = (ps.t_pos + 600 < lim_t);
+			if (!skip && !brk) {
+				int indel = ps.q_pos - ps.t_pos - (lim_q - lim_t); int ai = ABSV(indel);
+				if (ai > 200) skip = true;
+				else {
+					ns = ps.score + cs.len - (ai >> 3);
+					if ((uint32_t)pre_q_ed > cs.q_pos || (uint32_t)pre_t_ed > cs.t_pos) { int oq = pre_q_ed - cs.q_pos, ot = pre_t_ed - cs.t_pos; ns -= MAXV(oq, ot); }
+				}
 			}
 		}
-	} else {
-		const uint8_t *c_t = t_str + t_len - 9 - 4;
-		uint64_t kmer = bin2kmer9(c_t) << 2;
-		for (int i = 4; (uint32_t)i < t_kmer_num; i++, c_t--) {
-			kmer = (kmer >> 2) | ((uint64_t)c_t[0] << 16);
-			if ((i & 3) != 0) continue;
-			uint32_t next = head[kmer & KEY_MASK];
-			while (next != 0) {
-				if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; return; }
-				uint32_t q_pos = next - 1;
-				if (km[q_pos] == kmer) {
-					if (q_pos >= q_bg && q_pos <= q_ed) {
-						int fwd = MEM_search(q_str + q_pos + 9, c_t + 9, true, 4);
-						if (fwd < 4 || i == 4) {
-							uint32_t max_search = q_pos;
-							max_search = MINV((long)max_search, (long)(c_t - t_str)) + 50;
-							int back_len = MEM_search(q_str + q_pos - 1, c_t - 1, false, max_search);
-							int total = back_len + fwd + 1;
-							if (total >= 4) { DsbSms *p = push_sms(w); p->len = total; p->q_pos = q_pos - back_len; p->t_pos = (uint32_t)((long)(c_t - t_str) - back_len + t_st); }
-						}
-					}
-				}
-				next = nextv[q_pos];
-			}
-		}
+		// the reference stops at the first predecessor (newest first) that meets the distance cut
+		uint64_t bm = (MODE == 0) ? 0ULL : dsb_ballot(valid && brk);
+		int first_brk = bm ? __builtin_ctzll(bm) : DSB_WAVE;
+		if (valid && !skip && !brk && w.lane < first_brk) best = MAXV(best, ns);
+		if (bm) break;
 	}
+	return wave_max_i(best);
 }
 
 DV void fill_window(const WCtx &w, uint8_t *win, int n)
@@ -959,10 +1164,10 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 			p->score = score; p->q_pos = A[pre_a].index_in_read; p->t_pos = A[pre_a].ref_offset; p->len = A[pre_a].mtch_len - 9 + 1;
 			if (total_ref_len > 12) {
 				uint8_t *ref = w.win_mid;
-				fill_window(w, ref, 2000 + 128);
-				wave_sync();
+				if (total_ref_len >= 2000) { w.status |= DSB_ST_TIMEOUT; return 0; }   // the reference aborts here (xassert, src/cly.c:2473)
 				uint64_t ref_offset = pre_refoffset + t_offset + pre_mch;
 				get_ref_wave(w, ref, ref_offset, total_ref_len);
+				for (int k = total_ref_len + w.lane; k < total_ref_len + 64; k += DSB_WAVE) ref[k] = DSB_TPAD_VAL;   // reads reach <= 58 past the window
 				wave_sync();
 				sdp_match(w, A[pre_a].index_in_read + pre_mch - 8, A[c_a].index_in_read - 1, q_str, ref, total_ref_len, key_len, tbl,
 				          pre_refoffset + pre_mch, true);
@@ -973,23 +1178,7 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 				DsbSms *S = w.sms;
 				for (uint32_t ci = 1; ci < w.n_sms; ci++) {
 					DsbSms cs = S[ci];
-					int max_score = cs.len;
-					uint32_t max_q = cs.q_pos + 6, max_t = cs.t_pos + 6;
-					for (int32_t pi = (int32_t)ci - 1; pi >= 0; pi--) {
-						DsbSms ps = S[pi];
-						int pre_q_ed = ps.q_pos + ps.len + 9 - 1, pre_t_ed = ps.t_pos + ps.len + 9 - 1;
-						if ((uint32_t)pre_q_ed > max_q) continue;
-						if ((uint32_t)pre_t_ed > max_t) continue;
-						int indel = ps.q_pos - ps.t_pos - (max_q - max_t);
-						int ai = ABSV(indel);
-						if (ai > 200) continue;
-						int ns = ps.score + cs.len - (ai >> 3);
-						if ((uint32_t)pre_q_ed > cs.q_pos || (uint32_t)pre_t_ed > cs.t_pos) {
-							int oq = pre_q_ed - cs.q_pos, ot = pre_t_ed - cs.t_pos;
-							ns -= MAXV(oq, ot);
-						}
-						max_score = MAXV(max_score, ns);
-					}
+					int max_score = sdp_best_pred<0>(w, cs, (int32_t)ci);
 					score = MAXV(max_score, score);
 					S[ci].score = max_score;
 				}
@@ -1041,25 +1230,7 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 		}
 		DsbSms *c_sms = w.sms + current_sms++;
 		DsbSms cs = *c_sms;
-		int max_score = cs.len;
-		uint32_t max_pre_q = cs.q_pos + 6, max_pre_t = cs.t_pos + 6;
-		w.steps += current_sms >> 3;
-		for (int32_t pi = (int32_t)current_sms - 2; pi >= 0; pi--) {
-			DsbSms ps = w.sms[pi];
-			int pre_q_ed = ps.q_pos + ps.len + 9 - 1, pre_t_ed = ps.t_pos + ps.len + 9 - 1;
-			if ((uint32_t)pre_q_ed > max_pre_q) continue;
-			if ((uint32_t)pre_t_ed > max_pre_t) continue;
-			if (ps.t_pos + 600 < max_pre_t) break;
-			int indel = ps.q_pos - ps.t_pos - (max_pre_q - max_pre_t);
-			int ai = ABSV(indel);
-			if (ai > 200) continue;
-			int ns = ps.score + cs.len - (ai >> 3);
-			if ((uint32_t)pre_q_ed > cs.q_pos || (uint32_t)pre_t_ed > cs.t_pos) {
-				int oq = pre_q_ed - cs.q_pos, ot = pre_t_ed - cs.t_pos;
-				ns -= MAXV(oq, ot);
-			}
-			max_score = MAXV(max_score, ns);
-		}
+		int max_score = sdp_best_pred<1>(w, cs, (int32_t)current_sms - 1);
 		c_sms->score = max_score;
 		if ((int)cs.len >= 8 && combine_chain(c_st, chain_ID, sc_hash, cs.t_pos - cs.q_pos, false, cs.q_pos, &combined) == true) {
 			int c_len = cs.len;
@@ -1124,24 +1295,7 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 		}
 		DsbSms *c_sms = w.sms + current_sms++;
 		DsbSms cs = *c_sms;
-		int max_score = cs.len;
-		uint32_t min_pre_q = cs.q_pos + cs.len - 6 + 9 - 1, min_pre_t = cs.t_pos + cs.len - 6 + 9 - 1;
-		w.steps += current_sms >> 3;
-		for (int32_t pi = (int32_t)current_sms - 2; pi >= 0; pi--) {
-			DsbSms ps = w.sms[pi];
-			if (ps.q_pos < min_pre_q) continue;
-			if (ps.t_pos < min_pre_t) continue;
-			if (min_pre_t + 600 < ps.t_pos) break;
-			int indel = ps.q_pos - ps.t_pos - (min_pre_q - min_pre_t);
-			int ai = ABSV(indel);
-			if (ai > 200) continue;
-			int ns = ps.score + cs.len - (ai >> 3);
-			if (min_pre_q + 6 > ps.q_pos || min_pre_t + 6 > ps.t_pos) {
-				int oq = min_pre_q + 6 - ps.q_pos, ot = min_pre_t + 6 - ps.t_pos;
-				ns -= MAXV(oq, ot);
-			}
-			max_score = MAXV(max_score, ns);
-		}
+		int max_score = sdp_best_pred<2>(w, cs, (int32_t)current_sms - 1);
 		c_sms->score = max_score;
 		if ((int)cs.len >= 8 && combine_chain(c_st, chain_ID, sc_hash, cs.t_pos - cs.q_pos, true, cs.q_pos + cs.len, &combined) == true) {
 			int c_len = cs.len;
@@ -1165,9 +1319,11 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 // get_score_M2 (src/cly.c:2821-2849)
 DN void get_score_M2(WCtx &w, SDir *sd, uint32_t l_read, DsbScHash *sc_hash)
 {
+	TICK(w, 8);
 	MARK(w, 50);
 	int key_len = build_hash_table_M2(w, sd, l_read);
 	MARK(w, 51);
+	TICK(w, 4);
 	DsbChain *H = w.hit;
 	for (uint32_t i = 0; i < w.n_hit; i++) {
 		if (H[i].sum_score == 0) continue;
@@ -1176,10 +1332,13 @@ DN void get_score_M2(WCtx &w, SDir *sd, uint32_t l_read, DsbScHash *sc_hash)
 		MARK(w, 52);
 		int score = sdp_middle_M2(w, H[i].cur, csd->bin_read, tbl, key_len);
 		MARK(w, 53);
+		TICK(w, 5);
 		score = sdp_right_M2(w, csd->bin_read, tbl, key_len, H, i, l_read, sc_hash, score);
 		MARK(w, 54);
+		TICK(w, 6);
 		score = sdp_left_M2(w, csd->bin_read, tbl, key_len, H, i, l_read, sc_hash, score);
 		MARK(w, 55);
+		TICK(w, 7);
 		H[i].sum_score = score;
 	}
 }
@@ -1282,17 +1441,20 @@ DN uint32_t classify_read(WCtx &w, const uint64_t *bitsF, const uint64_t *bitsR)
 	if (read_len < 40) return fast;
 	SDir *sd = w.sd;
 	uint32_t n = read_len - w.x->ek_len + 1;
-	w.stage = 1; MARK(w, 1);
+	w.stage = 1; MARK(w, 1); if (w.dbg) w.tlast = DSB_CLOCK();
 	seed_vector(w, w.bin, bitsF, n, w.seeds, D_FORWARD, sd);
 	seed_vector(w, w.bin + read_len, bitsR, n, w.seeds + (read_len >> 2), D_REVERSE, sd + 1);
+	TICK(w, 0);
 	if (sd[0].total_score < sd[1].total_score) { SDir t = sd[0]; sd[0] = sd[1]; sd[1] = t; }
 	bool both_direction = ((sd[0].total_score - sd[1].total_score) <= (sd[0].total_score >> 3));
 	int super_repeat = 0;
 	w.stage = 2; MARK(w, 2);
 	fast_classify(w, sd, read_len);
 	if (both_direction) fast_classify(w, sd + 1, read_len);
+	TICK(w, 1);
 	w.stage = 3; MARK(w, 3);
 	resolve_tree(w);
+	TICK(w, 2);
 	w.stage = 4; MARK(w, 4);
 	int run_slow_mode = false;
 	if (w.n_hit <= 0) run_slow_mode = true;
@@ -1309,10 +1471,13 @@ DN uint32_t classify_read(WCtx &w, const uint64_t *bitsF, const uint64_t *bitsR)
 			resolve_tree(w);
 		}
 	}
+	TICK(w, 3);
 	w.stage = 5; MARK(w, 5);
 	delete_small_score_rst(w, sd, read_len);
+	TICK(w, 8);
 	w.stage = 6; MARK(w, 6);
 	detect_primary(w, read_len);
 	w.stage = 7; MARK(w, 7);
+	TICK(w, 9);
 	return fast;
 }

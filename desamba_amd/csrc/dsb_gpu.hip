@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) k_seed_probe(DsbDevIndex x, const DsbRead
 struct DsbSlotArena {
 	uint8_t *base; size_t stride;                 // per-slot bytes
 	size_t off_seeds, off_anc, off_anc_tmp, off_hit, off_hit_tmp, off_sms, off_kh, off_sc, off_mem, off_spset, off_scorev,
-	       off_sortkey, off_sortidx, off_win;
+	       off_sortkey, off_sortidx, off_win, off_lane_anc, off_lane_sp, off_top;
 	uint32_t max_len;                             // longest read the arena was sized for
 };
 
@@ -115,8 +115,16 @@ __global__ void __launch_bounds__(64) k_classify(DsbDevIndex x, const DsbReadDes
 {
 	const int lane = threadIdx.x;
 	uint8_t *slot = ar.base + (size_t)blockIdx.x * ar.stride;
+	// The index descriptor is read on every rank query: keep it in LDS.  (A pointer to the kernel-argument
+	// segment would turn each x->field into a vector load from host-coherent memory.)
+	__shared__ DsbDevIndex sx;
+	__shared__ uint32_t lds_tab[256];
+	if (lane == 0) sx = x;
+	__syncthreads();
 	WCtx w;
-	w.x = &x; w.lane = lane; w.dbg = dbg ? dbg + 4 * blockIdx.x : nullptr;
+	w.lds_tab = lds_tab;
+	w.x = &sx; w.lane = lane; w.dbg = dbg ? dbg + 4 * blockIdx.x : nullptr;
+	for (int i = 0; i < 10; i++) w.tacc[i] = 0;
 	w.seeds = (DsbSeed *)(slot + ar.off_seeds);
 	w.anc = (DsbAnchor *)(slot + ar.off_anc); w.anc_tmp = (DsbAnchor *)(slot + ar.off_anc_tmp);
 	w.hit = (DsbChain *)(slot + ar.off_hit); w.hit_tmp = (DsbChain *)(slot + ar.off_hit_tmp);
@@ -131,13 +139,16 @@ __global__ void __launch_bounds__(64) k_classify(DsbDevIndex x, const DsbReadDes
 	w.score_v = (int *)(slot + ar.off_scorev);
 	w.sortkey = (uint64_t *)(slot + ar.off_sortkey); w.sortidx = (uint32_t *)(slot + ar.off_sortidx);
 	w.win_mid = slot + ar.off_win; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
+	w.lane_anc = (DsbAnchor *)(slot + ar.off_lane_anc); w.lane_spset = (uint64_t *)(slot + ar.off_lane_sp); w.top_idx = (uint32_t *)(slot + ar.off_top);
+	w.anc_cap = DSB_ANC_CAP;
 	if (w.dbg && lane == 0) w.dbg[0] = 300;
 	for (;;) {
 		unsigned int r = 0;
 		if (lane == 0) r = atomicAdd(work_counter, 1u);
 		r = __shfl(r, 0);
-		if (r >= n_reads) { if (w.dbg && lane == 0) w.dbg[0] = 999; break; }   // every wave reaches this: the grid always drains
+		if (r >= n_reads) { if (w.dbg && lane == 0) { w.dbg[0] = 999; for (int i = 0; i < 10; i++) dbg[4 * 65536 + 10 * blockIdx.x + i] = (uint32_t)(w.tacc[i] / 100); } break; }   // every wave reaches this: the grid always drains
 		DsbReadDesc d = rd[r];
+		uint64_t t_start = wall_clock64();
 		if (w.dbg && lane == 0) { w.dbg[2] = r; w.dbg[0] = 100; }
 		w.bin = bin + d.bin_off + DSB_QPAD_L; w.L = d.len; w.status = 0; w.max_read_l = d.hist_max;
 		uint32_t fast = classify_read(w, bits + d.bit_off, bits + d.bit_off + d.n_words);
@@ -154,7 +165,7 @@ __global__ void __launch_bounds__(64) k_classify(DsbDevIndex x, const DsbReadDes
 			hout[first + i] = o;
 		}
 		if (w.dbg && lane == 0) w.dbg[0] = 200;
-		if (lane == 0) { DsbReadOut ro; ro.first = first; ro.n = n_out; ro.status = w.status | (w.status ? (w.stage << 8) : 0); ro.fast = fast; rout[r] = ro; }
+		if (lane == 0) { DsbReadOut ro; ro.first = first; ro.n = n_out; ro.status = w.status | (w.status ? (w.stage << 8) : 0); ro.fast = fast | ((uint32_t)((wall_clock64() - t_start) / 100) << 1); rout[r] = ro; }
 	}
 }
 
@@ -226,8 +237,8 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	HIPCHK(hipMalloc((void **)&c->d_counters, 64));
 	c->dbg_host = c->dbg_dev = nullptr;
 	if (getenv("DSB_DEBUG")) {
-		HIPCHK(hipHostMalloc((void **)&c->dbg_host, 4 * 65536 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
-		memset(c->dbg_host, 0, 4 * 65536 * sizeof(uint32_t));
+		HIPCHK(hipHostMalloc((void **)&c->dbg_host, 16 * 65536 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+		memset(c->dbg_host, 0, 16 * 65536 * sizeof(uint32_t));
 		HIPCHK(hipHostGetDevicePointer((void **)&c->dbg_dev, c->dbg_host, 0));
 	}
 	c->n_slots = c->opts.n_slots > 0 ? c->opts.n_slots : 0;
@@ -279,6 +290,9 @@ static int size_arena(dsb_ctx *c, uint32_t max_len, int n_slots)
 	a.off_sortkey = o; o += al256((size_t)2 * DSB_ANC_CAP * sizeof(uint64_t));
 	a.off_sortidx = o; o += al256((size_t)2 * DSB_ANC_CAP * sizeof(uint32_t));
 	a.off_win = o;     o += al256((size_t)3 * DSB_REFWIN);
+	a.off_lane_anc = o; o += al256((size_t)64 * DSB_LANE_ANC_CAP * sizeof(DsbAnchor));
+	a.off_lane_sp = o;  o += al256((size_t)64 * 512 * 8);
+	a.off_top = o;      o += al256(((size_t)(max_len >> 1) + 64) * 4);
 	a.stride = al256(o);
 	c->n_slots = n_slots;
 	c->arena_bytes = a.stride * (size_t)n_slots;
@@ -371,6 +385,14 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	}
 	HIPCHK(hipEventRecord(c->ev[3], c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	if (dbg) {
+		static const char *nm[10] = {"seed_vector", "fast_classify", "resolve_tree", "slow+resolve", "hash_build", "sdp_middle", "sdp_right", "sdp_left", "sort/filter", "primary"};
+		double tot[10] = {0}, all = 0; unsigned slots = (unsigned)c->n_slots; if (slots > n) slots = (unsigned)n;
+		for (unsigned sI = 0; sI < slots; sI++) for (int i = 0; i < 10; i++) { tot[i] += c->dbg_host[4 * 65536 + 10 * sI + i]; all += c->dbg_host[4 * 65536 + 10 * sI + i]; }
+		fprintf(stderr, "[dsb] classify stage time (wave-seconds, %% of total %.2f s):", all / 1e6);
+		for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * tot[i] / (all > 0 ? all : 1));
+		fprintf(stderr, "\n");
+	}
 	HIPCHK(hipGetLastError());
 	hipEventElapsedTime(&c->timing.encode_ms, c->ev[0], c->ev[1]);
 	hipEventElapsedTime(&c->timing.seed_probe_ms, c->ev[1], c->ev[2]);
@@ -401,7 +423,7 @@ extern "C" int dsb_batch_fetch(dsb_ctx *c, dsb_result *out)
 	for (size_t i = 0; i < n; i++) {
 		const DsbReadOut &r = c->h_rout[i];
 		dsb_read_result &o = c->res_reads[i];
-		o.first = (uint32_t)c->res_hits.size(); o.n = r.n; o.fast = r.fast;
+		o.first = (uint32_t)c->res_hits.size(); o.n = r.n; o.fast = r.fast & 1u; o.device_us = r.fast >> 1;
 		o.status = r.status ? (DSB_ECAP * 256 - r.status) : 0;
 		if (r.status) worst = DSB_ECAP;
 		for (uint32_t k = 0; k < r.n; k++) {
@@ -441,7 +463,10 @@ extern "C" int dsb_batch_exist_bits(dsb_ctx *c, size_t read, int strand, uint8_t
 // seeds are a by-product of k_classify; recomputed here on the device for one read strand (stage dump for tests)
 __global__ void __launch_bounds__(64) k_seed_dump(DsbDevIndex x, DsbReadDesc d, uint8_t *bin, const uint64_t *bits, int strand, DsbSeed *out, uint32_t *n_out)
 {
-	WCtx w; w.x = &x; w.lane = threadIdx.x; w.L = d.len; w.status = 0;
+	__shared__ DsbDevIndex sx;
+	if (threadIdx.x == 0) sx = x;
+	__syncthreads();
+	WCtx w; w.x = &sx; w.lane = threadIdx.x; w.L = d.len; w.status = 0; w.dbg = nullptr; w.anc_cap = 0;
 	SDir sd;
 	uint32_t n = d.len - x.ek_len + 1;
 	if (strand) seed_vector(w, bin + d.bin_off + DSB_QPAD_L, bits + d.bit_off, n, out, D_FORWARD, &sd);

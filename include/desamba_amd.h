@@ -57,6 +57,7 @@ typedef struct {
 	uint32_t first, n;
 	int32_t status;       /* 0, or DSB_ECAP with the overflowing arena in the low bits */
 	uint32_t fast;        /* cly_r.fast_classify */
+	uint32_t device_us;   /* time the read occupied its wavefront (100 MHz wall clock), diagnostics */
 } dsb_read_result;
 
 typedef struct {

@@ -37,7 +37,7 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 {
 	if (L <= e->max_len) return;
 	e->max_len = L + L / 4 + 1024;
-	size_t o = 0, off[16]; int k = 0;
+	size_t o = 0, off[20]; int k = 0;
 	auto add = [&](size_t n) { off[k++] = o; o += al(n); };
 	add(((size_t)(e->max_len >> 1) + 64) * sizeof(DsbSeed));            // 0 seeds
 	add((size_t)DSB_ANC_CAP * sizeof(DsbAnchor)); add((size_t)DSB_ANC_CAP * sizeof(DsbAnchor));  // 1,2
@@ -49,6 +49,7 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	add((size_t)DSB_SPSET_CAP * 8); add(1024 * sizeof(int));             // 9,10
 	add((size_t)2 * DSB_ANC_CAP * 8); add((size_t)2 * DSB_ANC_CAP * 4);  // 11,12
 	add(3 * DSB_REFWIN);                                                 // 13
+	add((size_t)DSB_LANE_ANC_CAP * sizeof(DsbAnchor)); add(512 * 8); add(((size_t)(e->max_len >> 1) + 64) * 4);   // 14,15,16 (1 lane)
 	e->arena.assign(o + 256, 0xCD);
 	uint8_t *s = e->arena.data(); WCtx &w = e->w;
 	w.x = &e->dx; w.lane = 0; w.dbg = nullptr;
@@ -60,6 +61,7 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	w.sc = (DsbScHash *)(s + off[7]); w.mem_slow = (DsbMem *)(s + off[8]); w.spset = (uint64_t *)(s + off[9]); w.score_v = (int *)(s + off[10]);
 	w.sortkey = (uint64_t *)(s + off[11]); w.sortidx = (uint32_t *)(s + off[12]);
 	w.win_mid = s + off[13]; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
+	w.lane_anc = (DsbAnchor *)(s + off[14]); w.lane_spset = (uint64_t *)(s + off[15]); w.top_idx = (uint32_t *)(s + off[16]); w.anc_cap = DSB_ANC_CAP;
 }
 
 // returns n_hits (or -status when a cap/timeout status was raised); hits as DsbHitOut
