@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads-per-gpu", type=int, default=4096)
+    ap.add_argument("--reads-per-gpu", type=int, default=8192)
     ap.add_argument("--read-len", type=int, default=50000)
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -918,10 +918,10 @@ DV bool combine_chain(DsbChain *c_st, int chain_ID, DsbScHash *sc, int dis, bool
 }
 
 // ---- per-read 9-mer table (build_hash_table_M2, src/cly.c:2173-2224).
-// Same contents as the reference's chained hash -- for every key the read positions in ascending
-// order -- in a layout the wave can build in parallel: head[key] / next[pos] hold pos+1 (0 = end),
-// kmer[pos] the 18-bit 9-mer.  Positions are inserted 64 at a time from the end of the read; lanes
-// with equal keys inside a group are linked in lane order, the lowest becomes the new head.
+// Same contents as the reference's chained hash -- for every key the read positions holding it -- in a
+// layout the wave builds in parallel: head[key] / next[pos] hold pos+1 (0 = end), kmer[pos] the 18-bit
+// 9-mer.  The reference's chains are in ascending position order and its output depends on that order;
+// here the chain order is whatever the atomics produced and sdp_visit() sorts what it collects.
 DN int build_hash_table_M2(WCtx &w, SDir *sd, int q_len)
 {
 	int both_dir = 0;
@@ -945,56 +945,48 @@ DN int build_hash_table_M2(WCtx &w, SDir *sd, int q_len)
 			km[pos] = k;
 		}
 		wave_sync();
-		for (int base = ((n9 - 1) / DSB_WAVE) * DSB_WAVE; base >= 0; base -= DSB_WAVE) {
-			int pos = base + w.lane; bool valid = pos < n9;
-			uint32_t key = valid ? (km[pos] & KEY_MASK) : 0xffffffffu;
-			// Lanes whose key is unique in this group need no ordering.  A 128-entry LDS table finds the
-			// (rare) lanes that may share a key; only those go through the pairwise ballot loop.
-			int nxt_lane = -1; bool lowest = valid;
-			uint64_t todo;
+		// every position is pushed at the head of its key's chain with one atomic exchange: no ordering
+		// between lanes or groups is needed because lookups sort the few positions they collect
+		for (int pos = w.lane; pos < n9; pos += DSB_WAVE) {
+			uint32_t key = km[pos] & KEY_MASK;
 #ifdef DSB_HOST_EMU
-			todo = 0;
+			uint32_t old = head[key]; head[key] = (uint32_t)pos + 1;
 #else
-			{
-				uint32_t slot = (key ^ (key >> 7)) & 127u;
-				if (valid) { w.lds_tab[slot] = (uint32_t)w.lane; w.lds_tab[128 + slot] = 0; }
-				wave_sync();
-				bool loser = valid && w.lds_tab[slot] != (uint32_t)w.lane;
-				if (loser) w.lds_tab[128 + slot] = 1;
-				wave_sync();
-				bool involved = valid && (loser || w.lds_tab[128 + slot] != 0);
-				todo = dsb_ballot(involved);
-				wave_sync();
-			}
+			uint32_t old = atomicExch(&head[key], (uint32_t)pos + 1);
 #endif
-			while (todo) {
-				int leader = __builtin_ctzll(todo);
-				uint32_t lk = dsb_shfl(key, leader);
-				uint64_t m = dsb_ballot(valid && key == lk);
-				if (valid && key == lk) {
-					uint64_t hi = (w.lane == 63) ? 0ULL : (m & ~((2ULL << w.lane) - 1ULL));
-					nxt_lane = hi ? __builtin_ctzll(hi) : -1;
-					lowest = (__builtin_ctzll(m) == w.lane);
-				}
-				todo &= ~m;
-			}
-			if (valid) {
-				next[pos] = (nxt_lane >= 0) ? (uint32_t)(base + nxt_lane + 1) : head[key];
-			}
-			wave_sync();
-			if (valid && lowest) head[key] = pos + 1;
-			wave_sync();
+			next[pos] = old;
 		}
+		wave_sync();
 	}
 	return key_len;
 }
 
+DV uint64_t ld_u64(const uint8_t *p)
+{	// unaligned 8-byte load (byte buffers: read strands with pads, reference windows with pads)
+	uint64_t v;
+	__builtin_memcpy(&v, p, 8);
+	return v;
+}
+// MEM_search (src/cly.c:1810-1818): length of the exact match, at most max, walking forward from (q,t)
+// or backward.  Eight bases per step; every buffer it is used on has >= 8 readable bytes past the
+// compared range on either side (pads), and bytes beyond `max` are ignored.
 DV int MEM_search(const uint8_t *q, const uint8_t *t, bool forward, int max)
-{	// src/cly.c:1810-1818
+{
 	int len = 0;
-	if (forward) for (; len < max && *q++ == *t++; len++);
-	else for (; len < max && *q-- == *t--; len++);
-	return len;
+	if (forward) {
+		while (len < max) {
+			uint64_t x = ld_u64(q + len) ^ ld_u64(t + len);
+			if (x) { len += (int)(__builtin_ctzll(x) >> 3); break; }
+			len += 8;
+		}
+	} else {
+		while (len < max) {
+			uint64_t x = ld_u64(q - len - 7) ^ ld_u64(t - len - 7);
+			if (x) { len += (int)(__builtin_clzll(x) >> 3); break; }
+			len += 8;
+		}
+	}
+	return len < max ? len : (max > 0 ? max : 0);
 }
 DV DsbSms *push_sms(WCtx &w)
 {
@@ -1013,10 +1005,13 @@ DV uint64_t bin2kmer9(const uint8_t *s) { uint64_t v = 0;
 // walks the read's chain for it and evaluates the two exact-match extensions.  Nodes must come out in
 // the reference's order (i ascending, chain order within i): a first pass counts them per lane, an
 // exclusive wave scan gives each lane its slice of the node array, a second pass writes.
+#define DSB_SDP_CAND 16
+#define DSB_SDP_KEEP 3
+#define DSB_DP_UNROLL 4
 struct SdpArgs { uint32_t q_bg, q_ed; const uint8_t *q_str, *t_str; uint32_t t_len, t_st; const uint32_t *head, *nextv, *km; uint64_t KEY_MASK; };
 
 template <bool FWD, bool WRITE>
-DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out)
+DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out, uint32_t out_cap)
 {
 	uint32_t cnt = 0;
 	const uint8_t *c_t; uint64_t kmer = 0;
@@ -1031,11 +1026,34 @@ DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out)
 		for (int j = 0; j < 9; j++) kmer |= (uint64_t)c_t[j] << (16 - 2 * j);
 		if (i > 4) kmer |= (uint64_t)(c_t[9] >> 2);
 	}
-	uint32_t next = a.head[kmer & a.KEY_MASK];
-	while (next != 0) {
+	// collect the read positions of this 9-mer inside [q_bg, q_ed], then visit them in ascending order
+	// (= the reference's chain order)
+	uint32_t cand[DSB_SDP_CAND]; int nc = 0; bool many = false;
+	const uint32_t head0 = a.head[kmer & a.KEY_MASK];
+	for (uint32_t next = head0; next != 0;) {
 		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
 		uint32_t q_pos = next - 1;
-		if (a.km[q_pos] == kmer && q_pos >= a.q_bg && q_pos <= a.q_ed) {
+		if (a.km[q_pos] == kmer && q_pos >= a.q_bg && q_pos <= a.q_ed) { if (nc < DSB_SDP_CAND) cand[nc++] = q_pos; else many = true; }
+		next = a.nextv[q_pos];
+	}
+	if (!many)
+		for (int u = 1; u < nc; u++) { uint32_t v = cand[u]; int z = u - 1; while (z >= 0 && cand[z] > v) { cand[z + 1] = cand[z]; z--; } cand[z + 1] = v; }
+	int64_t last = -1; int ci = 0;
+	for (;;) {
+		uint32_t q_pos;
+		if (!many) { if (ci >= nc) break; q_pos = cand[ci++]; }
+		else {	// long repeat: repeated selection of the next larger position
+			int64_t best = -1;
+			for (uint32_t next = head0; next != 0;) {
+				if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
+				uint32_t qp = next - 1;
+				if (a.km[qp] == kmer && qp >= a.q_bg && qp <= a.q_ed && (int64_t)qp > last && (best < 0 || (int64_t)qp < best)) best = qp;
+				next = a.nextv[qp];
+			}
+			if (best < 0) break;
+			q_pos = (uint32_t)best; last = best;
+		}
+		{
 			if (FWD) {
 				int back_len = MEM_search(a.q_str + q_pos - 1, c_t - 1, false, 4);
 				if (back_len < 4 || i == 4) {
@@ -1044,7 +1062,7 @@ DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out)
 					int fwd = MEM_search(a.q_str + q_pos + 9, c_t + 9, true, max_search);
 					int total = back_len + fwd + 1;
 					if (total >= 4) {
-						if (WRITE) { DsbSms *p = out + cnt; p->len = total; p->q_pos = q_pos - back_len; p->t_pos = i - back_len + a.t_st; }
+						if (WRITE && cnt < out_cap) { DsbSms *p = out + cnt; p->len = total; p->q_pos = q_pos - back_len; p->t_pos = i - back_len + a.t_st; }
 						cnt++;
 					}
 				}
@@ -1056,13 +1074,12 @@ DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out)
 					int back_len = MEM_search(a.q_str + q_pos - 1, c_t - 1, false, max_search);
 					int total = back_len + fwd + 1;
 					if (total >= 4) {
-						if (WRITE) { DsbSms *p = out + cnt; p->len = total; p->q_pos = q_pos - back_len; p->t_pos = (uint32_t)((long)(c_t - a.t_str) - back_len + a.t_st); }
+						if (WRITE && cnt < out_cap) { DsbSms *p = out + cnt; p->len = total; p->q_pos = q_pos - back_len; p->t_pos = (uint32_t)((long)(c_t - a.t_str) - back_len + a.t_st); }
 						cnt++;
 					}
 				}
 			}
 		}
-		next = a.nextv[q_pos];
 	}
 	return cnt;
 }
@@ -1075,11 +1092,14 @@ DN void sdp_match_t(WCtx &w, const SdpArgs &a)
 	uint32_t n_pos = (t_kmer_num - 4 + 3) / 4;                      // i = 4, 8, ... < t_kmer_num
 	for (uint32_t g = 0; g < n_pos; g += DSB_WAVE) {
 		uint32_t pI = g + w.lane; bool valid = pI < n_pos; int i = 4 + 4 * (int)pI;
-		uint32_t cnt = valid ? sdp_visit<FWD, false>(w, a, i, nullptr) : 0;
+		DsbSms keep[DSB_SDP_KEEP];
+		uint32_t cnt = valid ? sdp_visit<FWD, true>(w, a, i, keep, DSB_SDP_KEEP) : 0;
 		uint32_t total, off = wave_excl_scan_u(cnt, &total);
 		if (total == 0) continue;
 		if (w.n_sms + total > DSB_SMS_CAP) { w.status |= DSB_ST_SMS_OVF; return; }
-		if (cnt) sdp_visit<FWD, true>(w, a, i, w.sms + w.n_sms + off);
+		DsbSms *dst = w.sms + w.n_sms + off;
+		if (cnt <= DSB_SDP_KEEP) { for (uint32_t k = 0; k < cnt; k++) { dst[k].len = keep[k].len; dst[k].q_pos = keep[k].q_pos; dst[k].t_pos = keep[k].t_pos; } }
+		else sdp_visit<FWD, true>(w, a, i, dst, 0xffffffffu);
 		w.n_sms += total;
 		wave_sync();
 	}
@@ -1103,39 +1123,53 @@ DV int sdp_best_pred(WCtx &w, const DsbSms &cs, int32_t cur)
 	uint32_t lim_q, lim_t;
 	if (MODE == 2) { lim_q = cs.q_pos + cs.len - 6 + 9 - 1; lim_t = cs.t_pos + cs.len - 6 + 9 - 1; }
 	else { lim_q = cs.q_pos + 6; lim_t = cs.t_pos + 6; }
-	for (int32_t hi = cur - 1; hi >= 0; hi -= DSB_WAVE) {
-		int32_t pi = hi - w.lane; bool valid = pi >= 0;
-		DsbSms ps; if (valid) ps = w.sms[pi]; else { ps.t_pos = ps.q_pos = ps.len = ps.score = 0; }
-		bool skip, brk = false; int ns = 0;
-		if (MODE == 2) {
-			skip = (ps.q_pos < lim_q) || (ps.t_pos < lim_t);
-			if (!skip) brk = (lim_t + 600 < ps.t_pos);
-			if (!skip && !brk) {
-				int indel = ps.q_pos - ps.t_pos - (lim_q - lim_t); int ai = ABSV(indel);
-				if (ai > 200) skip = true;
-				else {
-					ns = ps.score + cs.len - (ai >> 3);
-					if (lim_q + 6 > ps.q_pos || lim_t + 6 > ps.t_pos) { int oq = lim_q + 6 - ps.q_pos, ot = lim_t + 6 - ps.t_pos; ns -= MAXV(oq, ot); }
-				}
-			}
-		} else {
-			int pre_q_ed = ps.q_pos + ps.len + 9 - 1, pre_t_ed = ps.t_pos + ps.len + 9 - 1;
-			skip = ((uint32_t)pre_q_ed > lim_q) || ((uint32_t)pre_t_ed > lim_t);
-			if (MODE == 1 && !skip) brk = (ps.t_pos + 600 < lim_t);
-			if (!skip && !brk) {
-				int indel = ps.q_pos - ps.t_pos - (lim_q - lim_t); int ai = ABSV(indel);
-				if (ai > 200) skip = true;
-				else {
-					ns = ps.score + cs.len - (ai >> 3);
-					if ((uint32_t)pre_q_ed > cs.q_pos || (uint32_t)pre_t_ed > cs.t_pos) { int oq = pre_q_ed - cs.q_pos, ot = pre_t_ed - cs.t_pos; ns -= MAXV(oq, ot); }
-				}
-			}
+	for (int32_t hi = cur - 1; hi >= 0; hi -= DSB_DP_UNROLL * DSB_WAVE) {
+		// DSB_DP_UNROLL groups of predecessors are loaded at once (independent loads in flight), then
+		// judged newest group first so that the distance cut stops at the same node as the reference
+		DsbSms pv[DSB_DP_UNROLL];
+#pragma unroll
+		for (int u = 0; u < DSB_DP_UNROLL; u++) {
+			int32_t pi = hi - u * DSB_WAVE - w.lane;
+			if (pi >= 0) pv[u] = w.sms[pi]; else { pv[u].t_pos = pv[u].q_pos = pv[u].len = pv[u].score = 0; }
 		}
-		// the reference stops at the first predecessor (newest first) that meets the distance cut
-		uint64_t bm = (MODE == 0) ? 0ULL : dsb_ballot(valid && brk);
-		int first_brk = bm ? __builtin_ctzll(bm) : DSB_WAVE;
-		if (valid && !skip && !brk && w.lane < first_brk) best = MAXV(best, ns);
-		if (bm) break;
+		bool stop = false;
+#pragma unroll
+		for (int u = 0; u < DSB_DP_UNROLL; u++) {
+			if (stop) break;
+			int32_t pi = hi - u * DSB_WAVE - w.lane; bool valid = pi >= 0;
+			DsbSms ps = pv[u];
+			bool skip, brk = false; int ns = 0;
+			if (MODE == 2) {
+				skip = (ps.q_pos < lim_q) || (ps.t_pos < lim_t);
+				if (!skip) brk = (lim_t + 600 < ps.t_pos);
+				if (!skip && !brk) {
+					int indel = ps.q_pos - ps.t_pos - (lim_q - lim_t); int ai = ABSV(indel);
+					if (ai > 200) skip = true;
+					else {
+						ns = ps.score + cs.len - (ai >> 3);
+						if (lim_q + 6 > ps.q_pos || lim_t + 6 > ps.t_pos) { int oq = lim_q + 6 - ps.q_pos, ot = lim_t + 6 - ps.t_pos; ns -= MAXV(oq, ot); }
+					}
+				}
+			} else {
+				int pre_q_ed = ps.q_pos + ps.len + 9 - 1, pre_t_ed = ps.t_pos + ps.len + 9 - 1;
+				skip = ((uint32_t)pre_q_ed > lim_q) || ((uint32_t)pre_t_ed > lim_t);
+				if (MODE == 1 && !skip) brk = (ps.t_pos + 600 < lim_t);
+				if (!skip && !brk) {
+					int indel = ps.q_pos - ps.t_pos - (lim_q - lim_t); int ai = ABSV(indel);
+					if (ai > 200) skip = true;
+					else {
+						ns = ps.score + cs.len - (ai >> 3);
+						if ((uint32_t)pre_q_ed > cs.q_pos || (uint32_t)pre_t_ed > cs.t_pos) { int oq = pre_q_ed - cs.q_pos, ot = pre_t_ed - cs.t_pos; ns -= MAXV(oq, ot); }
+					}
+				}
+			}
+			// the reference stops at the first predecessor (newest first) that meets the distance cut
+			uint64_t bm = (MODE == 0) ? 0ULL : dsb_ballot(valid && brk);
+			int first_brk = bm ? __builtin_ctzll(bm) : DSB_WAVE;
+			if (valid && !skip && !brk && w.lane < first_brk) best = MAXV(best, ns);
+			if (bm) stop = true;
+		}
+		if (stop) break;
 	}
 	return wave_max_i(best);
 }
