@@ -43,6 +43,8 @@ template <class T> static inline T dsb_shfl(T v, int) { return v; }
 #endif
 // stage timers (100 MHz ticks), accumulated per slot when DSB_DEBUG is set
 #define TICK(w, k) do { if ((w).dbg) { uint64_t _t = DSB_CLOCK(); (w).tacc[k] += _t - (w).tlast; (w).tlast = _t; } } while (0)
+#define SUB0(w) do { if ((w).dbg) (w).tsub = DSB_CLOCK(); } while (0)
+#define SUB1(w, k) do { if ((w).dbg) (w).tacc[k] += DSB_CLOCK() - (w).tsub; } while (0)
 #define MARK(w, code) do { if ((w).dbg && (w).lane == 0) { (w).dbg[0] = (code); (w).dbg[1] = (w).steps; } } while (0)
 
 DV void wave_sync()
@@ -93,9 +95,10 @@ struct WCtx {
 	int *score_v;
 	uint64_t *sortkey; uint32_t *sortidx;      // 2 x cap each (ping-pong)
 	uint8_t *win_mid, *win_right, *win_left;
-	uint32_t *lds_tab;         // 256 words of LDS scratch (conflict filter of the 9-mer table build)
+	int *blk_max; uint32_t *blk_tmin, *blk_tmax;   // LDS: per-64-node block summaries (exact pruning of the sparse DP)
+	uint4 *ring;               // LDS: the most recent DSB_RING sparse-DP nodes of sdp_right/left ({t_pos,q_pos,len,score})
 	int status; int max_read_l;
-	int stage; uint32_t steps; volatile uint32_t *dbg; uint64_t tacc[10], tlast;   // optional host-visible progress words (DSB_DEBUG)
+	int stage; uint32_t steps; volatile uint32_t *dbg; uint64_t tacc[14], tlast, tsub;   // optional host-visible progress words (DSB_DEBUG)
             // loop-iteration budget: every unbounded loop charges it and bails when exhausted
 	SDir sd[2];
 };
@@ -1005,9 +1008,10 @@ DV uint64_t bin2kmer9(const uint8_t *s) { uint64_t v = 0;
 // walks the read's chain for it and evaluates the two exact-match extensions.  Nodes must come out in
 // the reference's order (i ascending, chain order within i): a first pass counts them per lane, an
 // exclusive wave scan gives each lane its slice of the node array, a second pass writes.
-#define DSB_SDP_CAND 16
+#define DSB_SDP_CAND 64
 #define DSB_SDP_KEEP 3
 #define DSB_DP_UNROLL 4
+#define DSB_RING 1024
 struct SdpArgs { uint32_t q_bg, q_ed; const uint8_t *q_str, *t_str; uint32_t t_len, t_st; const uint32_t *head, *nextv, *km; uint64_t KEY_MASK; };
 
 template <bool FWD, bool WRITE>
@@ -1036,8 +1040,12 @@ DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out, uint32_t ou
 		if (a.km[q_pos] == kmer && q_pos >= a.q_bg && q_pos <= a.q_ed) { if (nc < DSB_SDP_CAND) cand[nc++] = q_pos; else many = true; }
 		next = a.nextv[q_pos];
 	}
-	if (!many)
+	if (!many) {
+		// positions were pushed at the chain head roughly in ascending order, so the walk returns them
+		// roughly descending: reverse, then a (now nearly linear) insertion sort
+		for (int u = 0; u < nc / 2; u++) { uint32_t v = cand[u]; cand[u] = cand[nc - 1 - u]; cand[nc - 1 - u] = v; }
 		for (int u = 1; u < nc; u++) { uint32_t v = cand[u]; int z = u - 1; while (z >= 0 && cand[z] > v) { cand[z + 1] = cand[z]; z--; } cand[z + 1] = v; }
+	}
 	int64_t last = -1; int ci = 0;
 	for (;;) {
 		uint32_t q_pos;
@@ -1113,6 +1121,32 @@ DN void sdp_match(WCtx &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, c
 	if (isForward) sdp_match_t<true>(w, a); else sdp_match_t<false>(w, a);
 }
 
+DV void ring_put(WCtx &w, uint32_t idx, uint32_t t_pos, uint32_t q_pos, uint32_t len, uint32_t score)
+{
+	uint4 r; r.x = t_pos; r.y = q_pos; r.z = len; r.w = score;
+	w.ring[idx & (DSB_RING - 1)] = r;
+	uint32_t b = idx >> 6;
+	if ((idx & 63u) == 0) { w.blk_max[b] = (int)score; w.blk_tmin[b] = t_pos; w.blk_tmax[b] = t_pos; }
+	else {
+		if ((int)score > w.blk_max[b]) w.blk_max[b] = (int)score;
+		if (t_pos < w.blk_tmin[b]) w.blk_tmin[b] = t_pos;
+		if (t_pos > w.blk_tmax[b]) w.blk_tmax[b] = t_pos;
+	}
+}
+// the nodes sdp_match appended are consumed one by one: fetch them 64 at a time (one per lane) and hand
+// node idx to every lane with shuffles
+struct NodeBlock { uint32_t base, valid; DsbSms mine; };
+DV DsbSms node_get(WCtx &w, NodeBlock &b, uint32_t idx)
+{
+	if (idx < b.base || idx >= b.base + b.valid) {
+		b.base = idx; b.valid = MINV((uint32_t)DSB_WAVE, w.n_sms - idx);
+		if ((uint32_t)w.lane < b.valid) b.mine = w.sms[idx + w.lane];
+	}
+	DsbSms r; int src = (int)(idx - b.base);
+	r.t_pos = dsb_shfl(b.mine.t_pos, src); r.q_pos = dsb_shfl(b.mine.q_pos, src); r.len = dsb_shfl(b.mine.len, src); r.score = 0;
+	return r;
+}
+
 // best predecessor score of a new node among nodes [0, cur): the sparse-DP inner loops of
 // sdp_middle_M2 / sdp_right_M2 / sdp_left_M2 (src/cly.c:2495-2517, 2612-2638, 2759-2783), lanes over
 // predecessors (newest first), wave max at the end.  MODE 0 = middle (no distance cut), 1 = right, 2 = left.
@@ -1130,7 +1164,9 @@ DV int sdp_best_pred(WCtx &w, const DsbSms &cs, int32_t cur)
 #pragma unroll
 		for (int u = 0; u < DSB_DP_UNROLL; u++) {
 			int32_t pi = hi - u * DSB_WAVE - w.lane;
-			if (pi >= 0) pv[u] = w.sms[pi]; else { pv[u].t_pos = pv[u].q_pos = pv[u].len = pv[u].score = 0; }
+			if (pi < 0) { pv[u].t_pos = pv[u].q_pos = pv[u].len = pv[u].score = 0; }
+			else if (MODE != 0 && pi > cur - DSB_RING) { uint4 r = w.ring[pi & (DSB_RING - 1)]; pv[u].t_pos = r.x; pv[u].q_pos = r.y; pv[u].len = r.z; pv[u].score = r.w; }
+			else pv[u] = w.sms[pi];
 		}
 		bool stop = false;
 #pragma unroll
@@ -1173,6 +1209,7 @@ DV int sdp_best_pred(WCtx &w, const DsbSms &cs, int32_t cur)
 	}
 	return wave_max_i(best);
 }
+
 
 DV void fill_window(const WCtx &w, uint8_t *win, int n)
 {
@@ -1236,6 +1273,9 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 	wave_sync();
 	DsbSms *p = push_sms(w);
 	p->score = score_ori; p->q_pos = c_h->q_ed; p->t_pos = c_h->t_ed; p->len = 1 - 9;
+	ring_put(w, 0, p->t_pos, p->q_pos, p->len, p->score);
+	uint32_t best_t = c_h->t_ed, best_q = c_h->q_ed, best_len = (uint32_t)(1 - 9);     // fields of node max_sms_id
+	NodeBlock nb; nb.base = 0; nb.valid = 0;
 	uint32_t current_sms = 1;
 	uint64_t t_offset_global = x->refinfo[c_h->ref_ID].seq_offset, t_length = x->refinfo[c_h->ref_ID].seq_l;
 	uint32_t c_t_offset = c_h->t_ed - 3;
@@ -1254,34 +1294,45 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 			max_search_ref = MINV(600u, max_search_ref);
 			get_ref_wave(w, ref, c_t_offset + t_offset_global, max_search_ref + 50);
 			wave_sync();
-			int search_q_ed = (int)w.sms[max_sms_id].q_pos + 1000;
+			int search_q_ed = (int)best_q + 1000;
 			search_q_ed = MINV((uint32_t)search_q_ed, l_read);
 			int search_q_st = MAXV((uint32_t)(search_q_ed - 2000), c_h->q_st - 8);
+			SUB0(w);
 			sdp_match(w, search_q_st, search_q_ed, q_str, ref, max_search_ref, key_len, tbl, c_t_offset, true);
+			SUB1(w, 10);
 			c_t_offset += max_search_ref - 9 - 3;
 			if (w.n_sms == current_sms) break;
-			if (w.sms[current_sms].t_pos > w.sms[max_sms_id].t_pos + 1000) break;
+			nb.valid = 0;
+			if (node_get(w, nb, current_sms).t_pos > best_t + 1000) break;
 		}
-		DsbSms *c_sms = w.sms + current_sms++;
-		DsbSms cs = *c_sms;
+		DsbSms *c_sms = w.sms + current_sms;
+		DsbSms cs = node_get(w, nb, current_sms); current_sms++;
+		SUB0(w);
 		int max_score = sdp_best_pred<1>(w, cs, (int32_t)current_sms - 1);
+		SUB1(w, 11);
 		c_sms->score = max_score;
-		if ((int)cs.len >= 8 && combine_chain(c_st, chain_ID, sc_hash, cs.t_pos - cs.q_pos, false, cs.q_pos, &combined) == true) {
+		ring_put(w, current_sms - 1, cs.t_pos, cs.q_pos, cs.len, (uint32_t)max_score);
+		SUB0(w);
+		bool comb = (int)cs.len >= 8 && combine_chain(c_st, chain_ID, sc_hash, cs.t_pos - cs.q_pos, false, cs.q_pos, &combined) == true;
+		SUB1(w, 12);
+		if (comb) {
 			int c_len = cs.len;
 			total_max_score = MAXV(score_ori, max_score) - c_len + sdp_middle_M2(w, combined->cur, q_str, tbl, key_len);
 			score_ori = total_max_score; max_sms_id = 0;
 			w.n_sms = 0;
 			p = push_sms(w);
 			p->score = total_max_score; p->q_pos = c_h->q_ed; p->t_pos = c_h->t_ed; p->len = -9;
+			ring_put(w, 0, p->t_pos, p->q_pos, p->len, p->score);
+			best_t = c_h->t_ed; best_q = c_h->q_ed; best_len = (uint32_t)(-9); nb.valid = 0;
 			current_sms = 1;
 			c_t_offset = c_h->t_ed;
 			continue;
 		}
-		if (total_max_score < max_score) { total_max_score = max_score; max_sms_id = current_sms - 1; }
-		if (cs.t_pos > w.sms[max_sms_id].t_pos + 1000) break;
+		if (total_max_score < max_score) { total_max_score = max_score; max_sms_id = current_sms - 1; best_t = cs.t_pos; best_q = cs.q_pos; best_len = cs.len; }
+		if (cs.t_pos > best_t + 1000) break;
 	}
-	c_h->q_ed = w.sms[max_sms_id].q_pos + w.sms[max_sms_id].len + 9;
-	c_h->t_ed = w.sms[max_sms_id].t_pos + w.sms[max_sms_id].len + 9;
+	c_h->q_ed = best_q + best_len + 9;
+	c_h->t_ed = best_t + best_len + 9;
 	return total_max_score - 10000;
 }
 
@@ -1298,6 +1349,9 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 	wave_sync();
 	DsbSms *p = push_sms(w);
 	p->score = score_ori; p->q_pos = c_h->q_st; p->t_pos = c_h->t_st;
+	ring_put(w, 0, p->t_pos, p->q_pos, 0, p->score);                       // a[0].len is never read by the left DP
+	uint32_t best_t = c_h->t_st, best_q = c_h->q_st;                       // fields of node max_sms_id
+	NodeBlock nb; nb.base = 0; nb.valid = 0;
 	uint32_t current_sms = 1;
 	uint64_t t_offset_global = x->refinfo[c_h->ref_ID].seq_offset;
 	uint32_t c_t_offset = c_h->t_st + 3;
@@ -1319,18 +1373,24 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 			else
 				get_ref_wave(w, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref - 50), max_search_ref + 50);
 			wave_sync();
-			int search_q_st = (int)w.sms[max_sms_id].q_pos - 1000;
+			int search_q_st = (int)best_q - 1000;
 			search_q_st = MAXV(search_q_st, 0);
 			int search_q_ed = MINV((uint32_t)(search_q_st + 2000), c_h->q_st - 1);
+			SUB0(w);
 			sdp_match(w, search_q_st, search_q_ed, q_str, ref + 50, max_search_ref, key_len, tbl, c_t_offset - max_search_ref, false);
+			SUB1(w, 10);
 			c_t_offset = c_t_offset - max_search_ref + 9 + 3;
 			if (w.n_sms == current_sms) break;
-			if (w.sms[current_sms].t_pos + 1000 < w.sms[max_sms_id].t_pos) break;
+			nb.valid = 0;
+			if (node_get(w, nb, current_sms).t_pos + 1000 < best_t) break;
 		}
-		DsbSms *c_sms = w.sms + current_sms++;
-		DsbSms cs = *c_sms;
+		DsbSms *c_sms = w.sms + current_sms;
+		DsbSms cs = node_get(w, nb, current_sms); current_sms++;
+		SUB0(w);
 		int max_score = sdp_best_pred<2>(w, cs, (int32_t)current_sms - 1);
+		SUB1(w, 11);
 		c_sms->score = max_score;
+		ring_put(w, current_sms - 1, cs.t_pos, cs.q_pos, cs.len, (uint32_t)max_score);
 		if ((int)cs.len >= 8 && combine_chain(c_st, chain_ID, sc_hash, cs.t_pos - cs.q_pos, true, cs.q_pos + cs.len, &combined) == true) {
 			int c_len = cs.len;
 			total_max_score = MAXV(score_ori, max_score) - c_len + sdp_middle_M2(w, combined->cur, q_str, tbl, key_len);
@@ -1338,15 +1398,17 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 			w.n_sms = 0;
 			p = push_sms(w);
 			p->score = total_max_score; p->q_pos = c_h->q_st; p->t_pos = c_h->t_st;
+			ring_put(w, 0, p->t_pos, p->q_pos, 0, p->score);
+			best_t = c_h->t_st; best_q = c_h->q_st; nb.valid = 0;
 			current_sms = 1;
 			c_t_offset = c_h->t_st;
 			continue;
 		}
-		if (total_max_score < max_score) { total_max_score = max_score; max_sms_id = current_sms - 1; }
-		if (cs.t_pos + 1000 < w.sms[max_sms_id].t_pos) break;
+		if (total_max_score < max_score) { total_max_score = max_score; max_sms_id = current_sms - 1; best_t = cs.t_pos; best_q = cs.q_pos; }
+		if (cs.t_pos + 1000 < best_t) break;
 	}
-	c_h->q_st = w.sms[max_sms_id].q_pos;
-	c_h->t_st = w.sms[max_sms_id].t_pos;
+	c_h->q_st = best_q;
+	c_h->t_st = best_t;
 	return total_max_score - 10000;
 }
 

@@ -118,13 +118,15 @@ __global__ void __launch_bounds__(64) k_classify(DsbDevIndex x, const DsbReadDes
 	// The index descriptor is read on every rank query: keep it in LDS.  (A pointer to the kernel-argument
 	// segment would turn each x->field into a vector load from host-coherent memory.)
 	__shared__ DsbDevIndex sx;
-	__shared__ uint32_t lds_tab[256];
+	__shared__ uint4 lds_ring[DSB_RING];
+	__shared__ int lds_bmax[DSB_SMS_CAP / 64 + 1]; __shared__ uint32_t lds_btmin[DSB_SMS_CAP / 64 + 1], lds_btmax[DSB_SMS_CAP / 64 + 1];
+	__shared__ DsbScHash lds_sc[256 + 2 * 400 + 64];
 	if (lane == 0) sx = x;
 	__syncthreads();
 	WCtx w;
-	w.lds_tab = lds_tab;
+	w.ring = lds_ring; w.blk_max = lds_bmax; w.blk_tmin = lds_btmin; w.blk_tmax = lds_btmax;
 	w.x = &sx; w.lane = lane; w.dbg = dbg ? dbg + 4 * blockIdx.x : nullptr;
-	for (int i = 0; i < 10; i++) w.tacc[i] = 0;
+	for (int i = 0; i < 14; i++) w.tacc[i] = 0;
 	w.seeds = (DsbSeed *)(slot + ar.off_seeds);
 	w.anc = (DsbAnchor *)(slot + ar.off_anc); w.anc_tmp = (DsbAnchor *)(slot + ar.off_anc_tmp);
 	w.hit = (DsbChain *)(slot + ar.off_hit); w.hit_tmp = (DsbChain *)(slot + ar.off_hit_tmp);
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(64) k_classify(DsbDevIndex x, const DsbReadDes
 	size_t kh_strand = (size_t)(1u << 18) + 2 * (size_t)ar.max_len;
 	w.kh_head[0] = kh; w.kh_next[0] = kh + (1u << 18); w.kh_kmer[0] = w.kh_next[0] + ar.max_len;
 	w.kh_head[1] = kh + kh_strand; w.kh_next[1] = w.kh_head[1] + (1u << 18); w.kh_kmer[1] = w.kh_next[1] + ar.max_len;
-	w.sc = (DsbScHash *)(slot + ar.off_sc);
+	w.sc = lds_sc;
 	w.mem_slow = (DsbMem *)(slot + ar.off_mem);
 	w.spset = (uint64_t *)(slot + ar.off_spset);
 	w.score_v = (int *)(slot + ar.off_scorev);
@@ -146,7 +148,7 @@ __global__ void __launch_bounds__(64) k_classify(DsbDevIndex x, const DsbReadDes
 		unsigned int r = 0;
 		if (lane == 0) r = atomicAdd(work_counter, 1u);
 		r = __shfl(r, 0);
-		if (r >= n_reads) { if (w.dbg && lane == 0) { w.dbg[0] = 999; for (int i = 0; i < 10; i++) dbg[4 * 65536 + 10 * blockIdx.x + i] = (uint32_t)(w.tacc[i] / 100); } break; }   // every wave reaches this: the grid always drains
+		if (r >= n_reads) { if (w.dbg && lane == 0) { w.dbg[0] = 999; for (int i = 0; i < 14; i++) dbg[4 * 65536 + 14 * blockIdx.x + i] = (uint32_t)(w.tacc[i] / 100); } break; }   // every wave reaches this: the grid always drains
 		DsbReadDesc d = rd[r];
 		uint64_t t_start = wall_clock64();
 		if (w.dbg && lane == 0) { w.dbg[2] = r; w.dbg[0] = 100; }
@@ -388,7 +390,9 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	if (dbg) {
 		static const char *nm[10] = {"seed_vector", "fast_classify", "resolve_tree", "slow+resolve", "hash_build", "sdp_middle", "sdp_right", "sdp_left", "sort/filter", "primary"};
 		double tot[10] = {0}, all = 0; unsigned slots = (unsigned)c->n_slots; if (slots > n) slots = (unsigned)n;
-		for (unsigned sI = 0; sI < slots; sI++) for (int i = 0; i < 10; i++) { tot[i] += c->dbg_host[4 * 65536 + 10 * sI + i]; all += c->dbg_host[4 * 65536 + 10 * sI + i]; }
+		double sub[4] = {0};
+		for (unsigned sI = 0; sI < slots; sI++) { for (int i = 0; i < 10; i++) { tot[i] += c->dbg_host[4 * 65536 + 14 * sI + i]; all += c->dbg_host[4 * 65536 + 14 * sI + i]; } for (int i = 0; i < 4; i++) sub[i] += c->dbg_host[4 * 65536 + 14 * sI + 10 + i]; }
+		fprintf(stderr, "[dsb] inside sdp_right/left (ms): sdp_match %.1f  dp %.1f  combine %.1f\n", sub[0] / 1e3, sub[1] / 1e3, sub[2] / 1e3);
 		fprintf(stderr, "[dsb] classify stage time (wave-seconds, %% of total %.2f s):", all / 1e6);
 		for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * tot[i] / (all > 0 ? all : 1));
 		fprintf(stderr, "\n");

@@ -10,7 +10,10 @@ fq = "/tmp/prof_%d.fq" % n
 if not os.path.exists(fq):
     os.system("%s/tools/readsim %s/data/demo/index %s %d 50000 0.15 1 ont" % (ROOT, ROOT, fq, n))
 idx = D.Index(ROOT + "/data/demo/index"); ctx = D.Ctx(idx, 0, n_slots=slots)
-reads = D.make_reads(D.read_fastq(fq)); ctx.upload(reads)
+recs = D.read_fastq(fq)
+if os.environ.get("ONLY"):
+    recs = [recs[int(i)] for i in os.environ["ONLY"].split(",")]
+reads = D.make_reads(recs); ctx.upload(reads)
 for _ in range(reps):
     ctx.run()
 t = ctx.timing()
