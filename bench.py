@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads-per-gpu", type=int, default=8192)
+    ap.add_argument("--reads-per-gpu", type=int, default=32768)
     ap.add_argument("--read-len", type=int, default=50000)
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -140,6 +140,7 @@ def main():
     res = ctx.fetch(strict=False)
     n_bad = sum(1 for i in range(len(recs)) if res.reads[i].status != 0)
     n_mapped = sum(1 for i in range(len(recs)) if res.reads[i].n > 0)
+    dev_us = sorted(res.reads[i].device_us for i in range(len(recs)))
 
     if rank == 0:
         steps = max(a.steps, 1)
@@ -169,6 +170,8 @@ def main():
             "roofline": roof_cls if dom_is_cls else roof_seed,
             "roofline_seed_lookup": roof_seed,
             "reads_mapped_frac": n_mapped / max(len(recs), 1), "reads_with_device_status": n_bad,
+            "per_read_wave_us": {"mean": sum(dev_us) / max(len(dev_us), 1), "median": dev_us[len(dev_us) // 2] if dev_us else 0,
+                                 "p99": dev_us[int(len(dev_us) * 0.99)] if dev_us else 0, "max": dev_us[-1] if dev_us else 0},
         }
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(index_dir, fq, a.reads_per_gpu, a.cpu_sample)

@@ -1,4 +1,4 @@
-// Device side of classify_seq (src/cly.c:3064-3132), one read per 64-lane wavefront.
+// Device side of classify_seq (src/cly.c:3064-3132), one read per group of DSB_GROUP threads.
 //
 // Execution model: every lane of the wave runs the read's control flow redundantly (all
 // values are wave-uniform, loads broadcast, stores coalesce to one transaction), and the
@@ -8,25 +8,36 @@
 //
 // Integer types and expression shapes follow the reference where its results depend on C's
 // signed/unsigned conversions (e.g. src/cly.c:2590-2592); citations are on each function.
-#pragma once
+// This header may be included more than once: DSB_GROUP (threads that work on one read: 64 = one
+// wavefront, or a multiple of 64 = a whole workgroup) and DSB_NS (namespace of the instantiation) are set
+// by the includer.  k_classify uses <64>.  (A 512-thread instantiation for reads with a very heavy sparse DP
+// was tried in round 1: its barrier-based reductions cost more than the extra lanes gained; not built.)
 #include "dsb_device.h"
 
-// DSB_HOST_EMU (tests/emu only): the same functions compiled for the host as a 1-lane wave, so the
+#ifndef DSB_GROUP
+#define DSB_GROUP 64
+#endif
+#ifndef DSB_NS
+#define DSB_NS dsb_g64
+#endif
+
+// DSB_HOST_EMU (tests/emu only): the same functions compiled for the host as a 1-lane group, so the
 // per-read logic can be run under gdb / sanitizers on a machine without a GPU.  Never part of the product.
+#undef DV
+#undef DN
+#undef DSB_WAVE
 #ifdef DSB_HOST_EMU
 #define DV static inline
 #define DN static
 #define DSB_WAVE 1
-static inline unsigned long long dsb_ballot(int p) { return p ? 1ULL : 0ULL; }
-template <class T> static inline T dsb_shfl(T v, int) { return v; }
 #define __popcll __builtin_popcountll
 #else
 #define DV __device__ __forceinline__
 #define DN __device__ __noinline__
-#define DSB_WAVE 64
-#define dsb_ballot(p) __ballot(p)
-#define dsb_shfl(v, l) __shfl(v, l)
+#define DSB_WAVE DSB_GROUP
 #endif
+#ifndef DSB_DEV_COMMON
+#define DSB_DEV_COMMON
 #define MAXV(a,b) (((a) > (b))?(a):(b))
 #define MINV(a,b) (((a) < (b))?(a):(b))
 #define ABSV(a) (((a) > 0)?(a): (- (a)))
@@ -35,7 +46,8 @@ template <class T> static inline T dsb_shfl(T v, int) { return v; }
 #define D_REVERSE 0u
 #define D_U64MAX 0xffffffffffffffffULL
 #define DSB_STEP_LIMIT 20000000u
-#define SPENT(w) (++(w).steps > DSB_STEP_LIMIT)
+#define SPENT(w) (++(w).steps > DSB_STEP_LIMIT)        /* group-uniform code only */
+#define LSPENT(w) (++(w).lsteps > DSB_STEP_LIMIT)      /* per-thread code (fast_island, sdp_visit) */
 #ifdef DSB_HOST_EMU
 #define DSB_CLOCK() 0ULL
 #else
@@ -46,34 +58,105 @@ template <class T> static inline T dsb_shfl(T v, int) { return v; }
 #define SUB0(w) do { if ((w).dbg) (w).tsub = DSB_CLOCK(); } while (0)
 #define SUB1(w, k) do { if ((w).dbg) (w).tacc[k] += DSB_CLOCK() - (w).tsub; } while (0)
 #define MARK(w, code) do { if ((w).dbg && (w).lane == 0) { (w).dbg[0] = (code); (w).dbg[1] = (w).steps; } } while (0)
+// a read whose sparse DP scans more than this many predecessors is handed to the wide kernel
+#define DSB_HEAVY_PREDS 2500000u
+#endif
 
+#undef DSB_HEAVY_ABORT
+#if defined(DSB_ENABLE_HEAVY_ABORT)
+#define DSB_HEAVY_ABORT 1
+#else
+#define DSB_HEAVY_ABORT 0
+#endif
+
+// A read whose sparse DP has already scanned DSB_BOOST_PREDS predecessors is ALU-bound for a long time
+// (tandem repeats): give its wavefront issue priority over the latency-bound waves sharing the SIMD, so
+// the batch does not wait for it.  Reset when the read is done (k_classify).
+#ifndef DSB_BOOST_IF_HEAVY
+#define DSB_BOOST_PREDS 300000u
+#ifdef DSB_HOST_EMU
+#define DSB_BOOST_IF_HEAVY(w) do { } while (0)
+#else
+#define DSB_BOOST_IF_HEAVY(w) do { if (!(w).boosted && (w).dp_preds > DSB_BOOST_PREDS) { __builtin_amdgcn_s_setprio(3); (w).boosted = 1; } } while (0)
+#endif
+#endif
+
+namespace DSB_NS {
+
+// ---- group primitives: the threads working on one read (DSB_GROUP of them) ------------------------
+// wave_sync     make the group's earlier stores visible to all of its threads
+// grp_first     smallest thread index whose predicate is true (DSB_GROUP if none)
+// grp_max_i     maximum over the group
+// grp_excl_scan exclusive prefix sum over thread index, and the total
+// All are called by every thread of the group from group-uniform control flow.
+#ifdef DSB_HOST_EMU
+DV void wave_sync() {}
+DV int grp_first(uint32_t *, int, bool p) { return p ? 0 : DSB_WAVE; }
+DV int grp_max_i(uint32_t *, int, int v) { return v; }
+DV uint32_t grp_excl_scan_u(uint32_t *, int, uint32_t v, uint32_t *total) { *total = v; return 0; }
+template <class T> static inline T dsb_shfl(T v, int) { return v; }
+#elif DSB_GROUP == 64
 DV void wave_sync()
-{	// make this wave's earlier stores visible to all of its lanes (same CU, same L1)
-#ifndef DSB_HOST_EMU
+{	// same CU, same L1: a workgroup-scope release/acquire pair is enough
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#endif
 }
-
-// wave-level helpers (1-lane versions in the host emulation)
-#ifdef DSB_HOST_EMU
-DV int wave_max_i(int v) { return v; }
-DV uint32_t wave_excl_scan_u(uint32_t v, uint32_t *total) { *total = v; return 0; }
-#else
-DV int wave_max_i(int v)
+DV int grp_first(uint32_t *, int, bool p) { uint64_t m = __ballot(p); return m ? (int)__builtin_ctzll(m) : 64; }
+DV int grp_max_i(uint32_t *, int, int v)
 {
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) { int u = __shfl_xor(v, o); v = u > v ? u : v; }
 	return v;
 }
-DV uint32_t wave_excl_scan_u(uint32_t v, uint32_t *total)
+DV uint32_t grp_excl_scan_u(uint32_t *, int lane, uint32_t v, uint32_t *total)
 {
-	uint32_t inc = v; const int lane = __lane_id();
+	uint32_t inc = v;
 #pragma unroll
 	for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
 	*total = __shfl(inc, 63);
 	return inc - v;
+}
+#define dsb_shfl(v, l) __shfl(v, l)
+#else
+DV void wave_sync() { __syncthreads(); }
+// red: DSB_GROUP/64 + 1 words of LDS
+DV int grp_first(uint32_t *red, int tid, bool p)
+{
+	uint64_t m = __ballot(p);
+	if ((tid & 63) == 0) red[tid >> 6] = m ? (uint32_t)((tid & ~63) + __builtin_ctzll(m)) : (uint32_t)DSB_GROUP;
+	__syncthreads();
+	uint32_t r = DSB_GROUP;
+#pragma unroll
+	for (int k = 0; k < DSB_GROUP / 64; k++) r = red[k] < r ? red[k] : r;
+	__syncthreads();
+	return (int)r;
+}
+DV int grp_max_i(uint32_t *red, int tid, int v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { int u = __shfl_xor(v, o); v = u > v ? u : v; }
+	if ((tid & 63) == 0) red[tid >> 6] = (uint32_t)v;
+	__syncthreads();
+	int r = (int)red[0];
+#pragma unroll
+	for (int k = 1; k < DSB_GROUP / 64; k++) r = (int)red[k] > r ? (int)red[k] : r;
+	__syncthreads();
+	return r;
+}
+DV uint32_t grp_excl_scan_u(uint32_t *red, int tid, uint32_t v, uint32_t *total)
+{
+	uint32_t inc = v; const int lane = tid & 63;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+	if (lane == 63) red[tid >> 6] = inc;
+	__syncthreads();
+	uint32_t base = 0, tot = 0;
+#pragma unroll
+	for (int k = 0; k < DSB_GROUP / 64; k++) { if (k < (tid >> 6)) base += red[k]; tot += red[k]; }
+	__syncthreads();
+	*total = tot;
+	return base + inc - v;
 }
 #endif
 
@@ -95,10 +178,12 @@ struct WCtx {
 	int *score_v;
 	uint64_t *sortkey; uint32_t *sortidx;      // 2 x cap each (ping-pong)
 	uint8_t *win_mid, *win_right, *win_left;
-	int *blk_max; uint32_t *blk_tmin, *blk_tmax;   // LDS: per-64-node block summaries (exact pruning of the sparse DP)
+	uint32_t *red;             // LDS: DSB_GROUP/64+1 words for the group primitives
+	uint32_t *round_info;      // per-thread results of one island round of fast_classify (n | flag<<16 | ovf<<17)
+	uint32_t dp_preds;         // predecessors scanned by the sparse DP of this read (heavy-read detection)
 	uint4 *ring;               // LDS: the most recent DSB_RING sparse-DP nodes of sdp_right/left ({t_pos,q_pos,len,score})
 	int status; int max_read_l;
-	int stage; uint32_t steps; volatile uint32_t *dbg; uint64_t tacc[14], tlast, tsub;   // optional host-visible progress words (DSB_DEBUG)
+	int stage; int boosted; uint32_t steps, lsteps; volatile uint32_t *dbg; uint64_t tacc[14], tlast, tsub;   // optional host-visible progress words (DSB_DEBUG)
             // loop-iteration budget: every unbounded loop charges it and bails when exhausted
 	SDir sd[2];
 };
@@ -191,7 +276,7 @@ DV int64_t get_uni(const DsbDevIndex *x, uint64_t bwt_pos, int search_l, uint64_
 
 // ---- lv_extd (src/cly.c:510-609).  Both strings live in local byte arrays with 8 bytes in
 // front (oracle U5); the sentinels '#'/'$' are placed by the caller at index len.
-DV int32_t lv_extd(const uint8_t *ref, int32_t ref_length, const uint8_t *query, int32_t query_length)
+DN int32_t lv_extd(const uint8_t *ref, int32_t ref_length, const uint8_t *query, int32_t query_length)
 {
 	if (ref_length == 0 && query_length == 0) return 0;
 	int32_t mn_d[12], ed_d[12];
@@ -199,14 +284,10 @@ DV int32_t lv_extd(const uint8_t *ref, int32_t ref_length, const uint8_t *query,
 	int32_t best = query_length;
 #define MN(i) mn_d[(i) + 5]
 #define ED(i) ed_d[(i) + 5]
-#pragma unroll
-	for (int i = -5; i <= 5; i++) { MN(i) = -1; ED(i) = (i > 0) ? i : -i; }
-	MN(6) = -1; ED(6) = 6;
-#pragma unroll
+	for (int i = -5; i <= 6; i++) { MN(i) = -1; ED(i) = (i > 0) ? i : -i; }
 	for (int i = 0; i <= 4; i++) {
 		prev_mn = -1; cur_mn = i - 1; next_mn = MN(-i + 1);
 		prev_ed = i + 1; cur_ed = i; next_ed = ED(-i + 1);
-#pragma unroll
 		for (int j = -i; j <= 4; j++) {
 			int mnj, edj;
 			if (cur_mn + j < ref_length - 1) {
@@ -576,7 +657,7 @@ DV int fast_island(WCtx &w, SDir *s_d, uint32_t read_len, uint32_t seed_idx)
 	int skip_next = 0;
 	uint32_t a_b_idx = w.n_anc;
 	for (int j = (int)sv.len - 1; j >= min_index;) {
-		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
+		if (LSPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
 		int kmer_index = sv.offset + j;
 		int string_index = kmer_index + l_ek - 1;
 		uint64_t prefixValue = prefix13(bin_read, string_index);
@@ -621,11 +702,12 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 		if (ovf) w.status &= ~DSB_ST_ANC_OVF;
 		uint32_t my_n = w.n_anc;
 		w.anc = main_anc; w.n_anc = main_n; w.anc_cap = DSB_ANC_CAP; w.spset = main_sp;
+		w.round_info[w.lane] = my_n | ((uint32_t)flag << 16) | ((uint32_t)ovf << 17);
 		wave_sync();
 		uint32_t n_round = MINV((uint32_t)DSB_WAVE, n_top - base);
 		for (uint32_t l = 0; l < n_round; l++) {
 			uint32_t sidx = w.top_idx[base + l];
-			uint32_t n_l = dsb_shfl(my_n, (int)l); int f_l = dsb_shfl(flag, (int)l); int ovf_l = dsb_shfl(ovf, (int)l);
+			uint32_t ri = w.round_info[l]; uint32_t n_l = ri & 0xffffu; int f_l = (ri >> 16) & 1, ovf_l = (ri >> 17) & 1;
 			if (sidx == skip_seed) continue;
 			if (ovf_l) f_l = fast_island(w, s_d, read_len, sidx);
 			else {
@@ -1011,7 +1093,7 @@ DV uint64_t bin2kmer9(const uint8_t *s) { uint64_t v = 0;
 #define DSB_SDP_CAND 64
 #define DSB_SDP_KEEP 3
 #define DSB_DP_UNROLL 4
-#define DSB_RING 1024
+#define DSB_RING 256
 struct SdpArgs { uint32_t q_bg, q_ed; const uint8_t *q_str, *t_str; uint32_t t_len, t_st; const uint32_t *head, *nextv, *km; uint64_t KEY_MASK; };
 
 template <bool FWD, bool WRITE>
@@ -1035,7 +1117,7 @@ DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out, uint32_t ou
 	uint32_t cand[DSB_SDP_CAND]; int nc = 0; bool many = false;
 	const uint32_t head0 = a.head[kmer & a.KEY_MASK];
 	for (uint32_t next = head0; next != 0;) {
-		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
+		if (LSPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
 		uint32_t q_pos = next - 1;
 		if (a.km[q_pos] == kmer && q_pos >= a.q_bg && q_pos <= a.q_ed) { if (nc < DSB_SDP_CAND) cand[nc++] = q_pos; else many = true; }
 		next = a.nextv[q_pos];
@@ -1053,7 +1135,7 @@ DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out, uint32_t ou
 		else {	// long repeat: repeated selection of the next larger position
 			int64_t best = -1;
 			for (uint32_t next = head0; next != 0;) {
-				if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
+				if (LSPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
 				uint32_t qp = next - 1;
 				if (a.km[qp] == kmer && qp >= a.q_bg && qp <= a.q_ed && (int64_t)qp > last && (best < 0 || (int64_t)qp < best)) best = qp;
 				next = a.nextv[qp];
@@ -1102,7 +1184,7 @@ DN void sdp_match_t(WCtx &w, const SdpArgs &a)
 		uint32_t pI = g + w.lane; bool valid = pI < n_pos; int i = 4 + 4 * (int)pI;
 		DsbSms keep[DSB_SDP_KEEP];
 		uint32_t cnt = valid ? sdp_visit<FWD, true>(w, a, i, keep, DSB_SDP_KEEP) : 0;
-		uint32_t total, off = wave_excl_scan_u(cnt, &total);
+		uint32_t total, off = grp_excl_scan_u(w.red, w.lane, cnt, &total);
 		if (total == 0) continue;
 		if (w.n_sms + total > DSB_SMS_CAP) { w.status |= DSB_ST_SMS_OVF; return; }
 		DsbSms *dst = w.sms + w.n_sms + off;
@@ -1125,26 +1207,24 @@ DV void ring_put(WCtx &w, uint32_t idx, uint32_t t_pos, uint32_t q_pos, uint32_t
 {
 	uint4 r; r.x = t_pos; r.y = q_pos; r.z = len; r.w = score;
 	w.ring[idx & (DSB_RING - 1)] = r;
-	uint32_t b = idx >> 6;
-	if ((idx & 63u) == 0) { w.blk_max[b] = (int)score; w.blk_tmin[b] = t_pos; w.blk_tmax[b] = t_pos; }
-	else {
-		if ((int)score > w.blk_max[b]) w.blk_max[b] = (int)score;
-		if (t_pos < w.blk_tmin[b]) w.blk_tmin[b] = t_pos;
-		if (t_pos > w.blk_tmax[b]) w.blk_tmax[b] = t_pos;
-	}
 }
 // the nodes sdp_match appended are consumed one by one: fetch them 64 at a time (one per lane) and hand
 // node idx to every lane with shuffles
 struct NodeBlock { uint32_t base, valid; DsbSms mine; };
 DV DsbSms node_get(WCtx &w, NodeBlock &b, uint32_t idx)
 {
+#if DSB_GROUP == 64 && !defined(DSB_HOST_EMU)
 	if (idx < b.base || idx >= b.base + b.valid) {
-		b.base = idx; b.valid = MINV((uint32_t)DSB_WAVE, w.n_sms - idx);
+		b.base = idx; b.valid = MINV((uint32_t)64, w.n_sms - idx);
 		if ((uint32_t)w.lane < b.valid) b.mine = w.sms[idx + w.lane];
 	}
 	DsbSms r; int src = (int)(idx - b.base);
 	r.t_pos = dsb_shfl(b.mine.t_pos, src); r.q_pos = dsb_shfl(b.mine.q_pos, src); r.len = dsb_shfl(b.mine.len, src); r.score = 0;
 	return r;
+#else
+	DsbSms r = w.sms[idx]; r.score = 0;
+	return r;
+#endif
 }
 
 // best predecessor score of a new node among nodes [0, cur): the sparse-DP inner loops of
@@ -1158,6 +1238,7 @@ DV int sdp_best_pred(WCtx &w, const DsbSms &cs, int32_t cur)
 	if (MODE == 2) { lim_q = cs.q_pos + cs.len - 6 + 9 - 1; lim_t = cs.t_pos + cs.len - 6 + 9 - 1; }
 	else { lim_q = cs.q_pos + 6; lim_t = cs.t_pos + 6; }
 	for (int32_t hi = cur - 1; hi >= 0; hi -= DSB_DP_UNROLL * DSB_WAVE) {
+		w.dp_preds += DSB_DP_UNROLL * DSB_WAVE;
 		// DSB_DP_UNROLL groups of predecessors are loaded at once (independent loads in flight), then
 		// judged newest group first so that the distance cut stops at the same node as the reference
 		DsbSms pv[DSB_DP_UNROLL];
@@ -1200,14 +1281,13 @@ DV int sdp_best_pred(WCtx &w, const DsbSms &cs, int32_t cur)
 				}
 			}
 			// the reference stops at the first predecessor (newest first) that meets the distance cut
-			uint64_t bm = (MODE == 0) ? 0ULL : dsb_ballot(valid && brk);
-			int first_brk = bm ? __builtin_ctzll(bm) : DSB_WAVE;
+			int first_brk = (MODE == 0) ? DSB_WAVE : grp_first(w.red, w.lane, valid && brk);
 			if (valid && !skip && !brk && w.lane < first_brk) best = MAXV(best, ns);
-			if (bm) stop = true;
+			if (first_brk < DSB_WAVE) stop = true;
 		}
 		if (stop) break;
 	}
-	return wave_max_i(best);
+	return grp_max_i(w.red, w.lane, best);
 }
 
 
@@ -1282,6 +1362,8 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 	int last_search = false;
 	while (1) {
 		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
+		if (DSB_HEAVY_ABORT && w.dp_preds > DSB_HEAVY_PREDS) { w.status |= DSB_ST_HEAVY; break; }
+		DSB_BOOST_IF_HEAVY(w);
 		if (w.n_sms == current_sms) {
 			uint32_t next_step = t_length - c_t_offset;
 			if (next_step < 12) break;
@@ -1358,6 +1440,8 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 	int last_search = false;
 	while (1) {
 		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
+		if (DSB_HEAVY_ABORT && w.dp_preds > DSB_HEAVY_PREDS) { w.status |= DSB_ST_HEAVY; break; }
+		DSB_BOOST_IF_HEAVY(w);
 		if (w.n_sms == current_sms) {
 			uint32_t next_step = c_t_offset;
 			if (next_step < 12) break;
@@ -1423,6 +1507,7 @@ DN void get_score_M2(WCtx &w, SDir *sd, uint32_t l_read, DsbScHash *sc_hash)
 	DsbChain *H = w.hit;
 	for (uint32_t i = 0; i < w.n_hit; i++) {
 		if (H[i].sum_score == 0) continue;
+		if (w.status & DSB_ST_HEAVY) return;
 		SDir *csd = ((sd->direction == H[i].direction) ? 0 : 1) + sd;
 		int tbl = (H[i].direction == D_FORWARD) ? 0 : 1;
 		MARK(w, 52);
@@ -1532,7 +1617,7 @@ DN void detect_primary(WCtx &w, uint32_t read_len)
 DN uint32_t classify_read(WCtx &w, const uint64_t *bitsF, const uint64_t *bitsR)
 {
 	uint32_t read_len = w.L;
-	w.n_anc = 0; w.n_hit = 0; w.n_sms = 0; w.steps = 0;
+	w.n_anc = 0; w.n_hit = 0; w.n_sms = 0; w.steps = 0; w.lsteps = 0; w.dp_preds = 0; w.boosted = 0;
 	uint32_t fast = 1;
 	if (read_len < 40) return fast;
 	SDir *sd = w.sd;
@@ -1571,9 +1656,12 @@ DN uint32_t classify_read(WCtx &w, const uint64_t *bitsF, const uint64_t *bitsR)
 	w.stage = 5; MARK(w, 5);
 	delete_small_score_rst(w, sd, read_len);
 	TICK(w, 8);
+	if (w.status & DSB_ST_HEAVY) return fast;
 	w.stage = 6; MARK(w, 6);
 	detect_primary(w, read_len);
 	w.stage = 7; MARK(w, 7);
 	TICK(w, 9);
 	return fast;
 }
+
+} // namespace DSB_NS

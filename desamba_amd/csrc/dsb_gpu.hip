@@ -16,7 +16,12 @@
 #include <unistd.h>
 #include "dsb_device.h"
 #include "dsb_probe.h"
+// the per-read device code, instantiated for one wavefront per read
+#define DSB_GROUP 64
+#define DSB_NS dsb_g64
 #include "dsb_classify_dev.h"
+#undef DSB_GROUP
+#undef DSB_NS
 #include "dsb_host.h"
 
 #define HIPCHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "[desamba_amd] HIP error %s at %s:%d\n", hipGetErrorString(_e), __FILE__, __LINE__); return DSB_ENODEV; } } while (0)
@@ -101,75 +106,140 @@ __global__ void __launch_bounds__(256) k_seed_probe(DsbDevIndex x, const DsbRead
 	}
 }
 
+
+// ---- work order: longest-processing-time-first -----------------------------------------------------
+// The batch ends when its slowest read ends, and the slow reads are the ones whose sparse DP explodes:
+// tandem-repeat-like reads, where every reference 9-mer matches many read positions.  k_repeat_score
+// estimates that cheaply -- the number of 12-mers of the forward strand that already occurred in the read,
+// via a 2-hash Bloom filter of 2^19 bits in LDS -- and k_order sorts the reads into 32 log2 buckets,
+// heaviest first.  Only the order of processing changes, never a result.
+__global__ void __launch_bounds__(256) k_repeat_score(const DsbReadDesc *rd, const uint64_t *pk, uint32_t *score)
+{
+	__shared__ uint32_t bloom[1u << 14];
+	__shared__ uint32_t dup;
+	DsbReadDesc d = rd[blockIdx.x];
+	for (uint32_t i = threadIdx.x; i < (1u << 14); i += 256) bloom[i] = 0;
+	if (threadIdx.x == 0) dup = 0;
+	__syncthreads();
+	const uint64_t *P = pk + d.pk_off;
+	uint32_t n = d.len >= 12 ? d.len - 12 + 1 : 0, mine = 0;
+	for (uint32_t p = threadIdx.x; p < n; p += 256) {
+		uint32_t w0 = p >> 5, sh = (p & 31) * 2;
+		uint64_t a = P[w0], b = P[w0 + 1];
+		uint64_t hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
+		uint64_t kmer = hi >> 40;                                  // 12 bases
+		uint32_t h1 = (uint32_t)(dsb_ph1(kmer) >> 20) & 0x7ffffu, h2 = (uint32_t)(dsb_ph2(kmer) >> 13) & 0x7ffffu;
+		uint32_t o1 = atomicOr(&bloom[h1 >> 5], 1u << (h1 & 31)), o2 = atomicOr(&bloom[h2 >> 5], 1u << (h2 & 31));
+		if ((o1 >> (h1 & 31)) & (o2 >> (h2 & 31)) & 1u) mine++;
+	}
+	if (mine) atomicAdd(&dup, mine);
+	__syncthreads();
+	if (threadIdx.x == 0) score[blockIdx.x] = dup;
+}
+__global__ void __launch_bounds__(1024) k_order(const uint32_t *score, uint32_t n, uint32_t *order)
+{
+	__shared__ uint32_t hist[32], start[32];
+	if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < n; i += 1024) { uint32_t b = 31u - (uint32_t)__clz((int)(score[i] | 1u)); atomicAdd(&hist[b], 1u); }
+	__syncthreads();
+	if (threadIdx.x == 0) { uint32_t acc = 0; for (int b = 31; b >= 0; b--) { start[b] = acc; acc += hist[b]; } }
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < n; i += 1024) { uint32_t b = 31u - (uint32_t)__clz((int)(score[i] | 1u)); order[atomicAdd(&start[b], 1u)] = i; }
+}
+
 // ---- classify kernel: persistent waves, one read each ------------------------------------------
 struct DsbSlotArena {
 	uint8_t *base; size_t stride;                 // per-slot bytes
 	size_t off_seeds, off_anc, off_anc_tmp, off_hit, off_hit_tmp, off_sms, off_kh, off_sc, off_mem, off_spset, off_scorev,
-	       off_sortkey, off_sortidx, off_win, off_lane_anc, off_lane_sp, off_top;
+	       off_sortkey, off_sortidx, off_win, off_lane_anc, off_lane_sp, off_top, off_round;
 	uint32_t max_len;                             // longest read the arena was sized for
 };
 
-__global__ void __launch_bounds__(64) k_classify(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_reads, uint8_t *bin, const uint64_t *bits,
-                                                 DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout, DsbHitOut *hout,
-                                                 unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg)
-{
-	const int lane = threadIdx.x;
-	uint8_t *slot = ar.base + (size_t)blockIdx.x * ar.stride;
-	// The index descriptor is read on every rank query: keep it in LDS.  (A pointer to the kernel-argument
-	// segment would turn each x->field into a vector load from host-coherent memory.)
-	__shared__ DsbDevIndex sx;
-	__shared__ uint4 lds_ring[DSB_RING];
-	__shared__ int lds_bmax[DSB_SMS_CAP / 64 + 1]; __shared__ uint32_t lds_btmin[DSB_SMS_CAP / 64 + 1], lds_btmax[DSB_SMS_CAP / 64 + 1];
-	__shared__ DsbScHash lds_sc[256 + 2 * 400 + 64];
-	if (lane == 0) sx = x;
-	__syncthreads();
-	WCtx w;
-	w.ring = lds_ring; w.blk_max = lds_bmax; w.blk_tmin = lds_btmin; w.blk_tmax = lds_btmax;
-	w.x = &sx; w.lane = lane; w.dbg = dbg ? dbg + 4 * blockIdx.x : nullptr;
-	for (int i = 0; i < 14; i++) w.tacc[i] = 0;
-	w.seeds = (DsbSeed *)(slot + ar.off_seeds);
-	w.anc = (DsbAnchor *)(slot + ar.off_anc); w.anc_tmp = (DsbAnchor *)(slot + ar.off_anc_tmp);
-	w.hit = (DsbChain *)(slot + ar.off_hit); w.hit_tmp = (DsbChain *)(slot + ar.off_hit_tmp);
-	w.sms = (DsbSms *)(slot + ar.off_sms);
-	uint32_t *kh = (uint32_t *)(slot + ar.off_kh);
-	size_t kh_strand = (size_t)(1u << 18) + 2 * (size_t)ar.max_len;
-	w.kh_head[0] = kh; w.kh_next[0] = kh + (1u << 18); w.kh_kmer[0] = w.kh_next[0] + ar.max_len;
-	w.kh_head[1] = kh + kh_strand; w.kh_next[1] = w.kh_head[1] + (1u << 18); w.kh_kmer[1] = w.kh_next[1] + ar.max_len;
-	w.sc = lds_sc;
-	w.mem_slow = (DsbMem *)(slot + ar.off_mem);
-	w.spset = (uint64_t *)(slot + ar.off_spset);
-	w.score_v = (int *)(slot + ar.off_scorev);
-	w.sortkey = (uint64_t *)(slot + ar.off_sortkey); w.sortidx = (uint32_t *)(slot + ar.off_sortidx);
-	w.win_mid = slot + ar.off_win; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
-	w.lane_anc = (DsbAnchor *)(slot + ar.off_lane_anc); w.lane_spset = (uint64_t *)(slot + ar.off_lane_sp); w.top_idx = (uint32_t *)(slot + ar.off_top);
-	w.anc_cap = DSB_ANC_CAP;
-	if (w.dbg && lane == 0) w.dbg[0] = 300;
-	for (;;) {
-		unsigned int r = 0;
-		if (lane == 0) r = atomicAdd(work_counter, 1u);
-		r = __shfl(r, 0);
-		if (r >= n_reads) { if (w.dbg && lane == 0) { w.dbg[0] = 999; for (int i = 0; i < 14; i++) dbg[4 * 65536 + 14 * blockIdx.x + i] = (uint32_t)(w.tacc[i] / 100); } break; }   // every wave reaches this: the grid always drains
-		DsbReadDesc d = rd[r];
-		uint64_t t_start = wall_clock64();
-		if (w.dbg && lane == 0) { w.dbg[2] = r; w.dbg[0] = 100; }
-		w.bin = bin + d.bin_off + DSB_QPAD_L; w.L = d.len; w.status = 0; w.max_read_l = d.hist_max;
-		uint32_t fast = classify_read(w, bits + d.bit_off, bits + d.bit_off + d.n_words);
-		// publish the hits of this read
-		unsigned int first = 0;
-		if (lane == 0 && w.n_hit) first = atomicAdd(hout_counter, w.n_hit);
-		first = __shfl(first, 0);
-		uint32_t n_out = w.n_hit;
-		if (first + n_out > hout_cap) { w.status |= DSB_ST_OUT_OVF; n_out = 0; }
-		for (uint32_t i = lane; i < n_out; i += 64) {
-			DsbChain h = w.hit[i]; DsbHitOut o;
-			o.ref_ID = h.ref_ID; o.t_st = h.t_st; o.t_ed = h.t_ed; o.q_st = h.q_st; o.q_ed = h.q_ed; o.sum_score = h.sum_score; o.indel = h.indel;
-			o.direction = h.direction; o.primary = h.primary; o.pri_index = h.pri_index; o.pad = 0;
-			hout[first + i] = o;
-		}
-		if (w.dbg && lane == 0) w.dbg[0] = 200;
-		if (lane == 0) { DsbReadOut ro; ro.first = first; ro.n = n_out; ro.status = w.status | (w.status ? (w.stage << 8) : 0); ro.fast = fast | ((uint32_t)((wall_clock64() - t_start) / 100) << 1); rout[r] = ro; }
-	}
+// One kernel body, two instantiations.  Work items come from an atomic counter; with `list` == nullptr
+// item k is read k (all reads), otherwise read list[k] (the reads the narrow kernel flagged as heavy).
+#ifndef DSB_WAVES_PER_EU
+#define DSB_WAVES_PER_EU 4
+#endif
+#define DSB_DEFINE_CLASSIFY(KNAME, NS, THREADS)                                                                         \
+__global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,   \
+        const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout,  \
+        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *heavy_list, unsigned int *heavy_counter, uint32_t *dbg) \
+{                                                                                                                       \
+	const int lane = threadIdx.x;                                                                                       \
+	uint8_t *slot = ar.base + (size_t)blockIdx.x * ar.stride;                                                           \
+	/* The index descriptor is read on every rank query: keep it in LDS.  (A pointer to the kernel-argument segment   \
+	   would turn each x->field into a vector load from host-coherent memory.) */                                       \
+	__shared__ DsbDevIndex sx;                                                                                          \
+	__shared__ uint4 lds_ring[DSB_RING];                                                                                \
+	__shared__ DsbScHash lds_sc[256 + 2 * 400 + 64];                                                                    \
+	__shared__ uint32_t lds_red[THREADS / 64 + 1];                                                                      \
+	__shared__ unsigned int s_word;                                                                                     \
+	if (lane == 0) sx = x;                                                                                              \
+	__syncthreads();                                                                                                    \
+	NS::WCtx w;                                                                                                         \
+	w.ring = lds_ring; w.red = lds_red;                                                                                 \
+	w.x = &sx; w.lane = lane; w.dbg = dbg ? dbg + 4 * blockIdx.x : nullptr;                                             \
+	for (int i = 0; i < 14; i++) w.tacc[i] = 0;                                                                         \
+	w.seeds = (DsbSeed *)(slot + ar.off_seeds);                                                                         \
+	w.anc = (DsbAnchor *)(slot + ar.off_anc); w.anc_tmp = (DsbAnchor *)(slot + ar.off_anc_tmp);                         \
+	w.hit = (DsbChain *)(slot + ar.off_hit); w.hit_tmp = (DsbChain *)(slot + ar.off_hit_tmp);                           \
+	w.sms = (DsbSms *)(slot + ar.off_sms);                                                                              \
+	uint32_t *kh = (uint32_t *)(slot + ar.off_kh);                                                                      \
+	size_t kh_strand = (size_t)(1u << 18) + 2 * (size_t)ar.max_len;                                                     \
+	w.kh_head[0] = kh; w.kh_next[0] = kh + (1u << 18); w.kh_kmer[0] = w.kh_next[0] + ar.max_len;                        \
+	w.kh_head[1] = kh + kh_strand; w.kh_next[1] = w.kh_head[1] + (1u << 18); w.kh_kmer[1] = w.kh_next[1] + ar.max_len;  \
+	w.sc = lds_sc;                                                                                                      \
+	w.mem_slow = (DsbMem *)(slot + ar.off_mem);                                                                         \
+	w.spset = (uint64_t *)(slot + ar.off_spset);                                                                        \
+	w.score_v = (int *)(slot + ar.off_scorev);                                                                          \
+	w.sortkey = (uint64_t *)(slot + ar.off_sortkey); w.sortidx = (uint32_t *)(slot + ar.off_sortidx);                   \
+	w.win_mid = slot + ar.off_win; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;         \
+	w.lane_anc = (DsbAnchor *)(slot + ar.off_lane_anc); w.lane_spset = (uint64_t *)(slot + ar.off_lane_sp);             \
+	w.top_idx = (uint32_t *)(slot + ar.off_top); w.round_info = (uint32_t *)(slot + ar.off_round);                      \
+	w.anc_cap = DSB_ANC_CAP;                                                                                            \
+	const unsigned int n_items = n_ptr ? *n_ptr : n_fixed;                                                              \
+	if (w.dbg && lane == 0) w.dbg[0] = 300;                                                                             \
+	for (;;) {                                                                                                          \
+		if (lane == 0) s_word = atomicAdd(work_counter, 1u);                                                            \
+		__syncthreads();                                                                                                \
+		unsigned int k = s_word;                                                                                        \
+		__syncthreads();                                                                                                \
+		if (k >= n_items) {   /* every group reaches this: the grid always drains */                                   \
+			if (w.dbg && lane == 0) { w.dbg[0] = 999; for (int i = 0; i < 14; i++) dbg[4 * 65536 + 14 * blockIdx.x + i] += (uint32_t)(w.tacc[i] / 100); } \
+			break;                                                                                                      \
+		}                                                                                                               \
+		unsigned int r = list ? list[k] : k;                                                                            \
+		DsbReadDesc d = rd[r];                                                                                          \
+		uint64_t t_start = wall_clock64();                                                                              \
+		if (w.dbg && lane == 0) { w.dbg[2] = r; w.dbg[0] = 100; }                                                       \
+		w.bin = bin + d.bin_off + DSB_QPAD_L; w.L = d.len; w.status = 0; w.max_read_l = d.hist_max;                     \
+		uint32_t fast = NS::classify_read(w, bits + d.bit_off, bits + d.bit_off + d.n_words);                           \
+		if (w.boosted) __builtin_amdgcn_s_setprio(0);                                                                   \
+		if (w.status & DSB_ST_HEAVY) {   /* narrow kernel only: queue the read for the wide kernel */                   \
+			if (lane == 0) { unsigned int q = atomicAdd(heavy_counter, 1u); heavy_list[q] = r; }                        \
+			continue;                                                                                                   \
+		}                                                                                                               \
+		/* publish the hits of this read */                                                                             \
+		if (lane == 0) s_word = w.n_hit ? atomicAdd(hout_counter, w.n_hit) : 0u;                                        \
+		__syncthreads();                                                                                                \
+		unsigned int first = s_word;                                                                                    \
+		__syncthreads();                                                                                                \
+		uint32_t n_out = w.n_hit;                                                                                       \
+		if (first + n_out > hout_cap) { w.status |= DSB_ST_OUT_OVF; n_out = 0; }                                        \
+		for (uint32_t i = lane; i < n_out; i += THREADS) {                                                              \
+			DsbChain h = w.hit[i]; DsbHitOut o;                                                                         \
+			o.ref_ID = h.ref_ID; o.t_st = h.t_st; o.t_ed = h.t_ed; o.q_st = h.q_st; o.q_ed = h.q_ed; o.sum_score = h.sum_score; o.indel = h.indel; \
+			o.direction = h.direction; o.primary = h.primary; o.pri_index = h.pri_index; o.pad = 0;                     \
+			hout[first + i] = o;                                                                                        \
+		}                                                                                                               \
+		if (w.dbg && lane == 0) w.dbg[0] = 200;                                                                         \
+		if (lane == 0) { DsbReadOut ro; ro.first = first; ro.n = n_out; ro.status = w.status | (w.status ? (w.stage << 8) : 0); \
+			ro.fast = fast | ((uint32_t)((wall_clock64() - t_start) / 100) << 1); rout[r] = ro; }                       \
+	}                                                                                                                   \
 }
+
+DSB_DEFINE_CLASSIFY(k_classify, dsb_g64, 64)
 
 // ================================== host side ====================================================
 struct dsb_ctx {
@@ -182,6 +252,8 @@ struct dsb_ctx {
 	DsbReadOut *d_rout; DsbHitOut *d_hout; size_t cap_rout, cap_hout;
 	unsigned int *d_counters;                      // [0] work, [1] hits; +8: u64 p1 counter
 	DsbSlotArena arena; size_t arena_bytes; int n_slots;
+	DsbSlotArena arena_wide; int n_wide_slots; uint32_t *d_heavy; size_t cap_heavy; unsigned int last_heavy;
+	uint32_t *d_score, *d_order; size_t cap_score, cap_order;
 	// host mirrors
 	std::vector<DsbReadDesc> h_rd; std::vector<DsbWordDesc> h_wd;
 	std::vector<DsbReadOut> h_rout; std::vector<DsbHitOut> h_hout;
@@ -254,7 +326,7 @@ extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 	hipSetDevice(c->device);
 	for (void *p : c->dev_allocs) hipFree(p);
 	hipFree(c->d_rd); hipFree(c->d_wd); hipFree(c->d_ascii); hipFree(c->d_bin); hipFree(c->d_pk); hipFree(c->d_bits);
-	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base);
+	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->arena_wide.base); hipFree(c->d_heavy); hipFree(c->d_score); hipFree(c->d_order);
 	for (int i = 0; i < 4; i++) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream);
 	delete c;
@@ -272,11 +344,11 @@ template <class T> static int grow(T **p, size_t *cap, size_t need)
 }
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-static int size_arena(dsb_ctx *c, uint32_t max_len, int n_slots)
+static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int n_slots, int group)
 {
-	if (c->arena.base && c->arena.max_len >= max_len && c->n_slots >= n_slots) return 0;
-	if (c->arena.base) { hipFree(c->arena.base); c->arena.base = nullptr; }
-	DsbSlotArena &a = c->arena; size_t o = 0;
+	if (a.base && a.max_len >= max_len && *cur_slots >= n_slots) return 0;
+	if (a.base) { hipFree(a.base); a.base = nullptr; }
+	size_t o = 0;
 	a.max_len = max_len;
 	a.off_seeds = o;   o += al256(((size_t)(max_len >> 1) + 64) * sizeof(DsbSeed));
 	a.off_anc = o;     o += al256((size_t)DSB_ANC_CAP * sizeof(DsbAnchor));
@@ -292,13 +364,13 @@ static int size_arena(dsb_ctx *c, uint32_t max_len, int n_slots)
 	a.off_sortkey = o; o += al256((size_t)2 * DSB_ANC_CAP * sizeof(uint64_t));
 	a.off_sortidx = o; o += al256((size_t)2 * DSB_ANC_CAP * sizeof(uint32_t));
 	a.off_win = o;     o += al256((size_t)3 * DSB_REFWIN);
-	a.off_lane_anc = o; o += al256((size_t)64 * DSB_LANE_ANC_CAP * sizeof(DsbAnchor));
-	a.off_lane_sp = o;  o += al256((size_t)64 * 512 * 8);
+	a.off_lane_anc = o; o += al256((size_t)group * DSB_LANE_ANC_CAP * sizeof(DsbAnchor));
+	a.off_lane_sp = o;  o += al256((size_t)group * 512 * 8);
 	a.off_top = o;      o += al256(((size_t)(max_len >> 1) + 64) * 4);
+	a.off_round = o;    o += al256((size_t)group * 4);
 	a.stride = al256(o);
-	c->n_slots = n_slots;
-	c->arena_bytes = a.stride * (size_t)n_slots;
-	if (hipMalloc((void **)&a.base, c->arena_bytes) != hipSuccess) { a.base = nullptr; return DSB_ENOMEM; }
+	*cur_slots = n_slots;
+	if (hipMalloc((void **)&a.base, a.stride * (size_t)n_slots) != hipSuccess) { a.base = nullptr; return DSB_ENOMEM; }
 	return 0;
 }
 
@@ -334,7 +406,10 @@ extern "C" int dsb_batch_upload(dsb_ctx *c, const dsb_read *reads, size_t n)
 	// reads in flight: one wavefront each; default 8 waves per SIMD's worth, bounded by the batch
 	int want = c->opts.n_slots > 0 ? c->opts.n_slots : 256 * 4 * 4;
 	if ((size_t)want > n) want = (int)(n ? n : 1);
-	if ((rc = size_arena(c, max_len, want > c->n_slots ? want : c->n_slots))) return rc;
+	if ((rc = size_arena(c->arena, &c->n_slots, max_len, want > c->n_slots ? want : c->n_slots, 64))) return rc;
+	if ((rc = grow(&c->d_heavy, &c->cap_heavy, n + 1))) return rc;
+	if ((rc = grow(&c->d_score, &c->cap_score, n + 1))) return rc;
+	if ((rc = grow(&c->d_order, &c->cap_order, n + 1))) return rc;
 	if (n) {
 		HIPCHK(hipMemcpyAsync(c->d_rd, c->h_rd.data(), n * sizeof(DsbReadDesc), hipMemcpyHostToDevice, c->stream));
 		if (!c->h_wd.empty()) HIPCHK(hipMemcpyAsync(c->d_wd, c->h_wd.data(), c->h_wd.size() * sizeof(DsbWordDesc), hipMemcpyHostToDevice, c->stream));
@@ -371,8 +446,14 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	if (dbg) { HIPCHK(hipStreamSynchronize(c->stream)); fprintf(stderr, "[dsb] seed probe done\n"); }
 	{
 		unsigned slots = (unsigned)c->n_slots; if (slots > n) slots = (unsigned)n;
-		hipLaunchKernelGGL(k_classify, dim3(slots), dim3(64), 0, c->stream, c->dx, c->d_rd, (uint32_t)n, c->d_bin, c->d_bits, c->arena,
-		                   c->d_counters, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, dbg ? c->dbg_dev : nullptr);
+		uint32_t *dbgp = dbg ? c->dbg_dev : nullptr;
+		if (dbg) memset(c->dbg_host, 0, 16 * 65536 * sizeof(uint32_t));
+		// counters: [0] work, [1] hits, [2..3] u64 table-1 probes, [4] heavy reads, [5] work of the wide kernel
+		hipLaunchKernelGGL(k_repeat_score, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_rd, c->d_pk, c->d_score);
+		hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, c->stream, c->d_score, (uint32_t)n, c->d_order);
+		hipLaunchKernelGGL(k_classify, dim3(slots), dim3(64), 0, c->stream, c->dx, c->d_rd, (uint32_t)n, (const unsigned int *)nullptr, (const uint32_t *)c->d_order,
+		                   c->d_bin, c->d_bits, c->arena, c->d_counters, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout,
+		                   c->d_heavy, c->d_counters + 4, dbgp);
 		if (dbg) {
 			// watchdog: poll the stream; dump the progress words of every slot if the kernel runs long
 			for (int sec = 0; sec < 60; sec++) {
@@ -403,6 +484,8 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	hipEventElapsedTime(&c->timing.classify_ms, c->ev[2], c->ev[3]);
 	hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[3]);
 	HIPCHK(hipMemcpy(&c->p1, c->d_counters + 2, 8, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(&c->last_heavy, c->d_counters + 4, 4, hipMemcpyDeviceToHost));
+	if (dbg) fprintf(stderr, "[dsb] heavy reads handed to the wide kernel: %u\n", c->last_heavy);
 	c->timing.windows = c->total_windows; c->timing.probes_t1 = c->p1; c->timing.bases = c->total_bases;
 	return DSB_OK;
 }
@@ -470,11 +553,11 @@ __global__ void __launch_bounds__(64) k_seed_dump(DsbDevIndex x, DsbReadDesc d, 
 	__shared__ DsbDevIndex sx;
 	if (threadIdx.x == 0) sx = x;
 	__syncthreads();
-	WCtx w; w.x = &sx; w.lane = threadIdx.x; w.L = d.len; w.status = 0; w.dbg = nullptr; w.anc_cap = 0;
-	SDir sd;
+	dsb_g64::WCtx w; w.x = &sx; w.lane = threadIdx.x; w.L = d.len; w.status = 0; w.dbg = nullptr; w.anc_cap = 0;
+	dsb_g64::SDir sd;
 	uint32_t n = d.len - x.ek_len + 1;
-	if (strand) seed_vector(w, bin + d.bin_off + DSB_QPAD_L, bits + d.bit_off, n, out, D_FORWARD, &sd);
-	else seed_vector(w, bin + d.bin_off + DSB_QPAD_L + d.len, bits + d.bit_off + d.n_words, n, out, D_REVERSE, &sd);
+	if (strand) dsb_g64::seed_vector(w, bin + d.bin_off + DSB_QPAD_L, bits + d.bit_off, n, out, D_FORWARD, &sd);
+	else dsb_g64::seed_vector(w, bin + d.bin_off + DSB_QPAD_L + d.len, bits + d.bit_off + d.n_words, n, out, D_REVERSE, &sd);
 	if (threadIdx.x == 0) { n_out[0] = sd.l_seed_v; n_out[1] = sd.total_score; }
 }
 extern "C" int dsb_batch_seeds(dsb_ctx *c, size_t read, int strand, dsb_seed *out, size_t cap, uint32_t *n, uint32_t *total_score)

@@ -9,6 +9,7 @@
 #include "dsb_probe.h"
 #include "dsb_classify_dev.h"
 #include "dsb_host.h"
+using namespace dsb_g64;
 
 struct EmuCtx {
 	DsbDevIndex dx; std::vector<uint8_t> arena; uint32_t max_len; WCtx w;
@@ -62,8 +63,7 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	w.sortkey = (uint64_t *)(s + off[11]); w.sortidx = (uint32_t *)(s + off[12]);
 	w.win_mid = s + off[13]; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
 	static uint4 emu_ring[DSB_RING]; w.ring = emu_ring;
-	static int emu_bmax[DSB_SMS_CAP / 64 + 1]; static uint32_t emu_btmin[DSB_SMS_CAP / 64 + 1], emu_btmax[DSB_SMS_CAP / 64 + 1];
-	w.blk_max = emu_bmax; w.blk_tmin = emu_btmin; w.blk_tmax = emu_btmax;
+	static uint32_t emu_red[4], emu_round[4]; w.red = emu_red; w.round_info = emu_round;
 	w.lane_anc = (DsbAnchor *)(s + off[14]); w.lane_spset = (uint64_t *)(s + off[15]); w.top_idx = (uint32_t *)(s + off[16]); w.anc_cap = DSB_ANC_CAP;
 }
 

@@ -29,6 +29,12 @@ def main():
         run([sim, idx, fq, str(n), str(L), str(e), str(seed), prof])
         run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx, fq, "-o", os.path.join(OUT, name + ".ubfree.sam")])
         run([os.path.join(REF, "deSAMBA"), "classify", "-t", "1", idx, fq, "-o", os.path.join(OUT, name + ".stock.sam")])
+    # the two heaviest reads of the 2000-read ONT set (tools/readsim seed 1, reads 1476 and 9): a tandem-repeat
+    # region where one reference 9-mer matches dozens of read positions -> thousands of sparse-DP nodes
+    heavy = os.path.join(OUT, "heavy.fq")
+    if os.path.exists(heavy):
+        run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx, heavy, "-o", os.path.join(OUT, "heavy.ubfree.sam")])
+        run([os.path.join(REF, "deSAMBA"), "classify", "-t", "1", idx, heavy, "-o", os.path.join(OUT, "heavy.stock.sam")])
     # the smallest reproducer of the stock reference's history dependence
     appc = os.path.join(OUT, "appc.fq")
     with open(appc, "w") as f:

@@ -43,7 +43,7 @@ def test_demo_sam_md5(gpu, demo, golden_md5):
     assert hashlib.md5(sam).hexdigest() == golden_md5
 
 
-@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc"])
+@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy"])
 def test_synthetic_golden_sam(gpu, name):
     D, idx, ctx = gpu
     hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))
@@ -127,3 +127,29 @@ def test_cli_drop_in(gpu, demo, golden_md5, tmp_path):
     assert p.returncode == 0, p.stderr
     assert b"1237 sequences processed in" in p.stderr and b"loading index" in p.stderr
     assert hashlib.md5(open(out, "rb").read()).hexdigest() == golden_md5
+
+
+def test_full_size_batch_properties(gpu, demo, oracle, tmp_path):
+    """BASELINE-size reads (50 kbp) in a batch large enough to exercise the work queue, the work ordering and
+    many waves per CU: (1) a shuffled copy of the batch gives the same per-read hits (order independence),
+    (2) two different batch splits give identical SAM (checksum of checksums), (3) a sample is checked hit by
+    hit against the oracle, (4) every read of this error profile is classified to its source reference."""
+    import hashlib, random, subprocess
+    D, idx, ctx = gpu
+    fq = tmp_path / "full.fq"
+    subprocess.check_call([os.path.join(ROOT, "tools", "readsim"), demo["index"], str(fq), "1536", "50000", "0.15", "31337", "ont"])
+    recs = D.read_fastq(str(fq))
+    whole, sam_whole = classify_all(D, ctx, recs)
+    split, sam_split = classify_all(D, ctx, recs, chunk=500)
+    assert hashlib.md5(sam_whole).hexdigest() == hashlib.md5(sam_split).hexdigest()
+    perm = list(range(len(recs))); random.Random(7).shuffle(perm)
+    shuf, _ = classify_all(D, ctx, [recs[i] for i in perm])
+    for k, i in enumerate(perm):
+        assert shuf[k] == whole[i]
+    for i in random.Random(11).sample(range(len(recs)), 48):
+        assert whole[i] == oracle.classify(recs[i][1], 50000), recs[i][0]
+    mapped = sum(1 for h in whole if h)
+    assert mapped == len(recs)
+    # read names carry the truth (r{i}_{refIndex}_{start}_{F|R}): the primary hit is on the source reference
+    ok = sum(1 for (nm, s, q), h in zip(recs, whole) if h and h[0][0] == int(nm.split(b"_")[1]))
+    assert ok >= 0.99 * len(recs)
