@@ -1291,6 +1291,116 @@ DV int sdp_best_pred(WCtx &w, const DsbSms &cs, int32_t cur)
 }
 
 
+// ---- batched sparse DP for the right/left extensions ---------------------------------------------------
+// In repeat-rich windows every new node scans thousands of predecessors, and consecutive nodes scan almost
+// the same ones.  DSB_DPB consecutive new nodes are therefore scored together: one pass over the OLD
+// predecessors (index < first node of the batch) serves all of them (each loaded chunk is judged against every
+// node of the batch, each with its own distance cut), then each node adds the few predecessors INSIDE the batch
+// once their scores are final.  The reference scans newest first and stops at the first predecessor that
+// meets the distance cut; in-batch predecessors are newer than all old ones, so a cut found among them
+// discards the old-pass result for that node.  Same maxima, 1/DSB_DPB of the memory traffic.
+#define DSB_DPB 8
+struct DpBatch { uint32_t n0, K; int old_best[DSB_DPB]; DsbSms nd[DSB_DPB]; };
+
+template <int MODE>
+DV void sdp_limits(const DsbSms &cs, uint32_t &lim_q, uint32_t &lim_t)
+{
+	if (MODE == 2) { lim_q = cs.q_pos + cs.len - 6 + 9 - 1; lim_t = cs.t_pos + cs.len - 6 + 9 - 1; }
+	else { lim_q = cs.q_pos + 6; lim_t = cs.t_pos + 6; }
+}
+// judge one predecessor of a right (MODE 1) / left (MODE 2) extension node, conditions in the reference's order
+template <int MODE>
+DV void sdp_judge(const DsbSms &cs, const DsbSms &ps, uint32_t lim_q, uint32_t lim_t, bool &skip, bool &brk, int &ns)
+{
+	brk = false; ns = 0;
+	if (MODE == 2) {
+		skip = (ps.q_pos < lim_q) || (ps.t_pos < lim_t);
+		if (!skip) brk = (lim_t + 600 < ps.t_pos);
+		if (!skip && !brk) {
+			int indel = ps.q_pos - ps.t_pos - (lim_q - lim_t); int ai = ABSV(indel);
+			if (ai > 200) skip = true;
+			else {
+				ns = ps.score + cs.len - (ai >> 3);
+				if (lim_q + 6 > ps.q_pos || lim_t + 6 > ps.t_pos) { int oq = lim_q + 6 - ps.q_pos, ot = lim_t + 6 - ps.t_pos; ns -= MAXV(oq, ot); }
+			}
+		}
+	} else {
+		int pre_q_ed = ps.q_pos + ps.len + 9 - 1, pre_t_ed = ps.t_pos + ps.len + 9 - 1;
+		skip = ((uint32_t)pre_q_ed > lim_q) || ((uint32_t)pre_t_ed > lim_t);
+		if (!skip) brk = (ps.t_pos + 600 < lim_t);
+		if (!skip && !brk) {
+			int indel = ps.q_pos - ps.t_pos - (lim_q - lim_t); int ai = ABSV(indel);
+			if (ai > 200) skip = true;
+			else {
+				ns = ps.score + cs.len - (ai >> 3);
+				if ((uint32_t)pre_q_ed > cs.q_pos || (uint32_t)pre_t_ed > cs.t_pos) { int oq = pre_q_ed - cs.q_pos, ot = pre_t_ed - cs.t_pos; ns -= MAXV(oq, ot); }
+			}
+		}
+	}
+}
+
+template <int MODE>
+DN void sdp_batch_old(WCtx &w, DpBatch &b)
+{
+	uint32_t lq[DSB_DPB], lt[DSB_DPB]; int best[DSB_DPB]; bool stop[DSB_DPB];
+#pragma unroll
+	for (int j = 0; j < DSB_DPB; j++) { sdp_limits<MODE>(b.nd[j], lq[j], lt[j]); best[j] = -2147483647 - 1; stop[j] = (uint32_t)j >= b.K; }
+	const int32_t n0 = (int32_t)b.n0;
+	for (int32_t hi = n0 - 1; hi >= 0; hi -= DSB_DP_UNROLL * DSB_WAVE) {
+		DsbSms pv[DSB_DP_UNROLL];
+#pragma unroll
+		for (int u = 0; u < DSB_DP_UNROLL; u++) {
+			int32_t pi = hi - u * DSB_WAVE - w.lane;
+			if (pi < 0) { pv[u].t_pos = pv[u].q_pos = pv[u].len = pv[u].score = 0; }
+			else if (pi > n0 - DSB_RING) { uint4 r = w.ring[pi & (DSB_RING - 1)]; pv[u].t_pos = r.x; pv[u].q_pos = r.y; pv[u].len = r.z; pv[u].score = r.w; }
+			else pv[u] = w.sms[pi];
+		}
+		bool all_stop = true;
+#pragma unroll
+		for (int j = 0; j < DSB_DPB; j++) {
+			if (stop[j]) continue;
+			w.dp_preds += DSB_DP_UNROLL * DSB_WAVE;
+#pragma unroll
+			for (int u = 0; u < DSB_DP_UNROLL; u++) {
+				if (stop[j]) break;
+				int32_t pi = hi - u * DSB_WAVE - w.lane; bool valid = pi >= 0;
+				bool skip, brk; int ns;
+				sdp_judge<MODE>(b.nd[j], pv[u], lq[j], lt[j], skip, brk, ns);
+				int first_brk = grp_first(w.red, w.lane, valid && brk);
+				if (valid && !skip && !brk && w.lane < first_brk && ns > best[j]) best[j] = ns;
+				if (first_brk < DSB_WAVE) stop[j] = true;
+			}
+			if (!stop[j]) all_stop = false;
+		}
+		if (all_stop) break;
+	}
+#pragma unroll
+	for (int j = 0; j < DSB_DPB; j++) b.old_best[j] = ((uint32_t)j < b.K) ? grp_max_i(w.red, w.lane, best[j]) : 0;
+}
+
+// best predecessor score of node `cur` (right/left extension), through the batch
+template <int MODE>
+DV int sdp_best_pred_b(WCtx &w, DpBatch &b, const DsbSms &cs, int32_t cur)
+{
+	if ((uint32_t)cur < b.n0 || (uint32_t)cur >= b.n0 + b.K) {
+		b.n0 = (uint32_t)cur; b.K = MINV((uint32_t)DSB_DPB, w.n_sms - (uint32_t)cur);
+		for (uint32_t j = 0; j < b.K; j++) { b.nd[j] = w.sms[cur + j]; b.nd[j].score = 0; }
+		sdp_batch_old<MODE>(w, b);
+	}
+	int best = (int)cs.len; bool cut = false;
+	uint32_t lim_q, lim_t; sdp_limits<MODE>(cs, lim_q, lim_t);
+	for (int32_t pi = cur - 1; pi >= (int32_t)b.n0; pi--) {      // in-batch predecessors, newest first
+		uint4 r = w.ring[pi & (DSB_RING - 1)]; DsbSms ps; ps.t_pos = r.x; ps.q_pos = r.y; ps.len = r.z; ps.score = r.w;
+		bool skip, brk; int ns;
+		sdp_judge<MODE>(cs, ps, lim_q, lim_t, skip, brk, ns);
+		if (!skip && brk) { cut = true; break; }
+		if (!skip && ns > best) best = ns;
+	}
+	int ob = b.old_best[cur - (int32_t)b.n0];
+	if (!cut && ob > best) best = ob;
+	return best;
+}
+
 DV void fill_window(const WCtx &w, uint8_t *win, int n)
 {
 	for (int i = w.lane; i < n; i += DSB_WAVE) win[i] = DSB_TPAD_VAL;
@@ -1356,6 +1466,7 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 	ring_put(w, 0, p->t_pos, p->q_pos, p->len, p->score);
 	uint32_t best_t = c_h->t_ed, best_q = c_h->q_ed, best_len = (uint32_t)(1 - 9);     // fields of node max_sms_id
 	NodeBlock nb; nb.base = 0; nb.valid = 0;
+	DpBatch db; db.n0 = 0; db.K = 0;
 	uint32_t current_sms = 1;
 	uint64_t t_offset_global = x->refinfo[c_h->ref_ID].seq_offset, t_length = x->refinfo[c_h->ref_ID].seq_l;
 	uint32_t c_t_offset = c_h->t_ed - 3;
@@ -1390,7 +1501,7 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 		DsbSms *c_sms = w.sms + current_sms;
 		DsbSms cs = node_get(w, nb, current_sms); current_sms++;
 		SUB0(w);
-		int max_score = sdp_best_pred<1>(w, cs, (int32_t)current_sms - 1);
+		int max_score = sdp_best_pred_b<1>(w, db, cs, (int32_t)current_sms - 1);
 		SUB1(w, 11);
 		c_sms->score = max_score;
 		ring_put(w, current_sms - 1, cs.t_pos, cs.q_pos, cs.len, (uint32_t)max_score);
@@ -1405,7 +1516,7 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 			p = push_sms(w);
 			p->score = total_max_score; p->q_pos = c_h->q_ed; p->t_pos = c_h->t_ed; p->len = -9;
 			ring_put(w, 0, p->t_pos, p->q_pos, p->len, p->score);
-			best_t = c_h->t_ed; best_q = c_h->q_ed; best_len = (uint32_t)(-9); nb.valid = 0;
+			best_t = c_h->t_ed; best_q = c_h->q_ed; best_len = (uint32_t)(-9); nb.valid = 0; db.K = 0;
 			current_sms = 1;
 			c_t_offset = c_h->t_ed;
 			continue;
@@ -1434,6 +1545,7 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 	ring_put(w, 0, p->t_pos, p->q_pos, 0, p->score);                       // a[0].len is never read by the left DP
 	uint32_t best_t = c_h->t_st, best_q = c_h->q_st;                       // fields of node max_sms_id
 	NodeBlock nb; nb.base = 0; nb.valid = 0;
+	DpBatch db; db.n0 = 0; db.K = 0;
 	uint32_t current_sms = 1;
 	uint64_t t_offset_global = x->refinfo[c_h->ref_ID].seq_offset;
 	uint32_t c_t_offset = c_h->t_st + 3;
@@ -1471,7 +1583,7 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 		DsbSms *c_sms = w.sms + current_sms;
 		DsbSms cs = node_get(w, nb, current_sms); current_sms++;
 		SUB0(w);
-		int max_score = sdp_best_pred<2>(w, cs, (int32_t)current_sms - 1);
+		int max_score = sdp_best_pred_b<2>(w, db, cs, (int32_t)current_sms - 1);
 		SUB1(w, 11);
 		c_sms->score = max_score;
 		ring_put(w, current_sms - 1, cs.t_pos, cs.q_pos, cs.len, (uint32_t)max_score);
@@ -1483,7 +1595,7 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 			p = push_sms(w);
 			p->score = total_max_score; p->q_pos = c_h->q_st; p->t_pos = c_h->t_st;
 			ring_put(w, 0, p->t_pos, p->q_pos, 0, p->score);
-			best_t = c_h->t_st; best_q = c_h->q_st; nb.valid = 0;
+			best_t = c_h->t_st; best_q = c_h->q_st; nb.valid = 0; db.K = 0;
 			current_sms = 1;
 			c_t_offset = c_h->t_st;
 			continue;
