@@ -58,6 +58,9 @@
 #define SUB0(w) do { if ((w).dbg) (w).tsub = DSB_CLOCK(); } while (0)
 #define SUB1(w, k) do { if ((w).dbg) (w).tacc[k] += DSB_CLOCK() - (w).tsub; } while (0)
 #define MARK(w, code) do { if ((w).dbg && (w).lane == 0) { (w).dbg[0] = (code); (w).dbg[1] = (w).steps; } } while (0)
+#define DSB_WTAB_SLOTS 3072u     /* 12 KB of LDS: <= 2048 window positions, load factor <= 0.67 */
+#define DSB_WTAB_MAXQ 2048u
+#define DSB_WTAB_EMPTY 0xffffffffu
 // a read whose sparse DP scans more than this many predecessors is handed to the wide kernel
 #define DSB_HEAVY_PREDS 2500000u
 #endif
@@ -171,7 +174,7 @@ struct WCtx {
 	DsbAnchor *lane_anc; uint64_t *lane_spset; uint32_t *top_idx;   // per-lane scratch of the island-parallel fast_classify
 	DsbChain *hit, *hit_tmp; uint32_t n_hit;
 	DsbSms *sms; uint32_t n_sms;
-	uint32_t *kh_head[2], *kh_next[2], *kh_kmer[2];
+	uint32_t *wtab;            // LDS: DSB_WTAB_SLOTS-entry hash of the 9-mers of the current query window (sdp_match)
 	DsbScHash *sc;
 	DsbMem *mem_slow;
 	uint64_t *spset;
@@ -1002,48 +1005,36 @@ DV bool combine_chain(DsbChain *c_st, int chain_ID, DsbScHash *sc, int dis, bool
 	return false;
 }
 
-// ---- per-read 9-mer table (build_hash_table_M2, src/cly.c:2173-2224).
-// Same contents as the reference's chained hash -- for every key the read positions holding it -- in a
-// layout the wave builds in parallel: head[key] / next[pos] hold pos+1 (0 = end), kmer[pos] the 18-bit
-// 9-mer.  The reference's chains are in ascending position order and its output depends on that order;
-// here the chain order is whatever the atomics produced and sdp_visit() sorts what it collects.
-DN int build_hash_table_M2(WCtx &w, SDir *sd, int q_len)
+// ---- 9-mer lookup (build_hash_table_M2 + the chain walks of sdp_match, src/cly.c:2173-2224,2354-2388).
+// The reference hashes every 9-mer of the read once and filters each lookup by the query window
+// [q_bg, q_ed].  Every window is at most 2001 positions wide (600-bp extension steps look 2000 bases around
+// the best node; gaps between chained anchors are shorter), so the table is built per sdp_match call
+// for exactly that window, in LDS: open addressing, entry = kmer << 12 | (pos - q_bg).  A lookup collects
+// the entries of its 9-mer and visits them in ascending position = the reference's chain order.  No global
+// memory is touched besides the read bytes themselves.
+DV uint32_t wtab_slot(uint32_t kmer) { return (uint32_t)(((uint64_t)(kmer * 2654435761u) * DSB_WTAB_SLOTS) >> 32); }
+
+DN void wtab_build(WCtx &w, const uint8_t *q_str, uint32_t q_bg, uint32_t n_q)
 {
-	int both_dir = 0;
-	for (uint32_t i = 0; i < w.n_hit; i++) { both_dir |= (w.hit[i].direction == D_FORWARD) ? 0x2 : 0x1; if (both_dir == 3) break; }
-	int key_len = 10;
-	for (; key_len < 18; key_len++) if ((1u << key_len) >= (uint32_t)q_len) break;
-	uint32_t KEY_MASK = (1u << key_len) - 1u;
-	int n9 = q_len - 9 + 1;
-	for (int c_dir = 2; c_dir >= 1; c_dir--) {
-		if ((c_dir & both_dir) == 0) continue;
-		uint32_t direction = (c_dir == 1) ? D_REVERSE : D_FORWARD;
-		SDir *csd = ((sd->direction == direction) ? 0 : 1) + sd;
-		int t = (c_dir == 2) ? 0 : 1;
-		uint32_t *head = w.kh_head[t], *next = w.kh_next[t], *km = w.kh_kmer[t];
-		const uint8_t *q = csd->bin_read;
-		for (uint32_t i = w.lane; i < (1u << key_len); i += DSB_WAVE) head[i] = 0;
-		for (int pos = w.lane; pos < n9; pos += DSB_WAVE) {
-			uint32_t k = 0;
+	for (uint32_t i = w.lane; i < DSB_WTAB_SLOTS; i += DSB_WAVE) w.wtab[i] = DSB_WTAB_EMPTY;
+	wave_sync();
+	for (uint32_t r = w.lane; r < n_q; r += DSB_WAVE) {
+		const uint8_t *q = q_str + q_bg + r;
+		uint32_t k = 0;
 #pragma unroll
-			for (int b = 0; b < 9; b++) k = (k << 2) | q[pos + b];
-			km[pos] = k;
-		}
-		wave_sync();
-		// every position is pushed at the head of its key's chain with one atomic exchange: no ordering
-		// between lanes or groups is needed because lookups sort the few positions they collect
-		for (int pos = w.lane; pos < n9; pos += DSB_WAVE) {
-			uint32_t key = km[pos] & KEY_MASK;
+		for (int b = 0; b < 9; b++) k = (k << 2) | q[b];
+		uint32_t e = (k << 12) | r, sl = wtab_slot(k);
+		for (;;) {
 #ifdef DSB_HOST_EMU
-			uint32_t old = head[key]; head[key] = (uint32_t)pos + 1;
+			uint32_t old = w.wtab[sl]; if (old == DSB_WTAB_EMPTY) w.wtab[sl] = e;
 #else
-			uint32_t old = atomicExch(&head[key], (uint32_t)pos + 1);
+			uint32_t old = atomicCAS(&w.wtab[sl], DSB_WTAB_EMPTY, e);
 #endif
-			next[pos] = old;
+			if (old == DSB_WTAB_EMPTY) break;
+			sl = sl + 1 == DSB_WTAB_SLOTS ? 0 : sl + 1;
 		}
-		wave_sync();
 	}
-	return key_len;
+	wave_sync();
 }
 
 DV uint64_t ld_u64(const uint8_t *p)
@@ -1091,10 +1082,11 @@ DV uint64_t bin2kmer9(const uint8_t *s) { uint64_t v = 0;
 // the reference's order (i ascending, chain order within i): a first pass counts them per lane, an
 // exclusive wave scan gives each lane its slice of the node array, a second pass writes.
 #define DSB_SDP_CAND 64
+
 #define DSB_SDP_KEEP 3
 #define DSB_DP_UNROLL 4
-#define DSB_RING 256
-struct SdpArgs { uint32_t q_bg, q_ed; const uint8_t *q_str, *t_str; uint32_t t_len, t_st; const uint32_t *head, *nextv, *km; uint64_t KEY_MASK; };
+#define DSB_RING 16      /* recent DP nodes kept in LDS: the in-batch predecessors of the batched DP */
+struct SdpArgs { uint32_t q_bg, q_ed; const uint8_t *q_str, *t_str; uint32_t t_len, t_st; const uint32_t *tab; uint32_t n_q; };
 
 template <bool FWD, bool WRITE>
 DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out, uint32_t out_cap)
@@ -1112,33 +1104,32 @@ DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out, uint32_t ou
 		for (int j = 0; j < 9; j++) kmer |= (uint64_t)c_t[j] << (16 - 2 * j);
 		if (i > 4) kmer |= (uint64_t)(c_t[9] >> 2);
 	}
-	// collect the read positions of this 9-mer inside [q_bg, q_ed], then visit them in ascending order
-	// (= the reference's chain order)
+	// collect the window positions holding this 9-mer, then visit them in ascending order (= the reference's
+	// chain order).  A 9-mer with pad bits set (>= 2^18) matches nothing.
 	uint32_t cand[DSB_SDP_CAND]; int nc = 0; bool many = false;
-	const uint32_t head0 = a.head[kmer & a.KEY_MASK];
-	for (uint32_t next = head0; next != 0;) {
+	if (a.n_q == 0 || kmer >= (1ULL << 18)) return 0;
+	const uint32_t k32 = (uint32_t)kmer, sl0 = wtab_slot(k32);
+	for (uint32_t sl = sl0;;) {
 		if (LSPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
-		uint32_t q_pos = next - 1;
-		if (a.km[q_pos] == kmer && q_pos >= a.q_bg && q_pos <= a.q_ed) { if (nc < DSB_SDP_CAND) cand[nc++] = q_pos; else many = true; }
-		next = a.nextv[q_pos];
+		uint32_t e = a.tab[sl];
+		if (e == DSB_WTAB_EMPTY) break;
+		if ((e >> 12) == k32) { if (nc < DSB_SDP_CAND) cand[nc++] = a.q_bg + (e & 0xfffu); else many = true; }
+		sl = sl + 1 == DSB_WTAB_SLOTS ? 0 : sl + 1;
 	}
-	if (!many) {
-		// positions were pushed at the chain head roughly in ascending order, so the walk returns them
-		// roughly descending: reverse, then a (now nearly linear) insertion sort
-		for (int u = 0; u < nc / 2; u++) { uint32_t v = cand[u]; cand[u] = cand[nc - 1 - u]; cand[nc - 1 - u] = v; }
+	if (!many)
 		for (int u = 1; u < nc; u++) { uint32_t v = cand[u]; int z = u - 1; while (z >= 0 && cand[z] > v) { cand[z + 1] = cand[z]; z--; } cand[z + 1] = v; }
-	}
 	int64_t last = -1; int ci = 0;
 	for (;;) {
 		uint32_t q_pos;
 		if (!many) { if (ci >= nc) break; q_pos = cand[ci++]; }
-		else {	// long repeat: repeated selection of the next larger position
+		else {	// more than DSB_SDP_CAND positions: repeated selection of the next larger one
 			int64_t best = -1;
-			for (uint32_t next = head0; next != 0;) {
+			for (uint32_t sl = sl0;;) {
 				if (LSPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
-				uint32_t qp = next - 1;
-				if (a.km[qp] == kmer && qp >= a.q_bg && qp <= a.q_ed && (int64_t)qp > last && (best < 0 || (int64_t)qp < best)) best = qp;
-				next = a.nextv[qp];
+				uint32_t e = a.tab[sl];
+				if (e == DSB_WTAB_EMPTY) break;
+				if ((e >> 12) == k32) { int64_t qp = (int64_t)a.q_bg + (e & 0xfffu); if (qp > last && (best < 0 || qp < best)) best = qp; }
+				sl = sl + 1 == DSB_WTAB_SLOTS ? 0 : sl + 1;
 			}
 			if (best < 0) break;
 			q_pos = (uint32_t)best; last = best;
@@ -1198,8 +1189,15 @@ DN void sdp_match_t(WCtx &w, const SdpArgs &a)
 DN void sdp_match(WCtx &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len, int key_len,
                   int tbl, uint32_t t_st, bool isForward)
 {
-	SdpArgs a; a.q_bg = q_bg; a.q_ed = q_ed; a.q_str = q_str; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st;
-	a.head = w.kh_head[tbl]; a.nextv = w.kh_next[tbl]; a.km = w.kh_kmer[tbl]; a.KEY_MASK = (1ULL << key_len) - 1;
+	(void)key_len; (void)tbl;
+	SdpArgs a; a.q_bg = q_bg; a.q_ed = q_ed; a.q_str = q_str; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st; a.tab = w.wtab;
+	// read positions that can be returned: q_bg <= pos <= q_ed, and pos has a 9-mer (pos <= L - 9)
+	uint32_t n9 = w.L - 9 + 1, hi = q_ed < n9 - 1 ? q_ed : n9 - 1;
+	a.n_q = (q_bg <= hi) ? hi - q_bg + 1 : 0;
+	if (a.n_q > DSB_WTAB_MAXQ) { w.status |= DSB_ST_SMS_OVF; return; }     // cannot happen: windows are <= 2001 wide
+	uint32_t t_kmer_num = t_len - 9 + 1;
+	if (a.n_q == 0 || t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return;
+	wtab_build(w, q_str, q_bg, a.n_q);
 	if (isForward) sdp_match_t<true>(w, a); else sdp_match_t<false>(w, a);
 }
 
@@ -1613,7 +1611,7 @@ DN void get_score_M2(WCtx &w, SDir *sd, uint32_t l_read, DsbScHash *sc_hash)
 {
 	TICK(w, 8);
 	MARK(w, 50);
-	int key_len = build_hash_table_M2(w, sd, l_read);
+	int key_len = 0;
 	MARK(w, 51);
 	TICK(w, 4);
 	DsbChain *H = w.hit;

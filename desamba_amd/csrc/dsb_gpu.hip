@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	   would turn each x->field into a vector load from host-coherent memory.) */                                       \
 	__shared__ DsbDevIndex sx;                                                                                          \
 	__shared__ uint4 lds_ring[DSB_RING];                                                                                \
-	__shared__ DsbScHash lds_sc[256 + 2 * 400 + 64];                                                                    \
+	__shared__ uint32_t lds_wtab[DSB_WTAB_SLOTS];                                                                       \
 	__shared__ uint32_t lds_red[THREADS / 64 + 1];                                                                      \
 	__shared__ unsigned int s_word;                                                                                     \
 	if (lane == 0) sx = x;                                                                                              \
@@ -185,11 +185,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	w.anc = (DsbAnchor *)(slot + ar.off_anc); w.anc_tmp = (DsbAnchor *)(slot + ar.off_anc_tmp);                         \
 	w.hit = (DsbChain *)(slot + ar.off_hit); w.hit_tmp = (DsbChain *)(slot + ar.off_hit_tmp);                           \
 	w.sms = (DsbSms *)(slot + ar.off_sms);                                                                              \
-	uint32_t *kh = (uint32_t *)(slot + ar.off_kh);                                                                      \
-	size_t kh_strand = (size_t)(1u << 18) + 2 * (size_t)ar.max_len;                                                     \
-	w.kh_head[0] = kh; w.kh_next[0] = kh + (1u << 18); w.kh_kmer[0] = w.kh_next[0] + ar.max_len;                        \
-	w.kh_head[1] = kh + kh_strand; w.kh_next[1] = w.kh_head[1] + (1u << 18); w.kh_kmer[1] = w.kh_next[1] + ar.max_len;  \
-	w.sc = lds_sc;                                                                                                      \
+	w.sc = (DsbScHash *)(slot + ar.off_sc); w.wtab = lds_wtab;                                                          \
 	w.mem_slow = (DsbMem *)(slot + ar.off_mem);                                                                         \
 	w.spset = (uint64_t *)(slot + ar.off_spset);                                                                        \
 	w.score_v = (int *)(slot + ar.off_scorev);                                                                          \
@@ -356,7 +352,7 @@ static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int n_s
 	a.off_hit = o;     o += al256((size_t)DSB_HIT_CAP * sizeof(DsbChain));
 	a.off_hit_tmp = o; o += al256((size_t)DSB_HIT_CAP * sizeof(DsbChain));
 	a.off_sms = o;     o += al256((size_t)DSB_SMS_CAP * sizeof(DsbSms));
-	a.off_kh = o;      o += al256(2 * ((size_t)(1u << 18) + 2 * (size_t)max_len) * sizeof(uint32_t));
+	a.off_kh = o;
 	a.off_sc = o;      o += al256((size_t)(256 + 2 * 400 + 64) * sizeof(DsbScHash));
 	a.off_mem = o;     o += al256((size_t)DSB_MEMSLOW_CAP * sizeof(DsbMem));
 	a.off_spset = o;   o += al256((size_t)DSB_SPSET_CAP * 8);

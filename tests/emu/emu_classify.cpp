@@ -44,7 +44,7 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	add((size_t)DSB_ANC_CAP * sizeof(DsbAnchor)); add((size_t)DSB_ANC_CAP * sizeof(DsbAnchor));  // 1,2
 	add((size_t)DSB_HIT_CAP * sizeof(DsbChain)); add((size_t)DSB_HIT_CAP * sizeof(DsbChain));    // 3,4
 	add((size_t)DSB_SMS_CAP * sizeof(DsbSms));                           // 5
-	add(2 * ((size_t)(1u << 18) + 2 * (size_t)e->max_len) * 4);          // 6 kh
+	add(256);                                                            // 6 (unused)
 	add((size_t)(256 + 2 * 400 + 64) * sizeof(DsbScHash));               // 7
 	add((size_t)DSB_MEMSLOW_CAP * sizeof(DsbMem));                       // 8
 	add((size_t)DSB_SPSET_CAP * 8); add(1024 * sizeof(int));             // 9,10
@@ -56,9 +56,7 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	w.x = &e->dx; w.lane = 0; w.dbg = nullptr;
 	w.seeds = (DsbSeed *)(s + off[0]); w.anc = (DsbAnchor *)(s + off[1]); w.anc_tmp = (DsbAnchor *)(s + off[2]);
 	w.hit = (DsbChain *)(s + off[3]); w.hit_tmp = (DsbChain *)(s + off[4]); w.sms = (DsbSms *)(s + off[5]);
-	uint32_t *kh = (uint32_t *)(s + off[6]); size_t st = (size_t)(1u << 18) + 2 * (size_t)e->max_len;
-	w.kh_head[0] = kh; w.kh_next[0] = kh + (1u << 18); w.kh_kmer[0] = w.kh_next[0] + e->max_len;
-	w.kh_head[1] = kh + st; w.kh_next[1] = w.kh_head[1] + (1u << 18); w.kh_kmer[1] = w.kh_next[1] + e->max_len;
+	static uint32_t emu_wtab[DSB_WTAB_SLOTS]; w.wtab = emu_wtab;
 	w.sc = (DsbScHash *)(s + off[7]); w.mem_slow = (DsbMem *)(s + off[8]); w.spset = (uint64_t *)(s + off[9]); w.score_v = (int *)(s + off[10]);
 	w.sortkey = (uint64_t *)(s + off[11]); w.sortidx = (uint32_t *)(s + off[12]);
 	w.win_mid = s + off[13]; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
