@@ -98,6 +98,8 @@ DV int grp_first(uint32_t *, int, bool p) { return p ? 0 : DSB_WAVE; }
 DV int grp_max_i(uint32_t *, int, int v) { return v; }
 DV uint32_t grp_excl_scan_u(uint32_t *, int, uint32_t v, uint32_t *total) { *total = v; return 0; }
 template <class T> static inline T dsb_shfl(T v, int) { return v; }
+#define dsb_ballot64(p) ((p) ? 1ULL : 0ULL)
+#define DSB_RFL(v) (v)
 #elif DSB_GROUP == 64
 DV void wave_sync()
 {	// same CU, same L1: a workgroup-scope release/acquire pair is enough
@@ -121,7 +123,11 @@ DV uint32_t grp_excl_scan_u(uint32_t *, int lane, uint32_t v, uint32_t *total)
 	return inc - v;
 }
 #define dsb_shfl(v, l) __shfl(v, l)
+#define dsb_ballot64(p) __ballot(p)
+#define DSB_RFL(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
 #else
+#define DSB_RFL(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
+#define dsb_ballot64(p) ((unsigned long long)__syncthreads_or(p))
 DV void wave_sync() { __syncthreads(); }
 // red: DSB_GROUP/64 + 1 words of LDS
 DV int grp_first(uint32_t *red, int tid, bool p)
@@ -1340,38 +1346,66 @@ DV void sdp_judge(const DsbSms &cs, const DsbSms &ps, uint32_t lim_q, uint32_t l
 template <int MODE>
 DN void sdp_batch_old(WCtx &w, DpBatch &b)
 {
-	uint32_t lq[DSB_DPB], lt[DSB_DPB]; int best[DSB_DPB]; bool stop[DSB_DPB];
+	// per node of the batch (group-uniform, kept in scalar registers): limits and the terms of sdp_judge that do
+	// not depend on the predecessor
+	uint32_t lq[DSB_DPB], lt[DSB_DPB], dl[DSB_DPB], nq[DSB_DPB], nt[DSB_DPB], nl[DSB_DPB]; int best[DSB_DPB];
+	uint32_t stopm = 0, preds = 0;
 #pragma unroll
-	for (int j = 0; j < DSB_DPB; j++) { sdp_limits<MODE>(b.nd[j], lq[j], lt[j]); best[j] = -2147483647 - 1; stop[j] = (uint32_t)j >= b.K; }
+	for (int j = 0; j < DSB_DPB; j++) {
+		uint32_t q_, t_; sdp_limits<MODE>(b.nd[j], q_, t_);
+		lq[j] = DSB_RFL(q_); lt[j] = DSB_RFL(t_);
+		dl[j] = lq[j] - lt[j]; nl[j] = DSB_RFL(b.nd[j].len);
+		if (MODE == 2) { nq[j] = lq[j] + 6; nt[j] = lt[j] + 6; } else { nq[j] = DSB_RFL(b.nd[j].q_pos); nt[j] = DSB_RFL(b.nd[j].t_pos); }
+		best[j] = -2147483647 - 1;
+		if ((uint32_t)j >= b.K) stopm |= 1u << j;
+	}
+	stopm = DSB_RFL(stopm);
 	const int32_t n0 = (int32_t)b.n0;
 	for (int32_t hi = n0 - 1; hi >= 0; hi -= DSB_DP_UNROLL * DSB_WAVE) {
-		DsbSms pv[DSB_DP_UNROLL];
+		// per predecessor (one per lane and unrolled group), shared by all nodes of the batch:
+		//   MODE 1: A = q_pos+len+8, B = t_pos+len+8, C = t_pos+600;  MODE 2: A = q_pos, B = t_pos, C = t_pos
+		//   D = q_pos - t_pos, S = score.  Lanes past the start of the list carry values that fail the first test.
+		uint32_t A[DSB_DP_UNROLL], B[DSB_DP_UNROLL], C[DSB_DP_UNROLL], D[DSB_DP_UNROLL], S[DSB_DP_UNROLL];
 #pragma unroll
 		for (int u = 0; u < DSB_DP_UNROLL; u++) {
 			int32_t pi = hi - u * DSB_WAVE - w.lane;
-			if (pi < 0) { pv[u].t_pos = pv[u].q_pos = pv[u].len = pv[u].score = 0; }
-			else if (pi > n0 - DSB_RING) { uint4 r = w.ring[pi & (DSB_RING - 1)]; pv[u].t_pos = r.x; pv[u].q_pos = r.y; pv[u].len = r.z; pv[u].score = r.w; }
-			else pv[u] = w.sms[pi];
+			DsbSms ps;
+			if (pi < 0) { ps.t_pos = 0; ps.q_pos = (MODE == 2) ? 0u : 0xfffffff0u; ps.len = 0; ps.score = 0; }
+			else if (pi > n0 - DSB_RING) { uint4 r = w.ring[pi & (DSB_RING - 1)]; ps.t_pos = r.x; ps.q_pos = r.y; ps.len = r.z; ps.score = r.w; }
+			else ps = w.sms[pi];
+			if (MODE == 2) { A[u] = ps.q_pos; B[u] = ps.t_pos; C[u] = ps.t_pos; }
+			else { A[u] = ps.q_pos + ps.len + 8; B[u] = ps.t_pos + ps.len + 8; C[u] = ps.t_pos + 600; }
+			D[u] = ps.q_pos - ps.t_pos; S[u] = ps.score;
+			if (pi < 0 && MODE != 2) A[u] = 0xffffffffu;
 		}
-		bool all_stop = true;
 #pragma unroll
 		for (int j = 0; j < DSB_DPB; j++) {
-			if (stop[j]) continue;
-			w.dp_preds += DSB_DP_UNROLL * DSB_WAVE;
+			if ((stopm >> j) & 1u) continue;
+			preds += DSB_DP_UNROLL * DSB_WAVE;
 #pragma unroll
 			for (int u = 0; u < DSB_DP_UNROLL; u++) {
-				if (stop[j]) break;
-				int32_t pi = hi - u * DSB_WAVE - w.lane; bool valid = pi >= 0;
-				bool skip, brk; int ns;
-				sdp_judge<MODE>(b.nd[j], pv[u], lq[j], lt[j], skip, brk, ns);
-				int first_brk = grp_first(w.red, w.lane, valid && brk);
-				if (valid && !skip && !brk && w.lane < first_brk && ns > best[j]) best[j] = ns;
-				if (first_brk < DSB_WAVE) stop[j] = true;
+				if ((stopm >> j) & 1u) break;
+				bool skip, brk, ov;
+				if (MODE == 2) { skip = (A[u] < lq[j]) | (B[u] < lt[j]); brk = !skip & (lt[j] + 600 < C[u]); ov = (nq[j] > A[u]) | (nt[j] > B[u]); }
+				else { skip = (A[u] > lq[j]) | (B[u] > lt[j]); brk = !skip & (C[u] < lt[j]); ov = (A[u] > nq[j]) | (B[u] > nt[j]); }
+				int indel = (int)(D[u] - dl[j]); int ai = ABSV(indel);
+				int ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3));
+				int oq = (MODE == 2) ? (int)(nq[j] - A[u]) : (int)(A[u] - nq[j]);
+				int ot = (MODE == 2) ? (int)(nt[j] - B[u]) : (int)(B[u] - nt[j]);
+				if (ov) ns -= MAXV(oq, ot);
+				bool ok = !skip & !brk & (ai <= 200);
+				uint64_t bm = dsb_ballot64(brk);
+				if (bm) {	// the reference stops at the newest predecessor that meets the distance cut
+					int first_brk = grp_first(w.red, w.lane, brk);
+					ok = ok & (w.lane < first_brk);
+					stopm |= 1u << j;
+				}
+				if (ok && ns > best[j]) best[j] = ns;
 			}
-			if (!stop[j]) all_stop = false;
 		}
-		if (all_stop) break;
+		if (stopm == (1u << DSB_DPB) - 1u) break;
 	}
+	w.dp_preds += preds;
 #pragma unroll
 	for (int j = 0; j < DSB_DPB; j++) b.old_best[j] = ((uint32_t)j < b.K) ? grp_max_i(w.red, w.lane, best[j]) : 0;
 }
