@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads-per-gpu", type=int, default=32768)
+    ap.add_argument("--reads-per-gpu", type=int, default=65536)
     ap.add_argument("--read-len", type=int, default=50000)
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -109,12 +109,10 @@ def main():
     tmp = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
     fq = os.path.join(tmp, "dsb_bench_r%d.fq" % rank)
     gen_reads(index_dir, fq, a.reads_per_gpu, a.read_len, 1 + rank)
-    recs = D.read_fastq(fq)
     idx = D.Index(index_dir)
     ctx = D.Ctx(idx, local, n_slots=a.slots)
-    reads = D.make_reads(recs)
-    bases = sum(len(r[1]) for r in recs)
-    ctx.upload(reads)                       # inputs resident in HBM before the timed region
+    n_up = ctx.upload_fastq(fq)             # parsed + staged by the library: inputs resident in HBM before the timed region
+    assert n_up == a.reads_per_gpu, (n_up, a.reads_per_gpu)
 
     def sync_all():
         if dist:
@@ -138,9 +136,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     res = ctx.fetch(strict=False)
-    n_bad = sum(1 for i in range(len(recs)) if res.reads[i].status != 0)
-    n_mapped = sum(1 for i in range(len(recs)) if res.reads[i].n > 0)
-    dev_us = sorted(res.reads[i].device_us for i in range(len(recs)))
+    bases = ctx.timing().bases
+    n_bad = sum(1 for i in range(n_up) if res.reads[i].status != 0)
+    n_mapped = sum(1 for i in range(n_up) if res.reads[i].n > 0)
+    dev_us = sorted(res.reads[i].device_us for i in range(n_up))
 
     if rank == 0:
         steps = max(a.steps, 1)
@@ -152,7 +151,7 @@ def main():
         # algorithmic bytes
         seed_bytes = tm.bases + 64.0 * (tm.windows + tm.probes_t1)
         # classify kernel: per-bp work rates measured by the oracle's counters on this workload
-        cls_bytes = tm.bases * (64 * 0.1368 + 16 * 0.01137 + 24 * 0.00624 + 1.2542 / 4 + 2.0 + 2 * 1.2 * (8.0 + 4.0 * 65536 / a.read_len))
+        cls_bytes = tm.bases * (64 * 0.1368 + 16 * 0.01137 + 24 * 0.00624 + 1.2542 / 4 + 2.0)
         dom_is_cls = classify_s >= probe_s
         roof_seed = {"kernel": "k_seed_probe", "bound": "hbm", "achieved": seed_bytes / probe_s / 1e9 if probe_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "traffic": None, "ms": probe_s * 1e3}
@@ -169,7 +168,7 @@ def main():
             "kernel_ms_per_step": {"k_encode": encode_ms / steps, "k_seed_probe": probe_ms / steps, "k_classify": classify_ms / steps},
             "roofline": roof_cls if dom_is_cls else roof_seed,
             "roofline_seed_lookup": roof_seed,
-            "reads_mapped_frac": n_mapped / max(len(recs), 1), "reads_with_device_status": n_bad,
+            "reads_mapped_frac": n_mapped / max(n_up, 1), "reads_with_device_status": n_bad,
             "per_read_wave_us": {"mean": sum(dev_us) / max(len(dev_us), 1), "median": dev_us[len(dev_us) // 2] if dev_us else 0,
                                  "p99": dev_us[int(len(dev_us) * 0.99)] if dev_us else 0, "max": dev_us[-1] if dev_us else 0},
         }

@@ -49,7 +49,7 @@ class DsbTiming(C.Structure):
 
 EXPORTS = ["dsb_index_open", "dsb_index_close", "dsb_index_n_ref", "dsb_index_ref_name", "dsb_index_ref_len", "dsb_index_ek_len",
            "dsb_index_occ_host", "dsb_ctx_create", "dsb_ctx_destroy", "dsb_ctx_reset_history", "dsb_classify_batch",
-           "dsb_batch_upload", "dsb_batch_run", "dsb_batch_fetch", "dsb_batch_timing", "dsb_batch_seeds", "dsb_batch_exist_bits",
+           "dsb_batch_upload", "dsb_batch_upload_fastq", "dsb_batch_run", "dsb_batch_fetch", "dsb_batch_timing", "dsb_batch_seeds", "dsb_batch_exist_bits",
            "dsb_format_sam", "dsb_strerror", "dsb_version"]
 
 _lib = None
@@ -75,6 +75,7 @@ def lib():
     L.dsb_ctx_reset_history.argtypes = [C.c_void_p]
     L.dsb_classify_batch.argtypes = [C.c_void_p, C.POINTER(DsbRead), C.c_size_t, C.POINTER(DsbResult)]
     L.dsb_batch_upload.argtypes = [C.c_void_p, C.POINTER(DsbRead), C.c_size_t]
+    L.dsb_batch_upload_fastq.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t]; L.dsb_batch_upload_fastq.restype = C.c_long
     L.dsb_batch_run.argtypes = [C.c_void_p]
     L.dsb_batch_fetch.argtypes = [C.c_void_p, C.POINTER(DsbResult)]
     L.dsb_batch_timing.argtypes = [C.c_void_p, C.POINTER(DsbTiming)]
@@ -164,6 +165,15 @@ class Ctx:
         rc = lib().dsb_batch_upload(self.h, reads, len(reads))
         if rc != 0:
             raise DsbError(rc, "dsb_batch_upload")
+
+    def upload_fastq(self, path, skip=0, max_reads=1 << 62):
+        """stage a plain-text FASTQ file straight into HBM; returns the number of reads"""
+        self.reads = None
+        n = lib().dsb_batch_upload_fastq(self.h, os.fsencode(path), skip, max_reads)
+        if n < 0:
+            raise DsbError(int(n), "dsb_batch_upload_fastq(%s)" % path)
+        self.n_uploaded = int(n)
+        return int(n)
 
     def run(self):
         rc = lib().dsb_batch_run(self.h)

@@ -80,7 +80,7 @@ static int classify_main(int argc, char **argv)
 	dsb_opts o = {170, 64, 5, 0}; int full = 0, dev = 0, c; FILE *out = stdout;
 	while ((c = getopt(argc, argv, "ht:l:r:f:o:s:g:")) >= 0) {
 		if (c == 'h') { usage(); return 0; }
-		else if (c == 't') (void)atoi(optarg);
+		else if (c == 't') { /* thread count: accepted for compatibility, unused */ }
 		else if (c == 'l') o.L_min_matching = atoi(optarg);
 		else if (c == 'r') o.max_sec_N = atoi(optarg);
 		else if (c == 'o') { out = fopen(optarg, "w"); if (!out) { fprintf(stderr, "[xopen] fail to open file '%s'\n", optarg); exit(1); } }

@@ -61,15 +61,6 @@
 #define DSB_WTAB_SLOTS 3072u     /* 12 KB of LDS: <= 2048 window positions, load factor <= 0.67 */
 #define DSB_WTAB_MAXQ 2048u
 #define DSB_WTAB_EMPTY 0xffffffffu
-// a read whose sparse DP scans more than this many predecessors is handed to the wide kernel
-#define DSB_HEAVY_PREDS 2500000u
-#endif
-
-#undef DSB_HEAVY_ABORT
-#if defined(DSB_ENABLE_HEAVY_ABORT)
-#define DSB_HEAVY_ABORT 1
-#else
-#define DSB_HEAVY_ABORT 0
 #endif
 
 // A read whose sparse DP has already scanned DSB_BOOST_PREDS predecessors is ALU-bound for a long time
@@ -1361,6 +1352,16 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 	}
 	stopm = DSB_RFL(stopm);
 	const int32_t n0 = (int32_t)b.n0;
+	// predecessors are fetched one iteration ahead (4 x 64 nodes in flight while the previous 4 x 64 are judged)
+	DsbSms nx[DSB_DP_UNROLL];
+#define DSB_FETCH_PREDS(dst, hi_)                                                                               \
+	_Pragma("unroll") for (int u = 0; u < DSB_DP_UNROLL; u++) {                                                 \
+		int32_t pi = (hi_) - u * DSB_WAVE - w.lane;                                                              \
+		if (pi < 0) { dst[u].t_pos = 0; dst[u].q_pos = (MODE == 2) ? 0u : 0xfffffff0u; dst[u].len = 0; dst[u].score = 0; } \
+		else if (pi > n0 - DSB_RING) { uint4 r = w.ring[pi & (DSB_RING - 1)]; dst[u].t_pos = r.x; dst[u].q_pos = r.y; dst[u].len = r.z; dst[u].score = r.w; } \
+		else dst[u] = w.sms[pi];                                                                                 \
+	}
+	if (n0 > 0) { DSB_FETCH_PREDS(nx, n0 - 1) }
 	for (int32_t hi = n0 - 1; hi >= 0; hi -= DSB_DP_UNROLL * DSB_WAVE) {
 		// per predecessor (one per lane and unrolled group), shared by all nodes of the batch:
 		//   MODE 1: A = q_pos+len+8, B = t_pos+len+8, C = t_pos+600;  MODE 2: A = q_pos, B = t_pos, C = t_pos
@@ -1369,15 +1370,13 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 #pragma unroll
 		for (int u = 0; u < DSB_DP_UNROLL; u++) {
 			int32_t pi = hi - u * DSB_WAVE - w.lane;
-			DsbSms ps;
-			if (pi < 0) { ps.t_pos = 0; ps.q_pos = (MODE == 2) ? 0u : 0xfffffff0u; ps.len = 0; ps.score = 0; }
-			else if (pi > n0 - DSB_RING) { uint4 r = w.ring[pi & (DSB_RING - 1)]; ps.t_pos = r.x; ps.q_pos = r.y; ps.len = r.z; ps.score = r.w; }
-			else ps = w.sms[pi];
+			DsbSms ps = nx[u];
 			if (MODE == 2) { A[u] = ps.q_pos; B[u] = ps.t_pos; C[u] = ps.t_pos; }
 			else { A[u] = ps.q_pos + ps.len + 8; B[u] = ps.t_pos + ps.len + 8; C[u] = ps.t_pos + 600; }
 			D[u] = ps.q_pos - ps.t_pos; S[u] = ps.score;
 			if (pi < 0 && MODE != 2) A[u] = 0xffffffffu;
 		}
+		if (hi - DSB_DP_UNROLL * DSB_WAVE >= 0) { DSB_FETCH_PREDS(nx, hi - DSB_DP_UNROLL * DSB_WAVE) }
 #pragma unroll
 		for (int j = 0; j < DSB_DPB; j++) {
 			if ((stopm >> j) & 1u) continue;
@@ -1505,7 +1504,6 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 	int last_search = false;
 	while (1) {
 		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
-		if (DSB_HEAVY_ABORT && w.dp_preds > DSB_HEAVY_PREDS) { w.status |= DSB_ST_HEAVY; break; }
 		DSB_BOOST_IF_HEAVY(w);
 		if (w.n_sms == current_sms) {
 			uint32_t next_step = t_length - c_t_offset;
@@ -1584,7 +1582,6 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 	int last_search = false;
 	while (1) {
 		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
-		if (DSB_HEAVY_ABORT && w.dp_preds > DSB_HEAVY_PREDS) { w.status |= DSB_ST_HEAVY; break; }
 		DSB_BOOST_IF_HEAVY(w);
 		if (w.n_sms == current_sms) {
 			uint32_t next_step = c_t_offset;
@@ -1651,7 +1648,6 @@ DN void get_score_M2(WCtx &w, SDir *sd, uint32_t l_read, DsbScHash *sc_hash)
 	DsbChain *H = w.hit;
 	for (uint32_t i = 0; i < w.n_hit; i++) {
 		if (H[i].sum_score == 0) continue;
-		if (w.status & DSB_ST_HEAVY) return;
 		SDir *csd = ((sd->direction == H[i].direction) ? 0 : 1) + sd;
 		int tbl = (H[i].direction == D_FORWARD) ? 0 : 1;
 		MARK(w, 52);
@@ -1800,7 +1796,6 @@ DN uint32_t classify_read(WCtx &w, const uint64_t *bitsF, const uint64_t *bitsR)
 	w.stage = 5; MARK(w, 5);
 	delete_small_score_rst(w, sd, read_len);
 	TICK(w, 8);
-	if (w.status & DSB_ST_HEAVY) return fast;
 	w.stage = 6; MARK(w, 6);
 	detect_primary(w, read_len);
 	w.stage = 7; MARK(w, 7);

@@ -77,5 +77,4 @@ struct DsbReadOut { uint32_t first, n; int32_t status; uint32_t fast; };
 #define DSB_ST_HIT_OVF 2
 #define DSB_ST_SMS_OVF 4
 #define DSB_ST_OUT_OVF 8
-#define DSB_ST_HEAVY 32     // narrow kernel only: the read was handed to the wide kernel (never reaches the host)
 #define DSB_ST_TIMEOUT 16   // the per-read loop budget ran out (guards the grid against a spinning wave)

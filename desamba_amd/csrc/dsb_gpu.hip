@@ -14,6 +14,9 @@
 #include <stdlib.h>
 #include <vector>
 #include <unistd.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include "dsb_device.h"
 #include "dsb_probe.h"
 // the per-read device code, instantiated for one wavefront per read
@@ -157,14 +160,14 @@ struct DsbSlotArena {
 };
 
 // One kernel body, two instantiations.  Work items come from an atomic counter; with `list` == nullptr
-// item k is read k (all reads), otherwise read list[k] (the reads the narrow kernel flagged as heavy).
+// item k is read k, otherwise read list[k] (the longest-processing-time-first order of k_order).
 #ifndef DSB_WAVES_PER_EU
-#define DSB_WAVES_PER_EU 4
+#define DSB_WAVES_PER_EU 3      /* LDS (12.6 KB per wave) admits 12 waves per CU: 168 VGPRs cost no occupancy */
 #endif
 #define DSB_DEFINE_CLASSIFY(KNAME, NS, THREADS)                                                                         \
 __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,   \
         const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout,  \
-        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *heavy_list, unsigned int *heavy_counter, uint32_t *dbg) \
+        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg)                                  \
 {                                                                                                                       \
 	const int lane = threadIdx.x;                                                                                       \
 	uint8_t *slot = ar.base + (size_t)blockIdx.x * ar.stride;                                                           \
@@ -208,14 +211,11 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 		unsigned int r = list ? list[k] : k;                                                                            \
 		DsbReadDesc d = rd[r];                                                                                          \
 		uint64_t t_start = wall_clock64();                                                                              \
+		uint64_t tacc0[14]; if (w.dbg) for (int i = 0; i < 14; i++) tacc0[i] = w.tacc[i];                               \
 		if (w.dbg && lane == 0) { w.dbg[2] = r; w.dbg[0] = 100; }                                                       \
 		w.bin = bin + d.bin_off + DSB_QPAD_L; w.L = d.len; w.status = 0; w.max_read_l = d.hist_max;                     \
 		uint32_t fast = NS::classify_read(w, bits + d.bit_off, bits + d.bit_off + d.n_words);                           \
 		if (w.boosted) __builtin_amdgcn_s_setprio(0);                                                                   \
-		if (w.status & DSB_ST_HEAVY) {   /* narrow kernel only: queue the read for the wide kernel */                   \
-			if (lane == 0) { unsigned int q = atomicAdd(heavy_counter, 1u); heavy_list[q] = r; }                        \
-			continue;                                                                                                   \
-		}                                                                                                               \
 		/* publish the hits of this read */                                                                             \
 		if (lane == 0) s_word = w.n_hit ? atomicAdd(hout_counter, w.n_hit) : 0u;                                        \
 		__syncthreads();                                                                                                \
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 			o.direction = h.direction; o.primary = h.primary; o.pri_index = h.pri_index; o.pad = 0;                     \
 			hout[first + i] = o;                                                                                        \
 		}                                                                                                               \
-		if (w.dbg && lane == 0) w.dbg[0] = 200;                                                                         \
+		if (w.dbg && lane == 0) { w.dbg[0] = 200; if (r < 65536u) for (int i = 0; i < 14; i++) dbg[16 * 65536 + 14 * r + i] = (uint32_t)((w.tacc[i] - tacc0[i]) / 100); } \
 		if (lane == 0) { DsbReadOut ro; ro.first = first; ro.n = n_out; ro.status = w.status | (w.status ? (w.stage << 8) : 0); \
 			ro.fast = fast | ((uint32_t)((wall_clock64() - t_start) / 100) << 1); rout[r] = ro; }                       \
 	}                                                                                                                   \
@@ -248,7 +248,6 @@ struct dsb_ctx {
 	DsbReadOut *d_rout; DsbHitOut *d_hout; size_t cap_rout, cap_hout;
 	unsigned int *d_counters;                      // [0] work, [1] hits; +8: u64 p1 counter
 	DsbSlotArena arena; size_t arena_bytes; int n_slots;
-	DsbSlotArena arena_wide; int n_wide_slots; uint32_t *d_heavy; size_t cap_heavy; unsigned int last_heavy;
 	uint32_t *d_score, *d_order; size_t cap_score, cap_order;
 	// host mirrors
 	std::vector<DsbReadDesc> h_rd; std::vector<DsbWordDesc> h_wd;
@@ -307,8 +306,8 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	HIPCHK(hipMalloc((void **)&c->d_counters, 64));
 	c->dbg_host = c->dbg_dev = nullptr;
 	if (getenv("DSB_DEBUG")) {
-		HIPCHK(hipHostMalloc((void **)&c->dbg_host, 16 * 65536 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
-		memset(c->dbg_host, 0, 16 * 65536 * sizeof(uint32_t));
+		HIPCHK(hipHostMalloc((void **)&c->dbg_host, 32 * 65536 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+		memset(c->dbg_host, 0, 32 * 65536 * sizeof(uint32_t));
 		HIPCHK(hipHostGetDevicePointer((void **)&c->dbg_dev, c->dbg_host, 0));
 	}
 	c->n_slots = c->opts.n_slots > 0 ? c->opts.n_slots : 0;
@@ -322,7 +321,7 @@ extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 	hipSetDevice(c->device);
 	for (void *p : c->dev_allocs) hipFree(p);
 	hipFree(c->d_rd); hipFree(c->d_wd); hipFree(c->d_ascii); hipFree(c->d_bin); hipFree(c->d_pk); hipFree(c->d_bits);
-	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->arena_wide.base); hipFree(c->d_heavy); hipFree(c->d_score); hipFree(c->d_order);
+	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->d_score); hipFree(c->d_order);
 	for (int i = 0; i < 4; i++) hipEventDestroy(c->ev[i]);
 	hipStreamDestroy(c->stream);
 	delete c;
@@ -370,7 +369,8 @@ static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int n_s
 	return 0;
 }
 
-extern "C" int dsb_batch_upload(dsb_ctx *c, const dsb_read *reads, size_t n)
+struct SeqView { const char *p; uint32_t len; };
+static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n)
 {
 	if (!c || (!reads && n)) return DSB_EINVAL;
 	HIPCHK(hipSetDevice(c->device));
@@ -403,7 +403,6 @@ extern "C" int dsb_batch_upload(dsb_ctx *c, const dsb_read *reads, size_t n)
 	int want = c->opts.n_slots > 0 ? c->opts.n_slots : 256 * 4 * 4;
 	if ((size_t)want > n) want = (int)(n ? n : 1);
 	if ((rc = size_arena(c->arena, &c->n_slots, max_len, want > c->n_slots ? want : c->n_slots, 64))) return rc;
-	if ((rc = grow(&c->d_heavy, &c->cap_heavy, n + 1))) return rc;
 	if ((rc = grow(&c->d_score, &c->cap_score, n + 1))) return rc;
 	if ((rc = grow(&c->d_order, &c->cap_order, n + 1))) return rc;
 	if (n) {
@@ -411,11 +410,65 @@ extern "C" int dsb_batch_upload(dsb_ctx *c, const dsb_read *reads, size_t n)
 		if (!c->h_wd.empty()) HIPCHK(hipMemcpyAsync(c->d_wd, c->h_wd.data(), c->h_wd.size() * sizeof(DsbWordDesc), hipMemcpyHostToDevice, c->stream));
 		// sequences: copied read by read out of the caller's buffers (caller owns read memory)
 		std::vector<char> stage((size_t)seq_off);
-		for (size_t i = 0; i < n; i++) memcpy(stage.data() + c->h_rd[i].seq_off, reads[i].seq, reads[i].len);
+		for (size_t i = 0; i < n; i++) memcpy(stage.data() + c->h_rd[i].seq_off, reads[i].p, reads[i].len);
 		HIPCHK(hipMemcpy(c->d_ascii, stage.data(), (size_t)seq_off, hipMemcpyHostToDevice));
 	}
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return DSB_OK;
+}
+
+extern "C" int dsb_batch_upload(dsb_ctx *c, const dsb_read *reads, size_t n)
+{
+	if (!c || (!reads && n)) return DSB_EINVAL;
+	std::vector<SeqView> v(n);
+	for (size_t i = 0; i < n; i++) { v[i].p = reads[i].seq; v[i].len = reads[i].len; }
+	return upload_views(c, v.data(), n);
+}
+
+// read_reads (src/cly_mt.c:42-56) for a plain-text FASTQ/FASTA file: parse up to max_reads records starting
+// at record `skip` straight out of the mapped file and stage them into HBM (no per-read host copies).
+extern "C" long dsb_batch_upload_fastq(dsb_ctx *c, const char *path, size_t skip, size_t max_reads)
+{
+	if (!c || !path) return DSB_EINVAL;
+	int fd = open(path, O_RDONLY);
+	if (fd < 0) return DSB_EIO;
+	struct stat st; if (fstat(fd, &st) != 0) { close(fd); return DSB_EIO; }
+	size_t sz = (size_t)st.st_size;
+	const char *b = sz ? (const char *)mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+	close(fd);
+	if (sz && b == MAP_FAILED) return DSB_EIO;
+	std::vector<SeqView> v; std::vector<std::vector<char>> joined; std::vector<size_t> joined_of;   // joined: multi-line records only
+	const char *p = b, *e = b + sz; size_t rec = 0;
+	while (p < e && v.size() < max_reads) {
+		while (p < e && *p != '>' && *p != '@') p++;
+		if (p >= e) break;
+		bool fq = *p == '@';
+		while (p < e && *p != '\n') p++;
+		p++;
+		const char *s0 = p; while (p < e && *p != '\n') p++;
+		const char *s1 = p; if (s1 > s0 && s1[-1] == '\r') s1--;
+		p++;
+		size_t len = (size_t)(s1 - s0); const char *sp = s0; bool multi = false;
+		if (p < e && *p != '>' && *p != '+' && *p != '@') {   // sequence continues on further lines: join them
+			joined.emplace_back(s0, s1); multi = true;
+			while (p < e && *p != '>' && *p != '+' && *p != '@') { const char *l0 = p; while (p < e && *p != '\n') p++; const char *l1 = p; if (l1 > l0 && l1[-1] == '\r') l1--; joined.back().insert(joined.back().end(), l0, l1); p++; }
+			len = joined.back().size();
+		}
+		if (fq && p < e && *p == '+') {
+			while (p < e && *p != '\n') p++;
+			p++;
+			size_t ql = 0; while (p < e && ql < len) { const char *l0 = p; while (p < e && *p != '\n') p++; ql += (size_t)(p - l0) - ((p > l0 && p[-1] == '\r') ? 1 : 0); p++; }
+		}
+		if (rec++ < skip) { if (multi) joined.pop_back(); continue; }
+		if (len > 0xffffffffu) { if (b) munmap((void *)b, sz); return DSB_EINVAL; }
+		SeqView sv; sv.p = multi ? nullptr : sp; sv.len = (uint32_t)len;
+		if (multi) joined_of.push_back(v.size());
+		v.push_back(sv);
+	}
+	for (size_t k = 0; k < joined_of.size(); k++) v[joined_of[k]].p = joined[k].data();   // after the vectors stopped growing
+	int rc = upload_views(c, v.data(), v.size());
+	if (b) munmap((void *)b, sz);
+	return rc ? rc : (long)v.size();
 }
 
 extern "C" int dsb_batch_run(dsb_ctx *c)
@@ -443,13 +496,13 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	{
 		unsigned slots = (unsigned)c->n_slots; if (slots > n) slots = (unsigned)n;
 		uint32_t *dbgp = dbg ? c->dbg_dev : nullptr;
-		if (dbg) memset(c->dbg_host, 0, 16 * 65536 * sizeof(uint32_t));
-		// counters: [0] work, [1] hits, [2..3] u64 table-1 probes, [4] heavy reads, [5] work of the wide kernel
+		if (dbg) memset(c->dbg_host, 0, 32 * 65536 * sizeof(uint32_t));
+		// counters: [0] work, [1] hits, [2..3] u64 table-1 probes
 		hipLaunchKernelGGL(k_repeat_score, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_rd, c->d_pk, c->d_score);
 		hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, c->stream, c->d_score, (uint32_t)n, c->d_order);
 		hipLaunchKernelGGL(k_classify, dim3(slots), dim3(64), 0, c->stream, c->dx, c->d_rd, (uint32_t)n, (const unsigned int *)nullptr, (const uint32_t *)c->d_order,
 		                   c->d_bin, c->d_bits, c->arena, c->d_counters, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout,
-		                   c->d_heavy, c->d_counters + 4, dbgp);
+		                   dbgp);
 		if (dbg) {
 			// watchdog: poll the stream; dump the progress words of every slot if the kernel runs long
 			for (int sec = 0; sec < 60; sec++) {
@@ -470,6 +523,13 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		double sub[4] = {0};
 		for (unsigned sI = 0; sI < slots; sI++) { for (int i = 0; i < 10; i++) { tot[i] += c->dbg_host[4 * 65536 + 14 * sI + i]; all += c->dbg_host[4 * 65536 + 14 * sI + i]; } for (int i = 0; i < 4; i++) sub[i] += c->dbg_host[4 * 65536 + 14 * sI + 10 + i]; }
 		fprintf(stderr, "[dsb] inside sdp_right/left (ms): sdp_match %.1f  dp %.1f  combine %.1f\n", sub[0] / 1e3, sub[1] / 1e3, sub[2] / 1e3);
+		{	// stage split of the slowest read of the batch (as it ran, i.e. under load)
+			size_t worst = 0; uint64_t wsum = 0;
+			for (size_t r = 0; r < n && r < 65536; r++) { uint64_t sm = 0; for (int i = 0; i < 10; i++) sm += c->dbg_host[16 * 65536 + 14 * r + i]; if (sm > wsum) { wsum = sm; worst = r; } }
+			fprintf(stderr, "[dsb] slowest read %zu: %.1f ms:", worst, wsum / 1e3);
+			for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.1f", nm[i], c->dbg_host[16 * 65536 + 14 * worst + i] / 1e3);
+			fprintf(stderr, " | sdp_match %.1f dp %.1f combine %.1f\n", c->dbg_host[16 * 65536 + 14 * worst + 10] / 1e3, c->dbg_host[16 * 65536 + 14 * worst + 11] / 1e3, c->dbg_host[16 * 65536 + 14 * worst + 12] / 1e3);
+		}
 		fprintf(stderr, "[dsb] classify stage time (wave-seconds, %% of total %.2f s):", all / 1e6);
 		for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * tot[i] / (all > 0 ? all : 1));
 		fprintf(stderr, "\n");
@@ -480,8 +540,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	hipEventElapsedTime(&c->timing.classify_ms, c->ev[2], c->ev[3]);
 	hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[3]);
 	HIPCHK(hipMemcpy(&c->p1, c->d_counters + 2, 8, hipMemcpyDeviceToHost));
-	HIPCHK(hipMemcpy(&c->last_heavy, c->d_counters + 4, 4, hipMemcpyDeviceToHost));
-	if (dbg) fprintf(stderr, "[dsb] heavy reads handed to the wide kernel: %u\n", c->last_heavy);
+
 	c->timing.windows = c->total_windows; c->timing.probes_t1 = c->p1; c->timing.bases = c->total_bases;
 	return DSB_OK;
 }

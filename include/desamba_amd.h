@@ -99,6 +99,9 @@ int  dsb_classify_batch(dsb_ctx *ctx, const dsb_read *reads, size_t n, dsb_resul
 
 /* the same, split so that a benchmark can time the device part with inputs resident in HBM */
 int  dsb_batch_upload(dsb_ctx *ctx, const dsb_read *reads, size_t n);
+/* read_reads (src/cly_mt.c:42-56) for a plain-text FASTQ/FASTA file: stage records [skip, skip+max_reads) of the
+ * file into HBM without per-read host copies; returns the number of reads staged, or a negative DSB_E* code */
+long dsb_batch_upload_fastq(dsb_ctx *ctx, const char *path, size_t skip, size_t max_reads);
 int  dsb_batch_run(dsb_ctx *ctx);                       /* all kernels, synchronous */
 int  dsb_batch_fetch(dsb_ctx *ctx, dsb_result *out);
 int  dsb_batch_timing(const dsb_ctx *ctx, dsb_timing *t);

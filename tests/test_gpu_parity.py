@@ -153,3 +153,17 @@ def test_full_size_batch_properties(gpu, demo, oracle, tmp_path):
     # read names carry the truth (r{i}_{refIndex}_{start}_{F|R}): the primary hit is on the source reference
     ok = sum(1 for (nm, s, q), h in zip(recs, whole) if h and h[0][0] == int(nm.split(b"_")[1]))
     assert ok >= 0.99 * len(recs)
+
+
+def test_upload_fastq_equals_upload(gpu, demo):
+    """dsb_batch_upload_fastq (the library parses the file) == dsb_batch_upload of the same records"""
+    D, idx, ctx = gpu
+    recs = D.read_fastq(demo["fastq"], 300)
+    ctx.reset_history(); a = ctx.sam(ctx.classify(D.make_reads(recs)))
+    ctx.reset_history()
+    n = ctx.upload_fastq(demo["fastq"], 0, 300)
+    assert n == 300
+    ctx.reads = D.make_reads(recs)          # names for the SAM formatter only
+    ctx.run(); b = ctx.sam(ctx.fetch())
+    assert a == b
+    assert ctx.upload_fastq(demo["fastq"], 1200, 1000) == 37
