@@ -159,6 +159,17 @@ def main():
         roof_cls = {"kernel": "k_classify", "bound": "hbm", "achieved": cls_bytes / classify_s / 1e9 if classify_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "traffic": None, "ms": classify_s * 1e3}
         roof_cls["frac"] = roof_cls["achieved"] / HBM_PEAK_GBS
+        # HBM-side traffic per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command (separate passes,
+        # KB -> bytes; random 64-B gathers, so the guide's x2 correction for 128-B streaming requests does not apply),
+        # committed under profiles/ -- only quoted when the workload is the profiled one
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_65536x50k.json")))["counters"]
+            if a.reads_per_gpu == 65536 and a.read_len == 50000:
+                roof_seed["traffic"] = (prof["k_seed_probe"]["FETCH_SIZE"] + prof["k_seed_probe"]["WRITE_SIZE"]) * 1024.0
+                roof_cls["traffic"] = (prof["k_classify"]["FETCH_SIZE"] + prof["k_classify"]["WRITE_SIZE"]) * 1024.0
+                roof_seed["algorithmic_bytes"] = seed_bytes; roof_cls["algorithmic_bytes"] = cls_bytes
+        except Exception:
+            pass
         out = {
             "metric": "classified reads/s (50 kbp ONT reads, viral index)", "value": value, "unit": "reads/s", "gbp_per_s": gbp,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
