@@ -92,8 +92,15 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # one rank per GPU over RCCL (backend "nccl").  DSB_BENCH_REHEARSAL=1: all ranks share GPU 0 and
+        # rendezvous over gloo -- only to exercise the multi-process control flow on a one-GPU box.
+        if os.environ.get("DSB_BENCH_REHEARSAL"):
+            local = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import __graft_entry__ as G
     import desamba_amd as D
@@ -132,7 +139,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist:
         import torch
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if os.environ.get("DSB_BENCH_REHEARSAL") else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     res = ctx.fetch(strict=False)

@@ -93,10 +93,13 @@ template <class T> static inline T dsb_shfl(T v, int) { return v; }
 #define DSB_RFL(v) (v)
 #elif DSB_GROUP == 64
 DV void wave_sync()
-{	// same CU, same L1: a workgroup-scope release/acquire pair is enough
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+{	// The 64 lanes of one wavefront exchange data through memory (LDS or global).  A wavefront's memory
+	// instructions issue in order through one L1, so a store by one lane is seen by a later load of another
+	// lane of the same wavefront without waiting for it to reach L2: wavefront-scope fences only stop the
+	// compiler from reordering.  (A workgroup-scope pair here costs an s_waitcnt vmcnt(0) per call.)
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 DV int grp_first(uint32_t *, int, bool p) { uint64_t m = __ballot(p); return m ? (int)__builtin_ctzll(m) : 64; }
 DV int grp_max_i(uint32_t *, int, int v)
@@ -183,7 +186,8 @@ struct WCtx {
 	uint32_t dp_preds;         // predecessors scanned by the sparse DP of this read (heavy-read detection)
 	uint4 *ring;               // LDS: the most recent DSB_RING sparse-DP nodes of sdp_right/left ({t_pos,q_pos,len,score})
 	int status; int max_read_l;
-	int stage; int boosted; uint32_t steps, lsteps; volatile uint32_t *dbg; uint64_t tacc[14], tlast, tsub;   // optional host-visible progress words (DSB_DEBUG)
+	int stage; int boosted; uint32_t sp_gen;   // generation of the visited-row sets (monotonic within a launch)
+	uint32_t steps, lsteps; volatile uint32_t *dbg; uint64_t tacc[14], tlast, tsub;   // optional host-visible progress words (DSB_DEBUG)
             // loop-iteration budget: every unbounded loop charges it and bails when exhausted
 	SDir sd[2];
 };
@@ -320,14 +324,25 @@ DN int32_t lv_extd(const uint8_t *ref, int32_t ref_length, const uint8_t *query,
 }
 
 // ---- FM search (src/cly.c:1286-1447) --------------------------------------------------------
-struct SpSet { uint64_t *set; int l, m; };
+// sp_set_insert (src/cly.c:1286-1298): the set of BWT rows already visited while walking one island; a row
+// seen again ends that walk.  The reference keeps a 500-entry array, scans it linearly on every insert and
+// starts over when it is full.  Same set, same capacity rule, but hashed: DSB_SPHASH slots of
+// {generation:20 | row:44}, linear probing; "start over" (and "new island") is a generation bump, entries of
+// older generations count as empty.  One or two loads per insert instead of up to 500.
+#define DSB_SPHASH 1024u
+struct SpSet { uint64_t *tab; int l, m; uint32_t *gen; };
+DV void sp_set_reset(SpSet &s) { s.l = 0; (*s.gen)++; }
 DV int sp_set_insert(uint64_t node, SpSet &s)
 {
-	if (s.l == s.m) s.l = 0;
-	int i = 0;
-	for (; i < s.l; i++) if (s.set[i] == node) return 0;
-	s.set[i] = node; s.l++;
-	return 1;
+	if (s.l == s.m) sp_set_reset(s);
+	const uint64_t g = (uint64_t)(*s.gen & 0xfffffu) << 44, key = node & 0xfffffffffffULL;
+	uint32_t sl = (uint32_t)((key * 0x9E3779B97F4A7C15ULL) >> 54);
+	for (;;) {
+		uint64_t e = s.tab[sl];
+		if ((e >> 44 << 44) != g) { s.tab[sl] = g | key; s.l++; return 1; }
+		if ((e & 0xfffffffffffULL) == key) return 0;
+		sl = (sl + 1) & (DSB_SPHASH - 1);
+	}
 }
 
 DV void bwt_single_search(const DsbDevIndex *x, uint64_t sp, const uint8_t *string, int max_match_len, SpSet &sp_set, DsbMem &m)
@@ -651,7 +666,8 @@ DV int fast_island(WCtx &w, SDir *s_d, uint32_t read_len, uint32_t seed_idx)
 	const DsbDevIndex *x = w.x;
 	int l_ek = x->ek_len, min_index = 21 - l_ek;
 	uint8_t *bin_read = s_d->bin_read;
-	SpSet sp_set = {w.spset, 0, DSB_SPSET_CAP};
+	SpSet sp_set = {w.spset, 0, DSB_SPSET_CAP, &w.sp_gen};
+	sp_set_reset(sp_set);
 	DsbMem m_r[2];
 	DsbSeed sv = s_d->seed_v[seed_idx];
 	int skip_next = 0;
@@ -684,7 +700,7 @@ DV int fast_island(WCtx &w, SDir *s_d, uint32_t read_len, uint32_t seed_idx)
 // one per lane, each into its own scratch (anchors, visited-row set); the results are then committed in
 // island order exactly as the reference would have produced them.  An island whose anchors do not fit
 // its lane scratch is redone by the whole wave straight into the anchor array.
-#define DSB_LANE_ANC_CAP 64
+#define DSB_LANE_ANC_CAP 192
 DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 {
 	DsbSeed *sv_b = s_d->seed_v; uint32_t n_seed = s_d->l_seed_v;
@@ -696,13 +712,16 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 		uint32_t t = base + w.lane; bool valid = t < n_top;
 		uint32_t main_n = w.n_anc; int st_before = w.status;
 		w.anc = w.lane_anc + (size_t)w.lane * DSB_LANE_ANC_CAP; w.n_anc = 0; w.anc_cap = DSB_LANE_ANC_CAP;
-		w.spset = w.lane_spset + (size_t)w.lane * 512;
+		w.spset = w.lane_spset + (size_t)w.lane * DSB_SPHASH;
 		int flag = valid ? fast_island(w, s_d, read_len, w.top_idx[t]) : 0;
 		int ovf = ((w.status & DSB_ST_ANC_OVF) && !(st_before & DSB_ST_ANC_OVF)) ? 1 : 0;
 		if (ovf) w.status &= ~DSB_ST_ANC_OVF;
 		uint32_t my_n = w.n_anc;
 		w.anc = main_anc; w.n_anc = main_n; w.anc_cap = DSB_ANC_CAP; w.spset = main_sp;
 		w.round_info[w.lane] = my_n | ((uint32_t)flag << 16) | ((uint32_t)ovf << 17);
+		// each lane bumped its own copy of the set generation: continue from the largest so that no lane's stale
+		// entries can look current, and the group-uniform code below sees one value
+		w.sp_gen = (uint32_t)grp_max_i(w.red, w.lane, (int)w.sp_gen);
 		wave_sync();
 		uint32_t n_round = MINV((uint32_t)DSB_WAVE, n_top - base);
 		for (uint32_t l = 0; l < n_round; l++) {
@@ -738,12 +757,12 @@ DN void slow_classify(WCtx &w, SDir *sd, uint32_t read_len)
 {
 	const DsbDevIndex *x = w.x;
 	int l_ek = x->ek_len; uint8_t *bin_read = sd->bin_read; DsbSeed *sv_f = sd->seed_v;
-	SpSet sp_set = {w.spset, 0, DSB_SPSET_CAP};
+	SpSet sp_set = {w.spset, 0, DSB_SPSET_CAP, &w.sp_gen};
 	DsbMem *mem_rst = w.mem_slow; int mem_rst_num;
 	for (uint32_t i = 0; i < sd->l_seed_v; i++) {
 		if ((int)(sv_f[i].len) < 3 && sv_f->top == 0) continue;
 		int min_match_len = MINV(20 - 1, l_ek + 1);
-		sp_set.l = 0; mem_rst_num = 0;
+		sp_set_reset(sp_set); mem_rst_num = 0;
 		for (int j = (int)sv_f[i].len - 1; j >= 1; j -= 2) {
 			if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; return; }
 			int k_idx = sv_f[i].offset + j;
@@ -1009,18 +1028,21 @@ DV bool combine_chain(DsbChain *c_st, int chain_ID, DsbScHash *sc, int dis, bool
 // for exactly that window, in LDS: open addressing, entry = kmer << 12 | (pos - q_bg).  A lookup collects
 // the entries of its 9-mer and visits them in ascending position = the reference's chain order.  No global
 // memory is touched besides the read bytes themselves.
-DV uint32_t wtab_slot(uint32_t kmer) { return (uint32_t)(((uint64_t)(kmer * 2654435761u) * DSB_WTAB_SLOTS) >> 32); }
+DV uint32_t wtab_slot(uint32_t kmer, uint32_t slots) { return (uint32_t)(((uint64_t)(kmer * 2654435761u) * slots) >> 32); }
+// slots used for a window of n_q positions: load factor <= 0.5 for small windows, the whole table for big ones
+DV uint32_t wtab_size(uint32_t n_q) { uint32_t s = 2 * n_q; return s < 64u ? 64u : (s > DSB_WTAB_SLOTS ? DSB_WTAB_SLOTS : s); }
 
 DN void wtab_build(WCtx &w, const uint8_t *q_str, uint32_t q_bg, uint32_t n_q)
 {
-	for (uint32_t i = w.lane; i < DSB_WTAB_SLOTS; i += DSB_WAVE) w.wtab[i] = DSB_WTAB_EMPTY;
+	const uint32_t slots = wtab_size(n_q);
+	for (uint32_t i = w.lane; i < slots; i += DSB_WAVE) w.wtab[i] = DSB_WTAB_EMPTY;
 	wave_sync();
 	for (uint32_t r = w.lane; r < n_q; r += DSB_WAVE) {
 		const uint8_t *q = q_str + q_bg + r;
 		uint32_t k = 0;
 #pragma unroll
 		for (int b = 0; b < 9; b++) k = (k << 2) | q[b];
-		uint32_t e = (k << 12) | r, sl = wtab_slot(k);
+		uint32_t e = (k << 12) | r, sl = wtab_slot(k, slots);
 		for (;;) {
 #ifdef DSB_HOST_EMU
 			uint32_t old = w.wtab[sl]; if (old == DSB_WTAB_EMPTY) w.wtab[sl] = e;
@@ -1028,7 +1050,7 @@ DN void wtab_build(WCtx &w, const uint8_t *q_str, uint32_t q_bg, uint32_t n_q)
 			uint32_t old = atomicCAS(&w.wtab[sl], DSB_WTAB_EMPTY, e);
 #endif
 			if (old == DSB_WTAB_EMPTY) break;
-			sl = sl + 1 == DSB_WTAB_SLOTS ? 0 : sl + 1;
+			sl = sl + 1 == slots ? 0 : sl + 1;
 		}
 	}
 	wave_sync();
@@ -1105,13 +1127,14 @@ DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out, uint32_t ou
 	// chain order).  A 9-mer with pad bits set (>= 2^18) matches nothing.
 	uint32_t cand[DSB_SDP_CAND]; int nc = 0; bool many = false;
 	if (a.n_q == 0 || kmer >= (1ULL << 18)) return 0;
-	const uint32_t k32 = (uint32_t)kmer, sl0 = wtab_slot(k32);
+	const uint32_t slots = wtab_size(a.n_q);
+	const uint32_t k32 = (uint32_t)kmer, sl0 = wtab_slot(k32, slots);
 	for (uint32_t sl = sl0;;) {
 		if (LSPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
 		uint32_t e = a.tab[sl];
 		if (e == DSB_WTAB_EMPTY) break;
 		if ((e >> 12) == k32) { if (nc < DSB_SDP_CAND) cand[nc++] = a.q_bg + (e & 0xfffu); else many = true; }
-		sl = sl + 1 == DSB_WTAB_SLOTS ? 0 : sl + 1;
+		sl = sl + 1 == slots ? 0 : sl + 1;
 	}
 	if (!many)
 		for (int u = 1; u < nc; u++) { uint32_t v = cand[u]; int z = u - 1; while (z >= 0 && cand[z] > v) { cand[z + 1] = cand[z]; z--; } cand[z + 1] = v; }
@@ -1126,7 +1149,7 @@ DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out, uint32_t ou
 				uint32_t e = a.tab[sl];
 				if (e == DSB_WTAB_EMPTY) break;
 				if ((e >> 12) == k32) { int64_t qp = (int64_t)a.q_bg + (e & 0xfffu); if (qp > last && (best < 0 || qp < best)) best = qp; }
-				sl = sl + 1 == DSB_WTAB_SLOTS ? 0 : sl + 1;
+				sl = sl + 1 == slots ? 0 : sl + 1;
 			}
 			if (best < 0) break;
 			q_pos = (uint32_t)best; last = best;
@@ -1468,6 +1491,35 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 			p->q_pos = A[c_a].index_in_read; p->t_pos = A[c_a].ref_offset; p->len = A[c_a].mtch_len - 9 + 1;
 			if (w.n_sms > 1) {
 				DsbSms *S = w.sms;
+#ifndef DSB_HOST_EMU
+				if (w.n_sms <= (uint32_t)DSB_WAVE && DSB_GROUP == 64) {
+					// small gap (the usual case): one node per lane, the whole DP in registers.  Lane ci's node is
+					// broadcast, lanes < ci judge their own node as its predecessor (sdp_best_pred<0> semantics:
+					// no distance cut), wave max; nothing is written back -- the list is local to this gap.
+					const uint32_t nn = w.n_sms;
+					DsbSms me; if ((uint32_t)w.lane < nn) me = S[w.lane]; else { me.t_pos = me.q_pos = me.len = 0; }
+					me.score = (w.lane == 0) ? (uint32_t)score : 0u;
+					for (uint32_t ci = 1; ci < nn; ci++) {
+						DsbSms cs; cs.t_pos = dsb_shfl(me.t_pos, (int)ci); cs.q_pos = dsb_shfl(me.q_pos, (int)ci); cs.len = dsb_shfl(me.len, (int)ci); cs.score = 0;
+						uint32_t lim_q = cs.q_pos + 6, lim_t = cs.t_pos + 6;
+						int cand = (int)cs.len;
+						if ((uint32_t)w.lane < ci) {
+							int pre_q_ed = me.q_pos + me.len + 9 - 1, pre_t_ed = me.t_pos + me.len + 9 - 1;
+							if (!((uint32_t)pre_q_ed > lim_q) && !((uint32_t)pre_t_ed > lim_t)) {
+								int indel = me.q_pos - me.t_pos - (lim_q - lim_t); int ai = ABSV(indel);
+								if (ai <= 200) {
+									int ns = me.score + cs.len - (ai >> 3);
+									if ((uint32_t)pre_q_ed > cs.q_pos || (uint32_t)pre_t_ed > cs.t_pos) { int oq = pre_q_ed - cs.q_pos, ot = pre_t_ed - cs.t_pos; ns -= MAXV(oq, ot); }
+									cand = MAXV(cand, ns);
+								}
+							}
+						}
+						int max_score = grp_max_i(w.red, w.lane, cand);
+						if ((uint32_t)w.lane == ci) me.score = (uint32_t)max_score;
+						score = MAXV(max_score, score);
+					}
+				} else
+#endif
 				for (uint32_t ci = 1; ci < w.n_sms; ci++) {
 					DsbSms cs = S[ci];
 					int max_score = sdp_best_pred<0>(w, cs, (int32_t)ci);
@@ -1721,7 +1773,7 @@ DN void detect_primary(WCtx &w, uint32_t read_len)
 {
 	DsbChain *hit = w.hit; uint32_t n_hit = w.n_hit;
 	if (n_hit == 0) return;
-	int *primary_v = w.score_v; uint8_t *primary_v_idx = reinterpret_cast<uint8_t *>(w.spset); int n_primary_v = 1;
+	int *primary_v = w.score_v; uint8_t *primary_v_idx = w.win_mid;   /* 800 bytes of scratch; the window is idle here */ int n_primary_v = 1;
 	hit->pri_index = primary_v_idx[0] = 0; primary_v[0] = 0; hit->primary = 1;
 	DsbChain *ed_hit = hit + n_hit;
 	for (DsbChain *c = hit; c < ed_hit; c++) if (c->q_st > 4294960000u) c->q_st = 0;

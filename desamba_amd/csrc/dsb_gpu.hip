@@ -196,7 +196,11 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	w.win_mid = slot + ar.off_win; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;         \
 	w.lane_anc = (DsbAnchor *)(slot + ar.off_lane_anc); w.lane_spset = (uint64_t *)(slot + ar.off_lane_sp);             \
 	w.top_idx = (uint32_t *)(slot + ar.off_top); w.round_info = (uint32_t *)(slot + ar.off_round);                      \
-	w.anc_cap = DSB_ANC_CAP;                                                                                            \
+	w.anc_cap = DSB_ANC_CAP; w.sp_gen = 0;                                                                              \
+	/* visited-row sets are generation-tagged: clear them once per launch */                                          \
+	for (uint32_t i = lane; i < (uint32_t)THREADS * DSB_SPHASH; i += THREADS) w.lane_spset[i] = 0;                       \
+	for (uint32_t i = lane; i < DSB_SPHASH; i += THREADS) w.spset[i] = 0;                                                \
+	__syncthreads();                                                                                                    \
 	const unsigned int n_items = n_ptr ? *n_ptr : n_fixed;                                                              \
 	if (w.dbg && lane == 0) w.dbg[0] = 300;                                                                             \
 	for (;;) {                                                                                                          \
@@ -354,13 +358,13 @@ static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int n_s
 	a.off_kh = o;
 	a.off_sc = o;      o += al256((size_t)(256 + 2 * 400 + 64) * sizeof(DsbScHash));
 	a.off_mem = o;     o += al256((size_t)DSB_MEMSLOW_CAP * sizeof(DsbMem));
-	a.off_spset = o;   o += al256((size_t)DSB_SPSET_CAP * 8);
+	a.off_spset = o;   o += al256((size_t)DSB_SPHASH * 8);
 	a.off_scorev = o;  o += al256((size_t)1024 * sizeof(int));
 	a.off_sortkey = o; o += al256((size_t)2 * DSB_ANC_CAP * sizeof(uint64_t));
 	a.off_sortidx = o; o += al256((size_t)2 * DSB_ANC_CAP * sizeof(uint32_t));
 	a.off_win = o;     o += al256((size_t)3 * DSB_REFWIN);
 	a.off_lane_anc = o; o += al256((size_t)group * DSB_LANE_ANC_CAP * sizeof(DsbAnchor));
-	a.off_lane_sp = o;  o += al256((size_t)group * 512 * 8);
+	a.off_lane_sp = o;  o += al256((size_t)group * DSB_SPHASH * 8);
 	a.off_top = o;      o += al256(((size_t)(max_len >> 1) + 64) * 4);
 	a.off_round = o;    o += al256((size_t)group * 4);
 	a.stride = al256(o);
@@ -528,7 +532,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 			for (size_t r = 0; r < n && r < 65536; r++) { uint64_t sm = 0; for (int i = 0; i < 10; i++) sm += c->dbg_host[16 * 65536 + 14 * r + i]; if (sm > wsum) { wsum = sm; worst = r; } }
 			fprintf(stderr, "[dsb] slowest read %zu: %.1f ms:", worst, wsum / 1e3);
 			for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.1f", nm[i], c->dbg_host[16 * 65536 + 14 * worst + i] / 1e3);
-			fprintf(stderr, " | sdp_match %.1f dp %.1f combine %.1f\n", c->dbg_host[16 * 65536 + 14 * worst + 10] / 1e3, c->dbg_host[16 * 65536 + 14 * worst + 11] / 1e3, c->dbg_host[16 * 65536 + 14 * worst + 12] / 1e3);
+			fprintf(stderr, " | in right/left: sdp_match %.1f dp %.1f combine %.1f\n", c->dbg_host[16 * 65536 + 14 * worst + 10] / 1e3, c->dbg_host[16 * 65536 + 14 * worst + 11] / 1e3, c->dbg_host[16 * 65536 + 14 * worst + 12] / 1e3);
 		}
 		fprintf(stderr, "[dsb] classify stage time (wave-seconds, %% of total %.2f s):", all / 1e6);
 		for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * tot[i] / (all > 0 ? all : 1));

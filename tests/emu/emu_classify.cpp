@@ -47,11 +47,12 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	add(256);                                                            // 6 (unused)
 	add((size_t)(256 + 2 * 400 + 64) * sizeof(DsbScHash));               // 7
 	add((size_t)DSB_MEMSLOW_CAP * sizeof(DsbMem));                       // 8
-	add((size_t)DSB_SPSET_CAP * 8); add(1024 * sizeof(int));             // 9,10
+	add((size_t)DSB_SPHASH * 8); add(1024 * sizeof(int));                // 9,10
 	add((size_t)2 * DSB_ANC_CAP * 8); add((size_t)2 * DSB_ANC_CAP * 4);  // 11,12
 	add(3 * DSB_REFWIN);                                                 // 13
-	add((size_t)DSB_LANE_ANC_CAP * sizeof(DsbAnchor)); add(512 * 8); add(((size_t)(e->max_len >> 1) + 64) * 4);   // 14,15,16 (1 lane)
+	add((size_t)DSB_LANE_ANC_CAP * sizeof(DsbAnchor)); add((size_t)DSB_SPHASH * 8); add(((size_t)(e->max_len >> 1) + 64) * 4);   // 14,15,16 (1 lane)
 	e->arena.assign(o + 256, 0xCD);
+	memset(e->arena.data() + off[9], 0, DSB_SPHASH * 8); memset(e->arena.data() + off[15], 0, DSB_SPHASH * 8); e->w.sp_gen = 0;
 	uint8_t *s = e->arena.data(); WCtx &w = e->w;
 	w.x = &e->dx; w.lane = 0; w.dbg = nullptr;
 	w.seeds = (DsbSeed *)(s + off[0]); w.anc = (DsbAnchor *)(s + off[1]); w.anc_tmp = (DsbAnchor *)(s + off[2]);
