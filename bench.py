@@ -12,6 +12,8 @@ Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel of the 
 `roofline_seed_lookup` the seed-lookup kernel the north star names; both use ALGORITHMIC bytes
  over the kernel's HIP-event time.  `cpu_baseline` times the unmodified
 reference binary (oracle/_ref/deSAMBA classify -t <cores>) on a bounded sample of the same reads.
+The demo index itself is input data: index CONSTRUCTION is out of scope and is done once by
+tools/make_demo_index.sh with the reference binary; nothing of oracle/ is on the measured path.
 """
 import argparse
 import json

@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(1024) k_order(const uint32_t *score, uint32_t 
 struct DsbSlotArena {
 	uint8_t *base; size_t stride;                 // per-slot bytes
 	size_t off_seeds, off_anc, off_anc_tmp, off_hit, off_hit_tmp, off_sms, off_kh, off_sc, off_mem, off_spset, off_scorev,
-	       off_sortkey, off_sortidx, off_win, off_lane_anc, off_lane_sp, off_top, off_round;
+	       off_sortkey, off_sortidx, off_win, off_lane_anc, off_lane_sp, off_top, off_round;   /* off_kh: unused since the 9-mer tables moved to LDS */
 	uint32_t max_len;                             // longest read the arena was sized for
 };
 
