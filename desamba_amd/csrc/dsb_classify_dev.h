@@ -192,6 +192,22 @@ struct WCtx {
 	SDir sd[2];
 };
 
+// Serial sections: stretches of the per-read logic with no lane-level parallelism run on lane 0 alone, so that
+// their loads and stores are one-address memory instructions instead of 64 copies of the same address going
+// through the CU's address pipeline; serial_end() broadcasts the scalars such a section may change.
+#ifdef DSB_HOST_EMU
+#define DSB_SERIAL(w) if (true)
+DV void serial_end(WCtx &) {}
+#else
+#define DSB_SERIAL(w) if ((w).lane == 0)
+DV void serial_end(WCtx &w)
+{
+	w.n_hit = dsb_shfl(w.n_hit, 0); w.status = dsb_shfl(w.status, 0); w.max_read_l = dsb_shfl(w.max_read_l, 0);
+	w.steps = dsb_shfl(w.steps, 0);
+	wave_sync();
+}
+#endif
+
 // ---- hashes (src/lib/utils.c:1067-1091) ---------------------------------------------------
 DV uint64_t d_hash64_1(uint64_t key)
 {
@@ -605,7 +621,7 @@ DV uint32_t run_ones_down(const uint64_t *bits, int start, uint32_t maxc)
 }
 #define DSB_M3 0x9249249249249249ULL      /* bits 0,3,6,...,63 */
 
-DN void seed_vector(WCtx &w, uint8_t *bin, const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t direction, SDir *out)
+DN void seed_vector_scan(const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t direction, uint32_t *ns_out, uint32_t *total_out)
 {
 	// Same scan as search_exist_kmer_M2 (probe every 3rd window, extend back <= 2, forward to len 61,
 	// resume 3 past the seed), but 64 windows per load: the next probe hit is a ctz over the word
@@ -655,6 +671,14 @@ DN void seed_vector(WCtx &w, uint8_t *bin, const uint64_t *bits, uint32_t n, Dsb
 	}
 	sv[max_index].top = 1;
 	total += max_length;
+	*ns_out = ns; *total_out = total;
+}
+DV void seed_vector(WCtx &w, uint8_t *bin, const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t direction, SDir *out)
+{
+	uint32_t ns = 0, total = 0;
+	DSB_SERIAL(w) seed_vector_scan(bits, n, sv, direction, &ns, &total);
+	ns = dsb_shfl(ns, 0); total = dsb_shfl(total, 0);
+	wave_sync();
 	out->seed_v = sv; out->l_seed_v = ns; out->bin_read = bin; out->bits = bits; out->direction = direction; out->total_score = total;
 }
 
@@ -856,7 +880,7 @@ DN uint32_t *stable_sort_keys(WCtx &w, uint32_t n)
 }
 
 // chain_insert_M3 (src/cly.c:238-323): stable sort by (ref_ID, direction, ref_offset), then sparse DP per group
-DN void chain_insert_M3(WCtx &w)
+DN void chain_sort_M3(WCtx &w)
 {
 	DsbAnchor *A = w.anc; int32_t n = w.n_anc;
 	for (int32_t i = w.lane; i < n; i += DSB_WAVE) {
@@ -869,6 +893,11 @@ DN void chain_insert_M3(WCtx &w)
 	wave_sync();
 	for (int32_t i = w.lane; i < n; i += DSB_WAVE) A[i] = w.anc_tmp[i];
 	wave_sync();
+}
+// ... and its serial part (one lane)
+DN void chain_dp_M3(WCtx &w)
+{
+	DsbAnchor *A = w.anc; int32_t n = w.n_anc;
 	int *score_v = w.score_v;
 	for (int32_t st = 0; st < n;) {
 		int32_t ed = st + 1;
@@ -977,12 +1006,16 @@ DN void glibc_sort_chains(WCtx &w, uint32_t n)
 DN void resolve_tree(WCtx &w)
 {
 	w.n_hit = 0;
-	if (w.n_anc < 50) for (uint32_t i = 0; i < w.n_anc; i++) chain_insert_M2(w, i);
-	else chain_insert_M3(w);
-	if (w.n_hit > 1) glibc_sort_chains<0>(w, w.n_hit);
-	int rst_num = MINV(5, w.n_hit);
-	while (rst_num < w.n_hit && w.hit[rst_num].with_top_anchor == 1) rst_num++;
-	w.n_hit = rst_num;
+	if (w.n_anc >= 50) chain_sort_M3(w);
+	DSB_SERIAL(w) {
+		if (w.n_anc < 50) for (uint32_t i = 0; i < w.n_anc; i++) chain_insert_M2(w, i);
+		else chain_dp_M3(w);
+		if (w.n_hit > 1) glibc_sort_chains<0>(w, w.n_hit);
+		int rst_num = MINV(5, w.n_hit);
+		while (rst_num < w.n_hit && w.hit[rst_num].with_top_anchor == 1) rst_num++;
+		w.n_hit = rst_num;
+	}
+	serial_end(w);
 }
 
 // ---- sc_hash_idx / combine_chain (src/cly.c:1691-1710,1763-1808) -------------------------------
@@ -1721,14 +1754,18 @@ DN void delete_small_score_rst(WCtx &w, SDir *sd, uint32_t l_read)
 {
 	const DsbDevIndex *x = w.x;
 	if (w.n_hit == 0) return;
-	if (w.n_hit > 200) {
-		uint32_t r = 200;
-		for (; r < w.n_hit && w.hit[r].sum_score > 50; r++);
-		w.n_hit = r;
+	DSB_SERIAL(w) {
+		if (w.n_hit > 200) {
+			uint32_t r = 200;
+			for (; r < w.n_hit && w.hit[r].sum_score > 50; r++);
+			w.n_hit = r;
+		}
+		w.n_hit = MINV(400u, w.n_hit);
+		sc_hash_idx(w.sc, w.hit, w.n_hit);
 	}
-	w.n_hit = MINV(400u, w.n_hit);
-	sc_hash_idx(w.sc, w.hit, w.n_hit);
+	serial_end(w);
 	get_score_M2(w, sd, l_read, w.sc);
+	DSB_SERIAL(w) {
 	DsbChain *st_c = w.hit, *ed_c = st_c + w.n_hit, *c_c;
 	if (w.n_hit > 1) glibc_sort_chains<1>(w, w.n_hit);
 	for (c_c = st_c; c_c < ed_c - 1; c_c++) {
@@ -1766,6 +1803,8 @@ DN void delete_small_score_rst(WCtx &w, SDir *sd, uint32_t l_read)
 	if (w.n_hit > 1) glibc_sort_chains<2>(w, w.n_hit);
 	for (c_c = st_c; c_c < ed_c; c_c++) if (c_c->sum_score == 0) break;
 	w.n_hit = c_c - st_c;
+	}
+	serial_end(w);
 }
 
 // detect_primary (src/cly.c:2995-3058); the primary list lives in score_v (ints) / spset (bytes)
@@ -1849,7 +1888,8 @@ DN uint32_t classify_read(WCtx &w, const uint64_t *bitsF, const uint64_t *bitsR)
 	delete_small_score_rst(w, sd, read_len);
 	TICK(w, 8);
 	w.stage = 6; MARK(w, 6);
-	detect_primary(w, read_len);
+	DSB_SERIAL(w) detect_primary(w, read_len);
+	serial_end(w);
 	w.stage = 7; MARK(w, 7);
 	TICK(w, 9);
 	return fast;

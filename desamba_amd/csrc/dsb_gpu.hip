@@ -77,30 +77,84 @@ __global__ void __launch_bounds__(256) k_encode_pack(const DsbReadDesc *rd, cons
 }
 
 // seed-lookup kernel.  Each wave takes word descriptors (64 windows of one read strand) in a grid-stride loop.
-__global__ void __launch_bounds__(256) k_seed_probe(DsbDevIndex x, const DsbReadDesc *rd, const DsbWordDesc *wd, uint64_t n_words_total,
-                                                    const uint64_t *pk, uint64_t *bits, unsigned long long *probe_counters)
+// Summary of exist table 0, built once when the index is staged: bit g is the OR of table bits [g << shift,
+// (g+1) << shift), shift 3..6, so that the summary (2 MiB at shift 6 for the 128 MiB table) stays resident in
+// L2 / Infinity Cache.  Thread t produces summary byte t.
+__global__ void __launch_bounds__(256) k_ek_summary(const uint8_t *ek0, uint64_t n_bytes_out, int shift, uint8_t *summ)
+{
+	uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= n_bytes_out) return;
+	const uint32_t gb = 1u << (shift - 3);                 // table bytes per summary bit (1..32)
+	const uint8_t *src = ek0 + t * 8 * gb;
+	uint32_t o = 0;
+	for (uint32_t j = 0; j < 8; j++) {
+		uint32_t any = 0;
+		for (uint32_t b = 0; b < gb; b++) any |= src[j * gb + b];
+		if (any) o |= 1u << j;
+	}
+	summ[t] = (uint8_t)o;
+}
+
+// DSB_PROBE_UN word descriptors per wave iteration: the loads of each stage (packed words, summary, table 0,
+// table 1) are issued for all of them before the first is consumed, so a wave keeps UN gathers in flight.
+#define DSB_PROBE_UN 4
+__global__ void __launch_bounds__(256) k_seed_probe(DsbDevIndex x, const DsbReadDesc *__restrict__ rd, const DsbWordDesc *__restrict__ wd, uint64_t n_words_total,
+                                                    const uint64_t *__restrict__ pk, uint64_t *__restrict__ bits, unsigned long long *probe_counters,
+                                                    const uint8_t *__restrict__ summ, int summ_shift)
 {
 	const int lane = threadIdx.x & 63;
-	const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const uint64_t wave = __builtin_amdgcn_readfirstlane((uint32_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
 	const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
 	const int k = x.ek_len; const int sbm = x.single_base_max;
 	const uint64_t kmask = k >= 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
 	unsigned long long p1_local = 0;
-	for (uint64_t wI = wave; wI < n_words_total; wI += n_waves) {
-		DsbWordDesc w = wd[wI];
-		DsbReadDesc d = rd[w.read];
-		uint32_t strand_r = w.word >> 31, wi = w.word & 0x7fffffffu;
-		uint32_t nwp = (d.len + 31) / 32 + 1;
-		const uint64_t *P = pk + d.pk_off + (strand_r ? nwp : 0);
-		uint32_t p = wi * 64 + lane;
-		int hit = 0;
-		if (p < d.n_win) {
-			int went_t1 = 0;
-			hit = dsb_probe_window(P, p, k, kmask, sbm, x.ek0, x.ek1, x.ek_mask, &went_t1);
-			p1_local += went_t1;
+	for (uint64_t w0 = wave * DSB_PROBE_UN; w0 < n_words_total; w0 += n_waves * DSB_PROBE_UN) {
+		uint64_t kmer[DSB_PROBE_UN], h1[DSB_PROBE_UN], out_idx[DSB_PROBE_UN];
+		bool live[DSB_PROBE_UN], have[DSB_PROBE_UN];
+		// stage 1: descriptors, packed words -> k-mer, low-complexity filter (store_kmers, src/cly.c:360-398)
+#pragma unroll
+		for (int u = 0; u < DSB_PROBE_UN; u++) {
+			have[u] = w0 + u < n_words_total; live[u] = false; kmer[u] = 0; out_idx[u] = 0;
+			if (!have[u]) continue;
+			DsbWordDesc w = wd[w0 + u];
+			const DsbReadDesc &d = rd[w.read];
+			uint32_t strand_r = w.word >> 31, wi = w.word & 0x7fffffffu;
+			uint32_t nwp = (d.len + 31) / 32 + 1;
+			const uint64_t *P = pk + d.pk_off + (strand_r ? nwp : 0);
+			out_idx[u] = d.bit_off + (strand_r ? d.n_words : 0) + wi;
+			uint32_t p = wi * 64 + lane;
+			if (p < d.n_win) {
+				uint64_t a = P[p >> 5], b = P[(p >> 5) + 1]; uint32_t sh = (p & 31) * 2;
+				uint64_t hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
+				uint64_t km = (hi >> (64 - 2 * k)) & kmask;
+				live[u] = dsb_kmer_ok(km, k, sbm); kmer[u] = km;
+			}
 		}
-		uint64_t word = __ballot(hit);
-		if (lane == 0) bits[d.bit_off + (strand_r ? d.n_words : 0) + wi] = word;
+		// stage 2: summary of table 0 (L2 resident)
+		uint8_t sv[DSB_PROBE_UN];
+#pragma unroll
+		for (int u = 0; u < DSB_PROBE_UN; u++) {
+			h1[u] = dsb_ph1(kmer[u]) & x.ek_mask; sv[u] = 0xff;
+			if (live[u] && summ) sv[u] = summ[(h1[u] >> summ_shift) >> 3];
+		}
+#pragma unroll
+		for (int u = 0; u < DSB_PROBE_UN; u++) live[u] = live[u] && ((sv[u] >> ((h1[u] >> summ_shift) & 7)) & 1);
+		// stage 3: table 0 (get_exist_kmer, src/cly.c:956-972)
+		uint8_t t0[DSB_PROBE_UN];
+#pragma unroll
+		for (int u = 0; u < DSB_PROBE_UN; u++) { t0[u] = 0; if (live[u]) t0[u] = x.ek0[h1[u] >> 3]; }
+#pragma unroll
+		for (int u = 0; u < DSB_PROBE_UN; u++) live[u] = live[u] && ((t0[u] >> (7 - (h1[u] & 7))) & 1);
+		// stage 4: table 1
+		uint8_t t1[DSB_PROBE_UN]; uint64_t h2[DSB_PROBE_UN];
+#pragma unroll
+		for (int u = 0; u < DSB_PROBE_UN; u++) { t1[u] = 0; h2[u] = dsb_ph2(kmer[u]) & x.ek_mask; if (live[u]) { t1[u] = x.ek1[h2[u] >> 3]; p1_local++; } }
+#pragma unroll
+		for (int u = 0; u < DSB_PROBE_UN; u++) {
+			int hit = live[u] && ((t1[u] >> (7 - (h2[u] & 7))) & 1);
+			uint64_t word = __ballot(hit);
+			if (lane == 0 && have[u]) bits[out_idx[u]] = word;
+		}
 	}
 	if (probe_counters) {
 		// wave-reduce, one atomic per wave
@@ -253,6 +307,7 @@ struct dsb_ctx {
 	unsigned int *d_counters;                      // [0] work, [1] hits; +8: u64 p1 counter
 	DsbSlotArena arena; size_t arena_bytes; int n_slots;
 	uint32_t *d_score, *d_order; size_t cap_score, cap_order;
+	uint8_t *d_summ; int summ_shift;               // cache-resident summary of exist table 0 (k_ek_summary); null = off
 	// host mirrors
 	std::vector<DsbReadDesc> h_rd; std::vector<DsbWordDesc> h_wd;
 	std::vector<DsbReadOut> h_rout; std::vector<DsbHitOut> h_hout;
@@ -296,6 +351,17 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	if ((rc = dev_upload(c, h->ek0, h->ek_size, &dx.ek0))) return rc;
 	if ((rc = dev_upload(c, h->ek1, h->ek_size, &dx.ek1))) return rc;
 	dx.ek_mask = h->ek_mask; dx.ek_len = h->ek_len; dx.single_base_max = h->single_base_max;
+	{
+		// DSB_EK_SUMMARY=0 turns the summary off, 3..6 choose its granularity
+		const char *lv = getenv("DSB_EK_SUMMARY"); int shift = lv ? atoi(lv) : 6;
+		if (shift >= 3 && shift <= 8 && (h->ek_size >> (shift - 3)) >= 4096) {
+			uint64_t n_out = h->ek_size >> shift;              // table bits / 2^shift / 8
+			HIPCHK(hipMalloc((void **)&c->d_summ, n_out + 256)); c->dev_allocs.push_back(c->d_summ);
+			hipLaunchKernelGGL(k_ek_summary, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream, dx.ek0, n_out, shift, c->d_summ);
+			HIPCHK(hipStreamSynchronize(c->stream));
+			c->summ_shift = shift;
+		}
+	}
 	if ((rc = dev_upload(c, h->fm, h->n_fm, &dx.fm))) return rc;
 	dx.bwt_len = h->bwt_len; memcpy(dx.rank, h->rank, sizeof dx.rank); dx.dollar_pos = h->dollar_pos; dx.dollar_row = h->dollar_row;
 	if ((rc = dev_upload(c, h->hash_index, ((size_t)1 << 26) + 1, &dx.hash_index))) return rc;
@@ -490,10 +556,10 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	const bool dbg = getenv("DSB_DEBUG") != NULL;
 	if (dbg) { HIPCHK(hipStreamSynchronize(c->stream)); fprintf(stderr, "[dsb] encode done\n"); }
 	if (c->n_words_total) {
-		uint64_t waves = c->n_words_total; unsigned blocks = (unsigned)((waves + 3) / 4);
+		uint64_t waves = (c->n_words_total + DSB_PROBE_UN - 1) / DSB_PROBE_UN; unsigned blocks = (unsigned)((waves + 3) / 4);
 		if (blocks > 256u * 32u) blocks = 256u * 32u;       // >= 8 blocks of 4 waves per CU, grid-stride beyond
 		hipLaunchKernelGGL(k_seed_probe, dim3(blocks), dim3(256), 0, c->stream, c->dx, c->d_rd, c->d_wd, c->n_words_total, c->d_pk, c->d_bits,
-		                   (unsigned long long *)(c->d_counters + 2));
+		                   (unsigned long long *)(c->d_counters + 2), c->d_summ, c->summ_shift);
 	}
 	HIPCHK(hipEventRecord(c->ev[2], c->stream));
 	if (dbg) { HIPCHK(hipStreamSynchronize(c->stream)); fprintf(stderr, "[dsb] seed probe done\n"); }

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Collect rocprofv3 PMC counters for the bench workload, one pass per counter group (PMC only, no tracing).
+#   tools/pmc_run.sh <tag> <reads> "<CTR CTR ...>" ["<CTR ...>" ...]
+# Writes gpurun_out/pmc_<tag>.json: per-kernel sums over all dispatches of every counter.
+set -e -o pipefail
+cd "$(dirname "$0")/.."
+ROOT=$PWD
+tag=$1; reads=$2; shift 2
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+i=0
+for grp in "$@"; do
+	out=$ROOT/gpurun_out/pmc_${tag}_$i
+	rm -rf "$out"
+	(cd /tmp && timeout -k 10 120 rocprofv3 --pmc $grp -d "$out" -o run --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 1 --warmup 0 --reads-per-gpu "$reads" > "$out.log" 2>&1)
+	i=$((i+1))
+done
+python3 - "$tag" "$reads" <<'EOF'
+import csv, glob, json, sys, collections
+tag, reads = sys.argv[1], int(sys.argv[2])
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob("gpurun_out/pmc_%s_*/**/*counter_collection.csv" % tag, recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if k.startswith("k_"):
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+json.dump({"workload": "%d x 50 kbp ONT reads, bench.py --steps 1 --warmup 0" % reads, "counters": acc}, open("gpurun_out/pmc_%s.json" % tag, "w"), indent=1, sort_keys=True)
+print(json.dumps(acc.get("k_classify", {}), indent=1, sort_keys=True))
+EOF
