@@ -270,13 +270,20 @@ DV void get_ref_small(const uint8_t *txt, uint8_t *out, int64_t off, int32_t len
 }
 // forward window of any length, lanes split the bases; caller must wave_sync() before reading
 DV void get_ref_wave(const WCtx &w, uint8_t *out, int64_t off, int32_t length)
-{
+{	// `out` is 8-byte aligned (window buffers in the arena or in LDS): a lane unpacks 8 bases per step from one
+	// unaligned 4-byte load of the 2-bit text (refbin carries a 4 KiB zero pad) and stores them as one u64
 	if (off < 0) off = 0;
 	if (length < 0) length = 0;
 	const uint8_t *txt = w.x->refbin;
-	for (int32_t k = w.lane; k < length; k += DSB_WAVE) {
+	for (int32_t k = 8 * w.lane; k < length; k += 8 * DSB_WAVE) {
 		uint64_t p = (uint64_t)off + (uint32_t)k;
-		out[k] = (txt[p >> 2] >> (6 - 2 * (p & 3))) & 3;
+		uint32_t raw; __builtin_memcpy(&raw, txt + (p >> 2), 4);
+		uint32_t v = __builtin_bswap32(raw), s = (uint32_t)p & 3u;
+		uint64_t o = 0;
+#pragma unroll
+		for (int m = 0; m < 8; m++) o |= (uint64_t)((v >> (30 - 2 * (s + m))) & 3u) << (8 * m);
+		if (k + 8 <= length) *reinterpret_cast<uint64_t *>(out + k) = o;
+		else for (int m = 0; k + m < length; m++) out[k + m] = (uint8_t)(o >> (8 * m));
 	}
 }
 
@@ -676,7 +683,17 @@ DN void seed_vector_scan(const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t
 DV void seed_vector(WCtx &w, uint8_t *bin, const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t direction, SDir *out)
 {
 	uint32_t ns = 0, total = 0;
-	DSB_SERIAL(w) seed_vector_scan(bits, n, sv, direction, &ns, &total);
+	// the scan is a chain of dependent loads of the hit-bit words: stage them in LDS (the window table is idle
+	// here) when the strand fits
+	const uint64_t *src = bits; const uint32_t n_words = (n + 63) >> 6;
+	if (w.wtab && n_words + 1 <= DSB_WTAB_SLOTS / 2) {
+		uint64_t *l = reinterpret_cast<uint64_t *>(w.wtab);
+		for (uint32_t i = w.lane; i < n_words; i += DSB_WAVE) l[i] = bits[i];
+		if (w.lane == 0) l[n_words] = 0;
+		wave_sync();
+		src = l;
+	}
+	DSB_SERIAL(w) seed_vector_scan(src, n, sv, direction, &ns, &total);
 	ns = dsb_shfl(ns, 0); total = dsb_shfl(total, 0);
 	wave_sync();
 	out->seed_v = sv; out->l_seed_v = ns; out->bin_read = bin; out->bits = bits; out->direction = direction; out->total_score = total;
@@ -1061,26 +1078,40 @@ DV bool combine_chain(DsbChain *c_st, int chain_ID, DsbScHash *sc, int dis, bool
 // for exactly that window, in LDS: open addressing, entry = kmer << 12 | (pos - q_bg).  A lookup collects
 // the entries of its 9-mer and visits them in ascending position = the reference's chain order.  No global
 // memory is touched besides the read bytes themselves.
+DV uint64_t ld_u64(const uint8_t *p)
+{	// unaligned 8-byte load (byte buffers: read strands with pads, reference windows with pads)
+	uint64_t v;
+	__builtin_memcpy(&v, p, 8);
+	return v;
+}
+// the window table is addressed as LDS (ds_read / ds_cmpst), not through generic pointers
+#ifdef DSB_HOST_EMU
+typedef uint32_t lds_u32;
+#else
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+#endif
 DV uint32_t wtab_slot(uint32_t kmer, uint32_t slots) { return (uint32_t)(((uint64_t)(kmer * 2654435761u) * slots) >> 32); }
 // slots used for a window of n_q positions: load factor <= 0.5 for small windows, the whole table for big ones
 DV uint32_t wtab_size(uint32_t n_q) { uint32_t s = 2 * n_q; return s < 64u ? 64u : (s > DSB_WTAB_SLOTS ? DSB_WTAB_SLOTS : s); }
 
-DN void wtab_build(WCtx &w, const uint8_t *q_str, uint32_t q_bg, uint32_t n_q)
+DN void wtab_build(lds_u32 *tab, int lane, const uint8_t *q_str, uint32_t q_bg, uint32_t n_q)
 {
 	const uint32_t slots = wtab_size(n_q);
-	for (uint32_t i = w.lane; i < slots; i += DSB_WAVE) w.wtab[i] = DSB_WTAB_EMPTY;
+	for (uint32_t i = lane; i < slots; i += DSB_WAVE) tab[i] = DSB_WTAB_EMPTY;
 	wave_sync();
-	for (uint32_t r = w.lane; r < n_q; r += DSB_WAVE) {
+	for (uint32_t r = lane; r < n_q; r += DSB_WAVE) {
 		const uint8_t *q = q_str + q_bg + r;
-		uint32_t k = 0;
+		uint64_t v = ld_u64(q); uint32_t k = 0;
 #pragma unroll
-		for (int b = 0; b < 9; b++) k = (k << 2) | q[b];
+		for (int b = 0; b < 8; b++) k = (k << 2) | (uint32_t)((v >> (8 * b)) & 0xffu);
+		k = (k << 2) | q[8];
 		uint32_t e = (k << 12) | r, sl = wtab_slot(k, slots);
 		for (;;) {
 #ifdef DSB_HOST_EMU
-			uint32_t old = w.wtab[sl]; if (old == DSB_WTAB_EMPTY) w.wtab[sl] = e;
+			uint32_t old = tab[sl]; if (old == DSB_WTAB_EMPTY) tab[sl] = e;
 #else
-			uint32_t old = atomicCAS(&w.wtab[sl], DSB_WTAB_EMPTY, e);
+			uint32_t old = DSB_WTAB_EMPTY;
+			__hip_atomic_compare_exchange_strong(tab + sl, &old, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 			if (old == DSB_WTAB_EMPTY) break;
 			sl = sl + 1 == slots ? 0 : sl + 1;
@@ -1089,12 +1120,6 @@ DN void wtab_build(WCtx &w, const uint8_t *q_str, uint32_t q_bg, uint32_t n_q)
 	wave_sync();
 }
 
-DV uint64_t ld_u64(const uint8_t *p)
-{	// unaligned 8-byte load (byte buffers: read strands with pads, reference windows with pads)
-	uint64_t v;
-	__builtin_memcpy(&v, p, 8);
-	return v;
-}
 // MEM_search (src/cly.c:1810-1818): length of the exact match, at most max, walking forward from (q,t)
 // or backward.  Eight bases per step; every buffer it is used on has >= 8 readable bytes past the
 // compared range on either side (pads), and bytes beyond `max` are ignored.
@@ -1138,22 +1163,26 @@ DV uint64_t bin2kmer9(const uint8_t *s) { uint64_t v = 0;
 #define DSB_SDP_KEEP 3
 #define DSB_DP_UNROLL 4
 #define DSB_RING 16      /* recent DP nodes kept in LDS: the in-batch predecessors of the batched DP */
-struct SdpArgs { uint32_t q_bg, q_ed; const uint8_t *q_str, *t_str; uint32_t t_len, t_st; const uint32_t *tab; uint32_t n_q; };
+struct SdpArgs { uint32_t q_bg, q_ed; const uint8_t *q_str, *t_str; uint32_t t_len, t_st; const lds_u32 *tab; uint32_t n_q; };
 
 template <bool FWD, bool WRITE>
-DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out, uint32_t out_cap)
+DV uint32_t sdp_visit(uint32_t &lsteps, int &st, const SdpArgs &a, int i, DsbSms *out, uint32_t out_cap)
 {
 	uint32_t cnt = 0;
 	const uint8_t *c_t; uint64_t kmer = 0;
 	if (FWD) {
 		c_t = a.t_str + i;
+		uint64_t v = ld_u64(c_t);
 #pragma unroll
-		for (int j = 0; j < 9; j++) kmer |= (uint64_t)c_t[j] << (16 - 2 * j);
+		for (int j = 0; j < 8; j++) kmer |= ((v >> (8 * j)) & 0xffULL) << (16 - 2 * j);
+		kmer |= (uint64_t)c_t[8];
 		kmer &= 0x3FFFFULL;
 	} else {
 		c_t = a.t_str + (a.t_len - 9 - 4) - (i - 4);
+		uint64_t v = ld_u64(c_t);
 #pragma unroll
-		for (int j = 0; j < 9; j++) kmer |= (uint64_t)c_t[j] << (16 - 2 * j);
+		for (int j = 0; j < 8; j++) kmer |= ((v >> (8 * j)) & 0xffULL) << (16 - 2 * j);
+		kmer |= (uint64_t)c_t[8];
 		if (i > 4) kmer |= (uint64_t)(c_t[9] >> 2);
 	}
 	// collect the window positions holding this 9-mer, then visit them in ascending order (= the reference's
@@ -1163,7 +1192,7 @@ DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out, uint32_t ou
 	const uint32_t slots = wtab_size(a.n_q);
 	const uint32_t k32 = (uint32_t)kmer, sl0 = wtab_slot(k32, slots);
 	for (uint32_t sl = sl0;;) {
-		if (LSPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
+		if (++lsteps > DSB_STEP_LIMIT) { st |= DSB_ST_TIMEOUT; break; }
 		uint32_t e = a.tab[sl];
 		if (e == DSB_WTAB_EMPTY) break;
 		if ((e >> 12) == k32) { if (nc < DSB_SDP_CAND) cand[nc++] = a.q_bg + (e & 0xfffu); else many = true; }
@@ -1178,7 +1207,7 @@ DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out, uint32_t ou
 		else {	// more than DSB_SDP_CAND positions: repeated selection of the next larger one
 			int64_t best = -1;
 			for (uint32_t sl = sl0;;) {
-				if (LSPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
+				if (++lsteps > DSB_STEP_LIMIT) { st |= DSB_ST_TIMEOUT; break; }
 				uint32_t e = a.tab[sl];
 				if (e == DSB_WTAB_EMPTY) break;
 				if ((e >> 12) == k32) { int64_t qp = (int64_t)a.q_bg + (e & 0xfffu); if (qp > last && (best < 0 || qp < best)) best = qp; }
@@ -1219,38 +1248,48 @@ DV uint32_t sdp_visit(WCtx &w, const SdpArgs &a, int i, DsbSms *out, uint32_t ou
 }
 
 template <bool FWD>
-DN void sdp_match_t(WCtx &w, const SdpArgs &a)
+DN void sdp_match_t(WCtx &w, const SdpArgs a)
 {
 	uint32_t t_kmer_num = a.t_len - 9 + 1;
 	if (t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return;       // the reference's loop does not run either (t_len >= 13 at every call site)
 	uint32_t n_pos = (t_kmer_num - 4 + 3) / 4;                      // i = 4, 8, ... < t_kmer_num
+	// the context lives in memory (it is shared by reference with non-inlined callers): work on copies
+	const int lane = w.lane; uint32_t *const red = w.red; DsbSms *const sms = w.sms;
+	uint32_t n_sms = w.n_sms, lsteps = w.lsteps; int st = 0;
 	for (uint32_t g = 0; g < n_pos; g += DSB_WAVE) {
-		uint32_t pI = g + w.lane; bool valid = pI < n_pos; int i = 4 + 4 * (int)pI;
+		uint32_t pI = g + lane; bool valid = pI < n_pos; int i = 4 + 4 * (int)pI;
 		DsbSms keep[DSB_SDP_KEEP];
-		uint32_t cnt = valid ? sdp_visit<FWD, true>(w, a, i, keep, DSB_SDP_KEEP) : 0;
-		uint32_t total, off = grp_excl_scan_u(w.red, w.lane, cnt, &total);
+		uint32_t cnt = valid ? sdp_visit<FWD, true>(lsteps, st, a, i, keep, DSB_SDP_KEEP) : 0;
+		uint32_t total, off = grp_excl_scan_u(red, lane, cnt, &total);
 		if (total == 0) continue;
-		if (w.n_sms + total > DSB_SMS_CAP) { w.status |= DSB_ST_SMS_OVF; return; }
-		DsbSms *dst = w.sms + w.n_sms + off;
+		if (n_sms + total > DSB_SMS_CAP) { st |= DSB_ST_SMS_OVF; break; }
+		DsbSms *dst = sms + n_sms + off;
 		if (cnt <= DSB_SDP_KEEP) { for (uint32_t k = 0; k < cnt; k++) { dst[k].len = keep[k].len; dst[k].q_pos = keep[k].q_pos; dst[k].t_pos = keep[k].t_pos; } }
-		else sdp_visit<FWD, true>(w, a, i, dst, 0xffffffffu);
-		w.n_sms += total;
+		else sdp_visit<FWD, true>(lsteps, st, a, i, dst, 0xffffffffu);
+		n_sms += total;
 		wave_sync();
 	}
+	w.n_sms = n_sms; w.lsteps = lsteps;
+	if (st) w.status |= st;
+}
+
+// read positions sdp_match can return: q_bg <= pos <= q_ed, and pos has a 9-mer (pos <= L - 9)
+DV uint32_t sdp_nq(const WCtx &w, uint32_t q_bg, uint32_t q_ed)
+{
+	uint32_t n9 = w.L - 9 + 1, hi = q_ed < n9 - 1 ? q_ed : n9 - 1;
+	return (q_bg <= hi) ? hi - q_bg + 1 : 0;
 }
 
 DN void sdp_match(WCtx &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len, int key_len,
                   int tbl, uint32_t t_st, bool isForward)
 {
 	(void)key_len; (void)tbl;
-	SdpArgs a; a.q_bg = q_bg; a.q_ed = q_ed; a.q_str = q_str; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st; a.tab = w.wtab;
-	// read positions that can be returned: q_bg <= pos <= q_ed, and pos has a 9-mer (pos <= L - 9)
-	uint32_t n9 = w.L - 9 + 1, hi = q_ed < n9 - 1 ? q_ed : n9 - 1;
-	a.n_q = (q_bg <= hi) ? hi - q_bg + 1 : 0;
+	SdpArgs a; a.q_bg = q_bg; a.q_ed = q_ed; a.q_str = q_str; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st; a.tab = (const lds_u32 *)w.wtab;
+	a.n_q = sdp_nq(w, q_bg, q_ed);
 	if (a.n_q > DSB_WTAB_MAXQ) { w.status |= DSB_ST_SMS_OVF; return; }     // cannot happen: windows are <= 2001 wide
 	uint32_t t_kmer_num = t_len - 9 + 1;
 	if (a.n_q == 0 || t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return;
-	wtab_build(w, q_str, q_bg, a.n_q);
+	wtab_build((lds_u32 *)w.wtab, w.lane, q_str, q_bg, a.n_q);
 	if (isForward) sdp_match_t<true>(w, a); else sdp_match_t<false>(w, a);
 }
 
@@ -1514,11 +1553,23 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 				uint8_t *ref = w.win_mid;
 				if (total_ref_len >= 2000) { w.status |= DSB_ST_TIMEOUT; return 0; }   // the reference aborts here (xassert, src/cly.c:2473)
 				uint64_t ref_offset = pre_refoffset + t_offset + pre_mch;
+				const uint32_t q_bg = A[pre_a].index_in_read + pre_mch - 8, q_ed = A[c_a].index_in_read - 1;
+				const uint8_t *qs = q_str;
+				// Small gap (the usual case): the reference window and the stretch of the read the match can touch live
+				// in LDS behind the window's hash table, so the k-mer builds and exact-match extensions of sdp_match
+				// are LDS reads instead of global round trips.  Forward matching reads q in [q_bg - 8, q_ed + 66].
+				const uint32_t n_q = sdp_nq(w, q_bg, q_ed), slots = wtab_size(n_q);
+				const int32_t q_lo = (int32_t)q_bg - 16, q_hi = (int32_t)q_ed + 80;
+				const uint32_t q_bytes = q_hi > q_lo ? (uint32_t)(q_hi - q_lo + 7) & ~7u : 0u, t_bytes = ((uint32_t)total_ref_len + 64 + 7) & ~7u;
+				if (n_q > 0 && q_bytes && q_lo >= -(int32_t)DSB_QPAD_L + 8 && 4 * slots + q_bytes + 8 + t_bytes + 8 <= 4 * DSB_WTAB_SLOTS) {
+					uint8_t *lq = reinterpret_cast<uint8_t *>(w.wtab + slots), *lt = lq + q_bytes + 8;
+					for (uint32_t k = 8 * w.lane; k < q_bytes; k += 8 * DSB_WAVE) *reinterpret_cast<uint64_t *>(lq + k) = ld_u64(q_str + q_lo + (int32_t)k);
+					ref = lt; qs = lq - q_lo;
+				}
 				get_ref_wave(w, ref, ref_offset, total_ref_len);
 				for (int k = total_ref_len + w.lane; k < total_ref_len + 64; k += DSB_WAVE) ref[k] = DSB_TPAD_VAL;   // reads reach <= 58 past the window
 				wave_sync();
-				sdp_match(w, A[pre_a].index_in_read + pre_mch - 8, A[c_a].index_in_read - 1, q_str, ref, total_ref_len, key_len, tbl,
-				          pre_refoffset + pre_mch, true);
+				sdp_match(w, q_bg, q_ed, qs, ref, total_ref_len, key_len, tbl, pre_refoffset + pre_mch, true);
 			}
 			p = push_sms(w);
 			p->q_pos = A[c_a].index_in_read; p->t_pos = A[c_a].ref_offset; p->len = A[c_a].mtch_len - 9 + 1;

@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	   would turn each x->field into a vector load from host-coherent memory.) */                                       \
 	__shared__ DsbDevIndex sx;                                                                                          \
 	__shared__ uint4 lds_ring[DSB_RING];                                                                                \
-	__shared__ uint32_t lds_wtab[DSB_WTAB_SLOTS];                                                                       \
+	__shared__ __attribute__((aligned(16))) uint32_t lds_wtab[DSB_WTAB_SLOTS];                                                                       \
 	__shared__ uint32_t lds_red[THREADS / 64 + 1];                                                                      \
 	__shared__ unsigned int s_word;                                                                                     \
 	if (lane == 0) sx = x;                                                                                              \
@@ -315,6 +315,7 @@ struct dsb_ctx {
 	size_t n_reads; uint64_t n_words_total, total_bases, total_windows; uint32_t max_len;
 	int hist_max;
 	hipEvent_t ev[4]; dsb_timing timing; unsigned long long p1;
+	hipStream_t stream2; hipEvent_t ev_order;      // the LPT ordering kernels run beside the seed probe
 	uint32_t *dbg_host, *dbg_dev;
 	dsb_opts opts;
 };
@@ -344,6 +345,7 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	c->opts.max_sec_N = opts ? opts->max_sec_N : 5; c->opts.n_slots = opts ? opts->n_slots : 0;
 	HIPCHK(hipStreamCreate(&c->stream));
 	for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
+	HIPCHK(hipStreamCreate(&c->stream2)); HIPCHK(hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming));
 	// stage the index into HBM once
 	const DsbHostIndex *h = dsb_index_host(idx);
 	DsbDevIndex &dx = c->dx; memset(&dx, 0, sizeof dx);
@@ -393,6 +395,7 @@ extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 	hipFree(c->d_rd); hipFree(c->d_wd); hipFree(c->d_ascii); hipFree(c->d_bin); hipFree(c->d_pk); hipFree(c->d_bits);
 	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->d_score); hipFree(c->d_order);
 	for (int i = 0; i < 4; i++) hipEventDestroy(c->ev[i]);
+	hipEventDestroy(c->ev_order); hipStreamDestroy(c->stream2);
 	hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -555,6 +558,12 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	HIPCHK(hipEventRecord(c->ev[1], c->stream));
 	const bool dbg = getenv("DSB_DEBUG") != NULL;
 	if (dbg) { HIPCHK(hipStreamSynchronize(c->stream)); fprintf(stderr, "[dsb] encode done\n"); }
+	// the LPT order needs only the packed reads: its two kernels (LDS/ALU work) run on a second stream beside the
+	// memory-bound seed probe, and k_classify waits for both
+	HIPCHK(hipStreamWaitEvent(c->stream2, c->ev[1], 0));
+	hipLaunchKernelGGL(k_repeat_score, dim3((unsigned)n), dim3(256), 0, c->stream2, c->d_rd, c->d_pk, c->d_score);
+	hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, c->stream2, c->d_score, (uint32_t)n, c->d_order);
+	HIPCHK(hipEventRecord(c->ev_order, c->stream2));
 	if (c->n_words_total) {
 		uint64_t waves = (c->n_words_total + DSB_PROBE_UN - 1) / DSB_PROBE_UN; unsigned blocks = (unsigned)((waves + 3) / 4);
 		if (blocks > 256u * 32u) blocks = 256u * 32u;       // >= 8 blocks of 4 waves per CU, grid-stride beyond
@@ -568,8 +577,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		uint32_t *dbgp = dbg ? c->dbg_dev : nullptr;
 		if (dbg) memset(c->dbg_host, 0, 32 * 65536 * sizeof(uint32_t));
 		// counters: [0] work, [1] hits, [2..3] u64 table-1 probes
-		hipLaunchKernelGGL(k_repeat_score, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_rd, c->d_pk, c->d_score);
-		hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, c->stream, c->d_score, (uint32_t)n, c->d_order);
+		HIPCHK(hipStreamWaitEvent(c->stream, c->ev_order, 0));
 		hipLaunchKernelGGL(k_classify, dim3(slots), dim3(64), 0, c->stream, c->dx, c->d_rd, (uint32_t)n, (const unsigned int *)nullptr, (const uint32_t *)c->d_order,
 		                   c->d_bin, c->d_bits, c->arena, c->d_counters, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout,
 		                   dbgp);
@@ -592,7 +600,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		double tot[10] = {0}, all = 0; unsigned slots = (unsigned)c->n_slots; if (slots > n) slots = (unsigned)n;
 		double sub[4] = {0};
 		for (unsigned sI = 0; sI < slots; sI++) { for (int i = 0; i < 10; i++) { tot[i] += c->dbg_host[4 * 65536 + 14 * sI + i]; all += c->dbg_host[4 * 65536 + 14 * sI + i]; } for (int i = 0; i < 4; i++) sub[i] += c->dbg_host[4 * 65536 + 14 * sI + 10 + i]; }
-		fprintf(stderr, "[dsb] inside sdp_right/left (ms): sdp_match %.1f  dp %.1f  combine %.1f\n", sub[0] / 1e3, sub[1] / 1e3, sub[2] / 1e3);
+		fprintf(stderr, "[dsb] inside sdp_right/left (ms): sdp_match %.1f  dp %.1f  combine %.1f  [3] %.1f\n", sub[0] / 1e3, sub[1] / 1e3, sub[2] / 1e3, sub[3] / 1e3);
 		{	// stage split of the slowest read of the batch (as it ran, i.e. under load)
 			size_t worst = 0; uint64_t wsum = 0;
 			for (size_t r = 0; r < n && r < 65536; r++) { uint64_t sm = 0; for (int i = 0; i < 10; i++) sm += c->dbg_host[16 * 65536 + 14 * r + i]; if (sm > wsum) { wsum = sm; worst = r; } }
@@ -678,7 +686,7 @@ __global__ void __launch_bounds__(64) k_seed_dump(DsbDevIndex x, DsbReadDesc d, 
 	__shared__ DsbDevIndex sx;
 	if (threadIdx.x == 0) sx = x;
 	__syncthreads();
-	dsb_g64::WCtx w; w.x = &sx; w.lane = threadIdx.x; w.L = d.len; w.status = 0; w.dbg = nullptr; w.anc_cap = 0;
+	dsb_g64::WCtx w; w.x = &sx; w.lane = threadIdx.x; w.L = d.len; w.status = 0; w.dbg = nullptr; w.anc_cap = 0; w.wtab = nullptr;
 	dsb_g64::SDir sd;
 	uint32_t n = d.len - x.ek_len + 1;
 	if (strand) dsb_g64::seed_vector(w, bin + d.bin_off + DSB_QPAD_L, bits + d.bit_off, n, out, D_FORWARD, &sd);

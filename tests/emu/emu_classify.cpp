@@ -57,7 +57,7 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	w.x = &e->dx; w.lane = 0; w.dbg = nullptr;
 	w.seeds = (DsbSeed *)(s + off[0]); w.anc = (DsbAnchor *)(s + off[1]); w.anc_tmp = (DsbAnchor *)(s + off[2]);
 	w.hit = (DsbChain *)(s + off[3]); w.hit_tmp = (DsbChain *)(s + off[4]); w.sms = (DsbSms *)(s + off[5]);
-	static uint32_t emu_wtab[DSB_WTAB_SLOTS]; w.wtab = emu_wtab;
+	alignas(16) static uint32_t emu_wtab[DSB_WTAB_SLOTS]; w.wtab = emu_wtab;
 	w.sc = (DsbScHash *)(s + off[7]); w.mem_slow = (DsbMem *)(s + off[8]); w.spset = (uint64_t *)(s + off[9]); w.score_v = (int *)(s + off[10]);
 	w.sortkey = (uint64_t *)(s + off[11]); w.sortidx = (uint32_t *)(s + off[12]);
 	w.win_mid = s + off[13]; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
