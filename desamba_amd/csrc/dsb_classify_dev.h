@@ -33,7 +33,11 @@
 #define __popcll __builtin_popcountll
 #else
 #define DV __device__ __forceinline__
+#ifdef DSB_INLINE_ALL
+#define DN __device__ __forceinline__
+#else
 #define DN __device__ __noinline__
+#endif
 #define DSB_WAVE DSB_GROUP
 #endif
 #ifndef DSB_DEV_COMMON
@@ -269,13 +273,12 @@ DV void get_ref_small(const uint8_t *txt, uint8_t *out, int64_t off, int32_t len
 		}
 }
 // forward window of any length, lanes split the bases; caller must wave_sync() before reading
-DV void get_ref_wave(const WCtx &w, uint8_t *out, int64_t off, int32_t length)
+DV void get_ref_wave(const uint8_t *txt, int lane, uint8_t *out, int64_t off, int32_t length)
 {	// `out` is 8-byte aligned (window buffers in the arena or in LDS): a lane unpacks 8 bases per step from one
 	// unaligned 4-byte load of the 2-bit text (refbin carries a 4 KiB zero pad) and stores them as one u64
 	if (off < 0) off = 0;
 	if (length < 0) length = 0;
-	const uint8_t *txt = w.x->refbin;
-	for (int32_t k = 8 * w.lane; k < length; k += 8 * DSB_WAVE) {
+	for (int32_t k = 8 * lane; k < length; k += 8 * DSB_WAVE) {
 		uint64_t p = (uint64_t)off + (uint32_t)k;
 		uint32_t raw; __builtin_memcpy(&raw, txt + (p >> 2), 4);
 		uint32_t v = __builtin_bswap32(raw), s = (uint32_t)p & 3u;
@@ -1248,14 +1251,14 @@ DV uint32_t sdp_visit(uint32_t &lsteps, int &st, const SdpArgs &a, int i, DsbSms
 }
 
 template <bool FWD>
-DN void sdp_match_t(WCtx &w, const SdpArgs a)
+DN uint32_t sdp_match_t(WCtx &w, const SdpArgs a, uint32_t n_sms)
 {
 	uint32_t t_kmer_num = a.t_len - 9 + 1;
-	if (t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return;       // the reference's loop does not run either (t_len >= 13 at every call site)
+	if (t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return n_sms; // the reference's loop does not run either (t_len >= 13 at every call site)
 	uint32_t n_pos = (t_kmer_num - 4 + 3) / 4;                      // i = 4, 8, ... < t_kmer_num
 	// the context lives in memory (it is shared by reference with non-inlined callers): work on copies
 	const int lane = w.lane; uint32_t *const red = w.red; DsbSms *const sms = w.sms;
-	uint32_t n_sms = w.n_sms, lsteps = w.lsteps; int st = 0;
+	uint32_t lsteps = w.lsteps; int st = 0;
 	for (uint32_t g = 0; g < n_pos; g += DSB_WAVE) {
 		uint32_t pI = g + lane; bool valid = pI < n_pos; int i = 4 + 4 * (int)pI;
 		DsbSms keep[DSB_SDP_KEEP];
@@ -1269,28 +1272,35 @@ DN void sdp_match_t(WCtx &w, const SdpArgs a)
 		n_sms += total;
 		wave_sync();
 	}
-	w.n_sms = n_sms; w.lsteps = lsteps;
+	w.lsteps = lsteps;
 	if (st) w.status |= st;
+	return n_sms;
 }
 
 // read positions sdp_match can return: q_bg <= pos <= q_ed, and pos has a 9-mer (pos <= L - 9)
-DV uint32_t sdp_nq(const WCtx &w, uint32_t q_bg, uint32_t q_ed)
+DV uint32_t sdp_nq(uint32_t L, uint32_t q_bg, uint32_t q_ed)
 {
-	uint32_t n9 = w.L - 9 + 1, hi = q_ed < n9 - 1 ? q_ed : n9 - 1;
+	uint32_t n9 = L - 9 + 1, hi = q_ed < n9 - 1 ? q_ed : n9 - 1;
 	return (q_bg <= hi) ? hi - q_bg + 1 : 0;
 }
 
-DN void sdp_match(WCtx &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len, int key_len,
+// appends the nodes to w.sms[n_sms...] and returns the new count (w.n_sms is not touched)
+DN uint32_t sdp_match_n(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len,
+                        uint32_t t_st, bool isForward)
+{
+	SdpArgs a; a.q_bg = q_bg; a.q_ed = q_ed; a.q_str = q_str; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st; a.tab = (const lds_u32 *)w.wtab;
+	a.n_q = sdp_nq(w.L, q_bg, q_ed);
+	if (a.n_q > DSB_WTAB_MAXQ) { w.status |= DSB_ST_SMS_OVF; return n_sms; }     // cannot happen: windows are <= 2001 wide
+	uint32_t t_kmer_num = t_len - 9 + 1;
+	if (a.n_q == 0 || t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return n_sms;
+	wtab_build((lds_u32 *)w.wtab, w.lane, q_str, q_bg, a.n_q);
+	return isForward ? sdp_match_t<true>(w, a, n_sms) : sdp_match_t<false>(w, a, n_sms);
+}
+DV void sdp_match(WCtx &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len, int key_len,
                   int tbl, uint32_t t_st, bool isForward)
 {
 	(void)key_len; (void)tbl;
-	SdpArgs a; a.q_bg = q_bg; a.q_ed = q_ed; a.q_str = q_str; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st; a.tab = (const lds_u32 *)w.wtab;
-	a.n_q = sdp_nq(w, q_bg, q_ed);
-	if (a.n_q > DSB_WTAB_MAXQ) { w.status |= DSB_ST_SMS_OVF; return; }     // cannot happen: windows are <= 2001 wide
-	uint32_t t_kmer_num = t_len - 9 + 1;
-	if (a.n_q == 0 || t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return;
-	wtab_build((lds_u32 *)w.wtab, w.lane, q_str, q_bg, a.n_q);
-	if (isForward) sdp_match_t<true>(w, a); else sdp_match_t<false>(w, a);
+	w.n_sms = sdp_match_n(w, w.n_sms, q_bg, q_ed, q_str, t_str, t_len, t_st, isForward);
 }
 
 DV void ring_put(WCtx &w, uint32_t idx, uint32_t t_pos, uint32_t q_pos, uint32_t len, uint32_t score)
@@ -1537,83 +1547,93 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 {
 	const DsbDevIndex *x = w.x;
 	int score = 10000;
-	const DsbAnchor *A = w.anc;
-	uint64_t t_offset = x->refinfo[A[c_a].ref_ID].seq_offset;
-	int32_t pre_a = -1;
-	while (c_a != -1) {
-		pre_a = A[c_a].pre;
-		if (pre_a != -1) {
-			int pre_mch = A[pre_a].mtch_len;
-			int pre_refoffset = A[pre_a].ref_offset - 3;
-			int total_ref_len = A[c_a].ref_offset - (pre_refoffset + pre_mch) + 3;
-			w.n_sms = 0;
-			DsbSms *p = push_sms(w);
-			p->score = score; p->q_pos = A[pre_a].index_in_read; p->t_pos = A[pre_a].ref_offset; p->len = A[pre_a].mtch_len - 9 + 1;
-			if (total_ref_len > 12) {
-				uint8_t *ref = w.win_mid;
-				if (total_ref_len >= 2000) { w.status |= DSB_ST_TIMEOUT; return 0; }   // the reference aborts here (xassert, src/cly.c:2473)
-				uint64_t ref_offset = pre_refoffset + t_offset + pre_mch;
-				const uint32_t q_bg = A[pre_a].index_in_read + pre_mch - 8, q_ed = A[c_a].index_in_read - 1;
-				const uint8_t *qs = q_str;
-				// Small gap (the usual case): the reference window and the stretch of the read the match can touch live
-				// in LDS behind the window's hash table, so the k-mer builds and exact-match extensions of sdp_match
-				// are LDS reads instead of global round trips.  Forward matching reads q in [q_bg - 8, q_ed + 66].
-				const uint32_t n_q = sdp_nq(w, q_bg, q_ed), slots = wtab_size(n_q);
-				const int32_t q_lo = (int32_t)q_bg - 16, q_hi = (int32_t)q_ed + 80;
-				const uint32_t q_bytes = q_hi > q_lo ? (uint32_t)(q_hi - q_lo + 7) & ~7u : 0u, t_bytes = ((uint32_t)total_ref_len + 64 + 7) & ~7u;
-				if (n_q > 0 && q_bytes && q_lo >= -(int32_t)DSB_QPAD_L + 8 && 4 * slots + q_bytes + 8 + t_bytes + 8 <= 4 * DSB_WTAB_SLOTS) {
-					uint8_t *lq = reinterpret_cast<uint8_t *>(w.wtab + slots), *lt = lq + q_bytes + 8;
-					for (uint32_t k = 8 * w.lane; k < q_bytes; k += 8 * DSB_WAVE) *reinterpret_cast<uint64_t *>(lq + k) = ld_u64(q_str + q_lo + (int32_t)k);
-					ref = lt; qs = lq - q_lo;
-				}
-				get_ref_wave(w, ref, ref_offset, total_ref_len);
-				for (int k = total_ref_len + w.lane; k < total_ref_len + 64; k += DSB_WAVE) ref[k] = DSB_TPAD_VAL;   // reads reach <= 58 past the window
-				wave_sync();
-				sdp_match(w, q_bg, q_ed, qs, ref, total_ref_len, key_len, tbl, pre_refoffset + pre_mch, true);
+	// the context lives in memory: work on copies (see sdp_match_t)
+	const DsbAnchor *A = w.anc; DsbSms *const S = w.sms; uint32_t *const wtab = w.wtab; uint8_t *const win = w.win_mid;
+	const int lane = w.lane; const uint32_t L = w.L;
+	DsbAnchor ca = A[c_a];
+	const uint64_t t_offset = x->refinfo[ca.ref_ID].seq_offset;
+	for (;;) {
+		const int32_t pre_a = ca.pre;
+		if (pre_a == -1) { score += ca.mtch_len - 9 + 1; break; }
+		const DsbAnchor pa = A[pre_a];
+		const int pre_mch = pa.mtch_len;
+		const int pre_refoffset = pa.ref_offset - 3;
+		const int total_ref_len = ca.ref_offset - (pre_refoffset + pre_mch) + 3;
+		// node 0 = the previous anchor, the last node = this anchor; both stay in registers unless the list
+		// has to go through the general path
+		DsbSms first; first.score = score; first.q_pos = pa.index_in_read; first.t_pos = pa.ref_offset; first.len = pa.mtch_len - 9 + 1;
+		DsbSms last; last.score = 0; last.q_pos = ca.index_in_read; last.t_pos = ca.ref_offset; last.len = ca.mtch_len - 9 + 1;
+		uint32_t n_sms = 1;
+		if (total_ref_len > 12) {
+			uint8_t *ref = win;
+			if (total_ref_len >= 2000) { w.status |= DSB_ST_TIMEOUT; w.n_sms = 0; return 0; }   // the reference aborts here (xassert, src/cly.c:2473)
+			uint64_t ref_offset = pre_refoffset + t_offset + pre_mch;
+			const uint32_t q_bg = pa.index_in_read + pre_mch - 8, q_ed = ca.index_in_read - 1;
+			const uint8_t *qs = q_str;
+			// Small gap (the usual case): the reference window and the stretch of the read the match can touch live
+			// in LDS behind the window's hash table, so the k-mer builds and exact-match extensions of sdp_match
+			// are LDS reads instead of global round trips.  Forward matching reads q in [q_bg - 8, q_ed + 66].
+			const uint32_t n_q = sdp_nq(L, q_bg, q_ed), slots = wtab_size(n_q);
+			const int32_t q_lo = (int32_t)q_bg - 16, q_hi = (int32_t)q_ed + 80;
+			const uint32_t q_bytes = q_hi > q_lo ? (uint32_t)(q_hi - q_lo + 7) & ~7u : 0u, t_bytes = ((uint32_t)total_ref_len + 64 + 7) & ~7u;
+			if (n_q > 0 && q_bytes && q_lo >= -(int32_t)DSB_QPAD_L + 8 && 4 * slots + q_bytes + 8 + t_bytes + 8 <= 4 * DSB_WTAB_SLOTS) {
+				uint8_t *lq = reinterpret_cast<uint8_t *>(wtab + slots), *lt = lq + q_bytes + 8;
+				for (uint32_t k = 8 * lane; k < q_bytes; k += 8 * DSB_WAVE) *reinterpret_cast<uint64_t *>(lq + k) = ld_u64(q_str + q_lo + (int32_t)k);
+				ref = lt; qs = lq - q_lo;
 			}
-			p = push_sms(w);
-			p->q_pos = A[c_a].index_in_read; p->t_pos = A[c_a].ref_offset; p->len = A[c_a].mtch_len - 9 + 1;
-			if (w.n_sms > 1) {
-				DsbSms *S = w.sms;
+			get_ref_wave(x->refbin, lane, ref, ref_offset, total_ref_len);
+			for (int k = total_ref_len + lane; k < total_ref_len + 64; k += DSB_WAVE) ref[k] = DSB_TPAD_VAL;   // reads reach <= 58 past the window
+			wave_sync();
+			n_sms = sdp_match_n(w, n_sms, q_bg, q_ed, qs, ref, total_ref_len, pre_refoffset + pre_mch, true);
+		}
+		n_sms++;                                                     // the last node
+		if (n_sms > DSB_SMS_CAP) { w.status |= DSB_ST_SMS_OVF; n_sms = DSB_SMS_CAP; }
+		{
 #ifndef DSB_HOST_EMU
-				if (w.n_sms <= (uint32_t)DSB_WAVE && DSB_GROUP == 64) {
-					// small gap (the usual case): one node per lane, the whole DP in registers.  Lane ci's node is
-					// broadcast, lanes < ci judge their own node as its predecessor (sdp_best_pred<0> semantics:
-					// no distance cut), wave max; nothing is written back -- the list is local to this gap.
-					const uint32_t nn = w.n_sms;
-					DsbSms me; if ((uint32_t)w.lane < nn) me = S[w.lane]; else { me.t_pos = me.q_pos = me.len = 0; }
-					me.score = (w.lane == 0) ? (uint32_t)score : 0u;
-					for (uint32_t ci = 1; ci < nn; ci++) {
-						DsbSms cs; cs.t_pos = dsb_shfl(me.t_pos, (int)ci); cs.q_pos = dsb_shfl(me.q_pos, (int)ci); cs.len = dsb_shfl(me.len, (int)ci); cs.score = 0;
-						uint32_t lim_q = cs.q_pos + 6, lim_t = cs.t_pos + 6;
-						int cand = (int)cs.len;
-						if ((uint32_t)w.lane < ci) {
-							int pre_q_ed = me.q_pos + me.len + 9 - 1, pre_t_ed = me.t_pos + me.len + 9 - 1;
-							if (!((uint32_t)pre_q_ed > lim_q) && !((uint32_t)pre_t_ed > lim_t)) {
-								int indel = me.q_pos - me.t_pos - (lim_q - lim_t); int ai = ABSV(indel);
-								if (ai <= 200) {
-									int ns = me.score + cs.len - (ai >> 3);
-									if ((uint32_t)pre_q_ed > cs.q_pos || (uint32_t)pre_t_ed > cs.t_pos) { int oq = pre_q_ed - cs.q_pos, ot = pre_t_ed - cs.t_pos; ns -= MAXV(oq, ot); }
-									cand = MAXV(cand, ns);
-								}
+			if (n_sms <= (uint32_t)DSB_WAVE && DSB_GROUP == 64) {
+				// small gap (the usual case): one node per lane, the whole DP in registers.  Lane ci's node is
+				// broadcast, lanes < ci judge their own node as its predecessor (sdp_best_pred<0> semantics:
+				// no distance cut), wave max; nothing is written back -- the list is local to this gap.
+				const uint32_t nn = n_sms;
+				DsbSms me; me.t_pos = me.q_pos = me.len = 0;
+				if (lane == 0) me = first; else if ((uint32_t)lane == nn - 1) me = last; else if ((uint32_t)lane < nn) me = S[lane];
+				me.score = (lane == 0) ? (uint32_t)score : 0u;
+				for (uint32_t ci = 1; ci < nn; ci++) {
+					DsbSms cs; cs.t_pos = dsb_shfl(me.t_pos, (int)ci); cs.q_pos = dsb_shfl(me.q_pos, (int)ci); cs.len = dsb_shfl(me.len, (int)ci); cs.score = 0;
+					uint32_t lim_q = cs.q_pos + 6, lim_t = cs.t_pos + 6;
+					int cand = (int)cs.len;
+					if ((uint32_t)lane < ci) {
+						int pre_q_ed = me.q_pos + me.len + 9 - 1, pre_t_ed = me.t_pos + me.len + 9 - 1;
+						if (!((uint32_t)pre_q_ed > lim_q) && !((uint32_t)pre_t_ed > lim_t)) {
+							int indel = me.q_pos - me.t_pos - (lim_q - lim_t); int ai = ABSV(indel);
+							if (ai <= 200) {
+								int ns = me.score + cs.len - (ai >> 3);
+								if ((uint32_t)pre_q_ed > cs.q_pos || (uint32_t)pre_t_ed > cs.t_pos) { int oq = pre_q_ed - cs.q_pos, ot = pre_t_ed - cs.t_pos; ns -= MAXV(oq, ot); }
+								cand = MAXV(cand, ns);
 							}
 						}
-						int max_score = grp_max_i(w.red, w.lane, cand);
-						if ((uint32_t)w.lane == ci) me.score = (uint32_t)max_score;
-						score = MAXV(max_score, score);
 					}
-				} else
+					int max_score = grp_max_i(w.red, lane, cand);
+					if ((uint32_t)lane == ci) me.score = (uint32_t)max_score;
+					score = MAXV(max_score, score);
+				}
+			} else
 #endif
-				for (uint32_t ci = 1; ci < w.n_sms; ci++) {
+			{
+				S[0] = first; S[n_sms - 1].q_pos = last.q_pos; S[n_sms - 1].t_pos = last.t_pos; S[n_sms - 1].len = last.len;
+				wave_sync();
+				w.n_sms = n_sms;
+				for (uint32_t ci = 1; ci < n_sms; ci++) {
 					DsbSms cs = S[ci];
 					int max_score = sdp_best_pred<0>(w, cs, (int32_t)ci);
 					score = MAXV(max_score, score);
 					S[ci].score = max_score;
 				}
 			}
-		} else score += A[c_a].mtch_len - 9 + 1;
-		c_a = pre_a;
+		}
+		ca = pa;
 	}
+	w.n_sms = 0;
 	return score - 10000;
 }
 
@@ -1651,7 +1671,7 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 				max_search_ref = l_read - c_h->q_ed + 60;
 			} else max_search_ref = t_length - c_t_offset;
 			max_search_ref = MINV(600u, max_search_ref);
-			get_ref_wave(w, ref, c_t_offset + t_offset_global, max_search_ref + 50);
+			get_ref_wave(x->refbin, w.lane, ref, c_t_offset + t_offset_global, max_search_ref + 50);
 			wave_sync();
 			int search_q_ed = (int)best_q + 1000;
 			search_q_ed = MINV((uint32_t)search_q_ed, l_read);
@@ -1730,9 +1750,9 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 			} else max_search_ref = c_t_offset;
 			max_search_ref = MINV(600u, max_search_ref);
 			if (t_offset_global == 0 && c_t_offset < 50 + max_search_ref)
-				get_ref_wave(w, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref), max_search_ref);
+				get_ref_wave(x->refbin, w.lane, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref), max_search_ref);
 			else
-				get_ref_wave(w, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref - 50), max_search_ref + 50);
+				get_ref_wave(x->refbin, w.lane, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref - 50), max_search_ref + 50);
 			wave_sync();
 			int search_q_st = (int)best_q - 1000;
 			search_q_st = MAXV(search_q_st, 0);
