@@ -900,36 +900,88 @@ DN uint32_t *stable_sort_keys(WCtx &w, uint32_t n)
 }
 
 // chain_insert_M3 (src/cly.c:238-323): stable sort by (ref_ID, direction, ref_offset), then sparse DP per group
+#define DSB_RANKSORT_MAX 768
 DN void chain_sort_M3(WCtx &w)
 {
-	DsbAnchor *A = w.anc; int32_t n = w.n_anc;
-	for (int32_t i = w.lane; i < n; i += DSB_WAVE) {
+	DsbAnchor *A = w.anc, *T = w.anc_tmp; const int32_t n = w.n_anc; const int lane = w.lane;
+	if (n <= DSB_RANKSORT_MAX && w.wtab) {
+		// the usual size: keys in LDS (the window table is idle), every lane ranks its own anchors against all keys
+		// (stable: ties by index) and moves them straight to their sorted place; the two anchor arrays swap roles
+#ifdef DSB_HOST_EMU
+		uint64_t *keys = reinterpret_cast<uint64_t *>(w.wtab);
+#else
+		__attribute__((address_space(3))) uint64_t *keys = (__attribute__((address_space(3))) uint64_t *)w.wtab;
+#endif
+		for (int32_t i = lane; i < n; i += DSB_WAVE) keys[i] = ((uint64_t)A[i].ref_ID << 33) | ((uint64_t)A[i].direction << 32) | A[i].ref_offset;
+		wave_sync();
+		for (int32_t i = lane; i < n; i += DSB_WAVE) {
+			const uint64_t k = keys[i]; const DsbAnchor mine = A[i];
+			uint32_t rank = 0;
+			int32_t j = 0;
+			for (; j + 4 <= n; j += 4) {
+				uint64_t k0 = keys[j], k1 = keys[j + 1], k2 = keys[j + 2], k3 = keys[j + 3];
+				rank += (k0 < k || (k0 == k && j < i)) + (k1 < k || (k1 == k && j + 1 < i)) + (k2 < k || (k2 == k && j + 2 < i)) + (k3 < k || (k3 == k && j + 3 < i));
+			}
+			for (; j < n; j++) { uint64_t kj = keys[j]; rank += (kj < k || (kj == k && j < i)); }
+			T[rank] = mine;
+		}
+		wave_sync();
+		w.anc = T; w.anc_tmp = A;
+		return;
+	}
+	for (int32_t i = lane; i < n; i += DSB_WAVE) {
 		w.sortkey[i] = ((uint64_t)A[i].ref_ID << 33) | ((uint64_t)A[i].direction << 32) | A[i].ref_offset;
 		w.sortidx[i] = i;
 	}
 	wave_sync();
 	uint32_t *ord = stable_sort_keys(w, n);
-	for (int32_t i = w.lane; i < n; i += DSB_WAVE) w.anc_tmp[i] = A[ord[i]];
+	for (int32_t i = lane; i < n; i += DSB_WAVE) T[i] = A[ord[i]];
 	wave_sync();
-	for (int32_t i = w.lane; i < n; i += DSB_WAVE) A[i] = w.anc_tmp[i];
+	w.anc = T; w.anc_tmp = A;
+}
+// ... and its serial part (one lane).  LDSMODE: the fields the DP touches were staged in LDS by chain_stage_M3
+// (q, t, mtch_len, then the score and predecessor arrays), n <= DSB_CHAINDP_LDS.
+#define DSB_CHAINDP_LDS 512
+#ifdef DSB_HOST_EMU
+typedef uint32_t lds_w32;
+#else
+typedef __attribute__((address_space(3))) uint32_t lds_w32;
+#endif
+DN void chain_stage_M3(WCtx &w)
+{
+	const DsbAnchor *A = w.anc; const int32_t n = w.n_anc; const int lane = w.lane;
+	lds_w32 *L = (lds_w32 *)w.wtab;
+	for (int32_t i = lane; i < n; i += DSB_WAVE) { L[i] = A[i].index_in_read; L[DSB_CHAINDP_LDS + i] = A[i].ref_offset; L[2 * DSB_CHAINDP_LDS + i] = A[i].mtch_len; }
 	wave_sync();
 }
-// ... and its serial part (one lane)
+DN void chain_unstage_M3(WCtx &w)
+{
+	DsbAnchor *A = w.anc; const int32_t n = w.n_anc; const int lane = w.lane;
+	const lds_w32 *P = (const lds_w32 *)w.wtab + 4 * DSB_CHAINDP_LDS;
+	wave_sync();
+	for (int32_t i = lane; i < n; i += DSB_WAVE) A[i].pre = (int32_t)P[i];
+	wave_sync();
+}
+template <bool LDSMODE>
 DN void chain_dp_M3(WCtx &w)
 {
 	DsbAnchor *A = w.anc; int32_t n = w.n_anc;
 	int *score_v = w.score_v;
+	lds_w32 *LQ = (lds_w32 *)w.wtab, *LT = LQ + DSB_CHAINDP_LDS, *LM = LQ + 2 * DSB_CHAINDP_LDS, *LS = LQ + 3 * DSB_CHAINDP_LDS, *LP = LQ + 4 * DSB_CHAINDP_LDS;
+#define AQ(i) (LDSMODE ? (uint32_t)LQ[i] : A[i].index_in_read)
+#define AT(i) (LDSMODE ? (uint32_t)LT[i] : A[i].ref_offset)
+#define AM(i) (LDSMODE ? (uint32_t)LM[i] : (uint32_t)A[i].mtch_len)
 	for (int32_t st = 0; st < n;) {
 		int32_t ed = st + 1;
 		uint32_t ref_ID = A[st].ref_ID, direction = A[st].direction;
-		for (; ed < n && A[ed].ref_ID == ref_ID && A[ed].direction == direction && A[ed].ref_offset - A[ed - 1].ref_offset < 2000; ed++);
+		for (; ed < n && A[ed].ref_ID == ref_ID && A[ed].direction == direction && AT(ed) - AT(ed - 1) < 2000; ed++);
 		if (ed - st > 1024) ed = st + 1024;
 		int32_t max_anchor = -1; int max_score = 0, ams;
 		for (int32_t ca = st; ca < ed; ca++) {
 			int32_t best_pre = -1; ams = A[ca].score;
-			uint32_t max_t = A[ca].ref_offset + 3, max_q = A[ca].index_in_read + 3; uint32_t ca_ml = A[ca].mtch_len;
+			uint32_t max_t = AT(ca) + 3, max_q = AQ(ca) + 3; uint32_t ca_ml = AM(ca);
 			for (int32_t p = ca - 1; p >= st; p--) {
-				uint32_t p_q = A[p].index_in_read, p_t = A[p].ref_offset, p_ml = A[p].mtch_len;
+				uint32_t p_q = AQ(p), p_t = AT(p), p_ml = AM(p);
 				if (p_q + p_ml > max_q) continue;
 				if (p_t + p_ml > max_t) continue;
 				if (p_q + 1000 < max_q) break;
@@ -937,32 +989,36 @@ DN void chain_dp_M3(WCtx &w)
 				int indel = p_q - p_t - (max_q - max_t);
 				int ai = ABSV(indel);
 				if (ai > 200) continue;
-				int ns = score_v[p - st] + ca_ml - (ai >> 4) - ((max_q - p_q) >> 8);
+				int ns = (LDSMODE ? (int)LS[p] : score_v[p - st]) + ca_ml - (ai >> 4) - ((max_q - p_q) >> 8);
 				if (ns > ams) { ams = ns; best_pre = p; }
 			}
-			A[ca].pre = best_pre;
-			score_v[ca - st] = ams;
+			if (LDSMODE) { LP[ca] = (uint32_t)best_pre; LS[ca] = (uint32_t)ams; } else { A[ca].pre = best_pre; score_v[ca - st] = ams; }
 			if (max_score < ams) { max_score = ams; max_anchor = ca; }
 		}
+#define APRE(i) (LDSMODE ? (int32_t)LP[i] : A[i].pre)
 		int sum_INDEL = 0, anchor_number = 1; int32_t pre = max_anchor;
 		int sum_score = (A[max_anchor].duplicate) ? 1 : A[max_anchor].score;
 		bool with_top = !A[max_anchor].useless;
-		for (; A[pre].pre != -1; anchor_number++) {
-			int32_t pre_ = A[pre].pre;
-			sum_INDEL += (A[pre].index_in_read - A[pre_].index_in_read) - (A[pre].ref_offset - A[pre_].ref_offset);
+		for (; APRE(pre) != -1; anchor_number++) {
+			int32_t pre_ = APRE(pre);
+			sum_INDEL += (AQ(pre) - AQ(pre_)) - (AT(pre) - AT(pre_));
 			with_top |= (!A[pre].useless);
 			sum_score += (A[pre].duplicate) ? 1 : A[pre].score;
 			pre = pre_;
 		}
 		DsbChain *nc = push_hit(w);
 		nc->chain_id = w.n_hit - 1; nc->ref_ID = ref_ID; nc->direction = direction;
-		nc->q_t_dis = A[max_anchor].ref_offset - A[max_anchor].index_in_read;
-		nc->t_st = A[pre].ref_offset; nc->t_ed = A[max_anchor].ref_offset + A[max_anchor].mtch_len;
-		nc->q_st = A[pre].index_in_read; nc->q_ed = A[max_anchor].index_in_read + A[max_anchor].mtch_len;
+		nc->q_t_dis = AT(max_anchor) - AQ(max_anchor);
+		nc->t_st = AT(pre); nc->t_ed = AT(max_anchor) + AM(max_anchor);
+		nc->q_st = AQ(pre); nc->q_ed = AQ(max_anchor) + AM(max_anchor);
 		nc->with_top_anchor = with_top; nc->anchor_number = anchor_number; nc->sum_score = sum_score;
 		nc->indel = sum_INDEL; nc->cur = max_anchor;
 		st = ed;
 	}
+#undef AQ
+#undef AT
+#undef AM
+#undef APRE
 }
 
 // comparators on chains
@@ -1026,16 +1082,20 @@ DN void glibc_sort_chains(WCtx &w, uint32_t n)
 DN void resolve_tree(WCtx &w)
 {
 	w.n_hit = 0;
+	const bool lds_dp = w.n_anc >= 50 && w.n_anc <= DSB_CHAINDP_LDS && w.wtab;
 	if (w.n_anc >= 50) chain_sort_M3(w);
+	if (lds_dp) chain_stage_M3(w);
 	DSB_SERIAL(w) {
 		if (w.n_anc < 50) for (uint32_t i = 0; i < w.n_anc; i++) chain_insert_M2(w, i);
-		else chain_dp_M3(w);
+		else if (lds_dp) chain_dp_M3<true>(w);
+		else chain_dp_M3<false>(w);
 		if (w.n_hit > 1) glibc_sort_chains<0>(w, w.n_hit);
 		int rst_num = MINV(5, w.n_hit);
 		while (rst_num < w.n_hit && w.hit[rst_num].with_top_anchor == 1) rst_num++;
 		w.n_hit = rst_num;
 	}
 	serial_end(w);
+	if (lds_dp) chain_unstage_M3(w);
 }
 
 // ---- sc_hash_idx / combine_chain (src/cly.c:1691-1710,1763-1808) -------------------------------
