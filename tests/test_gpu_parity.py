@@ -50,6 +50,15 @@ def test_synthetic_golden_sam(gpu, name):
     assert sam == open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read()
 
 
+@pytest.mark.parametrize("name", ["heavy", "ont5k_e25"])
+def test_heavy_first_launch(gpu, name, monkeypatch):
+    """the early launch of the heaviest reads (second stream, own slots) must not change any result"""
+    D, idx, ctx = gpu
+    monkeypatch.setenv("DSB_HEAVY_FIRST", "16")
+    hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))
+    assert sam == open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read()
+
+
 def test_stage_parity_seed_lookup(gpu, demo, oracle):
     """exist-kmer bits of every window and the seed lists (a-3) of both strands"""
     D, idx, ctx = gpu
