@@ -748,38 +748,75 @@ DV int fast_island(WCtx &w, SDir *s_d, uint32_t read_len, uint32_t seed_idx)
 DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 {
 	DsbSeed *sv_b = s_d->seed_v; uint32_t n_seed = s_d->l_seed_v;
+	const int lane = w.lane; uint32_t *const top_idx = w.top_idx;
+	// indices of the top seeds, in order (lanes over seeds, ballot compaction)
 	uint32_t n_top = 0;
-	for (uint32_t i = 0; i < n_seed; i++) if (sv_b[i].top) w.top_idx[n_top++] = i;
+	for (uint32_t b0 = 0; b0 < n_seed; b0 += DSB_WAVE) {
+		uint32_t i = b0 + lane; bool t = i < n_seed && sv_b[i].top;
+		uint64_t m = dsb_ballot64(t);
+		if (t) top_idx[n_top + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL))] = i;
+		n_top += (uint32_t)__popcll(m);
+	}
+	wave_sync();
 	uint32_t skip_seed = 0xffffffffu;
 	DsbAnchor *main_anc = w.anc; uint64_t *main_sp = w.spset;
 	for (uint32_t base = 0; base < n_top; base += DSB_WAVE) {
-		uint32_t t = base + w.lane; bool valid = t < n_top;
+		uint32_t t = base + lane; bool valid = t < n_top;
 		uint32_t main_n = w.n_anc; int st_before = w.status;
-		w.anc = w.lane_anc + (size_t)w.lane * DSB_LANE_ANC_CAP; w.n_anc = 0; w.anc_cap = DSB_LANE_ANC_CAP;
-		w.spset = w.lane_spset + (size_t)w.lane * DSB_SPHASH;
-		int flag = valid ? fast_island(w, s_d, read_len, w.top_idx[t]) : 0;
+		const uint32_t my_sidx = valid ? top_idx[t] : 0xffffffffu;
+		w.anc = w.lane_anc + (size_t)lane * DSB_LANE_ANC_CAP; w.n_anc = 0; w.anc_cap = DSB_LANE_ANC_CAP;
+		w.spset = w.lane_spset + (size_t)lane * DSB_SPHASH;
+		int flag = valid ? fast_island(w, s_d, read_len, my_sidx) : 0;
 		int ovf = ((w.status & DSB_ST_ANC_OVF) && !(st_before & DSB_ST_ANC_OVF)) ? 1 : 0;
 		if (ovf) w.status &= ~DSB_ST_ANC_OVF;
 		uint32_t my_n = w.n_anc;
 		w.anc = main_anc; w.n_anc = main_n; w.anc_cap = DSB_ANC_CAP; w.spset = main_sp;
-		w.round_info[w.lane] = my_n | ((uint32_t)flag << 16) | ((uint32_t)ovf << 17);
 		// each lane bumped its own copy of the set generation: continue from the largest so that no lane's stale
 		// entries can look current, and the group-uniform code below sees one value
-		w.sp_gen = (uint32_t)grp_max_i(w.red, w.lane, (int)w.sp_gen);
-		wave_sync();
+		w.sp_gen = (uint32_t)grp_max_i(w.red, lane, (int)w.sp_gen);
 		uint32_t n_round = MINV((uint32_t)DSB_WAVE, n_top - base);
-		for (uint32_t l = 0; l < n_round; l++) {
-			uint32_t sidx = w.top_idx[base + l];
-			uint32_t ri = w.round_info[l]; uint32_t n_l = ri & 0xffffu; int f_l = (ri >> 16) & 1, ovf_l = (ri >> 17) & 1;
-			if (sidx == skip_seed) continue;
-			if (ovf_l) f_l = fast_island(w, s_d, read_len, sidx);
-			else {
-				if (w.n_anc + n_l > DSB_ANC_CAP) { w.status |= DSB_ST_ANC_OVF; n_l = 0; }
-				const DsbAnchor *src = w.lane_anc + (size_t)l * DSB_LANE_ANC_CAP;
-				for (uint32_t k = w.lane; k < n_l; k += DSB_WAVE) main_anc[w.n_anc + k] = src[k];
-				w.n_anc += n_l;
+		bool committed = false;
+#if !defined(DSB_HOST_EMU) && DSB_GROUP == 64
+		{	// Commit in island order without walking the lanes one by one: a seed is skipped iff it directly follows
+			// (index + 1) a committed seed whose island raised the skip flag (src/cly.c:1530-1531) -- a bit recurrence
+			// over the lanes -- and every lane then copies its own anchors to its place in the list.
+			const uint64_t V = __ballot(valid), F = __ballot(valid && flag), O = __ballot(valid && ovf);
+			uint32_t prev = __shfl_up(my_sidx, 1);
+			bool adj = lane == 0 ? (my_sidx == skip_seed) : (my_sidx == prev + 1);
+			const uint64_t ADJ = __ballot(valid && adj);
+			if (O == 0) {
+				uint64_t S = ADJ & 1ULL;                                    // lane 0: skipped by the previous round's carry
+				const uint64_t C = ADJ & (F << 1) & ~1ULL;
+				for (int l = 1; l < 64; l++) if (((C >> l) & 1ULL) && !((S >> (l - 1)) & 1ULL)) S |= 1ULL << l;
+				const bool keep = valid && !((S >> lane) & 1ULL);
+				uint32_t total, off = grp_excl_scan_u(w.red, lane, keep ? my_n : 0u, &total);
+				if (main_n + total <= DSB_ANC_CAP) {
+					const DsbAnchor *src = w.lane_anc + (size_t)lane * DSB_LANE_ANC_CAP;
+					if (keep) for (uint32_t k = 0; k < my_n; k++) main_anc[main_n + off + k] = src[k];
+					w.n_anc = main_n + total;
+					const uint64_t KF = F & V & ~S;                             // committed seeds that raise the skip flag
+					if (KF) { int last = 63 - (int)__builtin_clzll(KF); skip_seed = __shfl(my_sidx, last) + 1; }
+					committed = true;
+				}
 			}
-			if (f_l) skip_seed = sidx + 1;
+		}
+#endif
+		if (!committed) {
+			w.round_info[lane] = my_n | ((uint32_t)flag << 16) | ((uint32_t)ovf << 17);
+			wave_sync();
+			for (uint32_t l = 0; l < n_round; l++) {
+				uint32_t sidx = top_idx[base + l];
+				uint32_t ri = w.round_info[l]; uint32_t n_l = ri & 0xffffu; int f_l = (ri >> 16) & 1, ovf_l = (ri >> 17) & 1;
+				if (sidx == skip_seed) continue;
+				if (ovf_l) f_l = fast_island(w, s_d, read_len, sidx);
+				else {
+					if (w.n_anc + n_l > DSB_ANC_CAP) { w.status |= DSB_ST_ANC_OVF; n_l = 0; }
+					const DsbAnchor *src = w.lane_anc + (size_t)l * DSB_LANE_ANC_CAP;
+					for (uint32_t k = lane; k < n_l; k += DSB_WAVE) main_anc[w.n_anc + k] = src[k];
+					w.n_anc += n_l;
+				}
+				if (f_l) skip_seed = sidx + 1;
+			}
 		}
 		wave_sync();
 	}
