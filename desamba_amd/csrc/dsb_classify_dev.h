@@ -635,8 +635,20 @@ DN void seed_vector_scan(const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t
 {
 	// Same scan as search_exist_kmer_M2 (probe every 3rd window, extend back <= 2, forward to len 61,
 	// resume 3 past the seed), but 64 windows per load: the next probe hit is a ctz over the word
-	// masked to the probe phase, the extensions are run-length counts.
+	// masked to the probe phase, the extensions are run-length counts.  The top-seed marking of
+	// get_seed_vector_M2 (longest seed per 100-window bin, src/cly.c:1200-1234) runs on each seed as it is
+	// produced -- same order, same state machine -- so that no seed is read back from memory.
 	uint32_t ns = 0;
+	uint32_t total = 0, max_index = 0, max_length = 0, index_end = 100;
+#define DSB_EMIT_SEED(off_, len_)                                                                           \
+	do {                                                                                                    \
+		const uint32_t o_ = (off_), l_ = (len_);                                                            \
+		sv[ns].offset = o_; sv[ns].len = l_; sv[ns].top = 0;                                                \
+		const uint32_t key_ = (direction == D_FORWARD) ? o_ : n - o_ - l_;                                  \
+		if (key_ < index_end) { if (max_length < l_) { max_length = l_; max_index = ns; } sv[max_index].top = 0; }   /* (this store matters: it undoes a 1 the else-branch put on a bin's first seed) */ \
+		else { sv[max_index].top = 1; index_end += 100; total += max_length; max_index = ns; max_length = l_; } \
+		ns++;                                                                                               \
+	} while (0)
 	if (direction == D_FORWARD) {
 		uint32_t i = 3 - 1;
 		while (i < n) {
@@ -649,7 +661,7 @@ DN void seed_vector_scan(const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t
 			if (ebit(bits, i - 1)) { back = 1; if (ebit(bits, i - 2)) back = 2; }
 			uint32_t offset = i - back, len = 1 + back;
 			len += run_ones_up(bits, n, i + 1, 61 - len);
-			sv[ns].offset = offset; sv[ns].len = len; ns++;
+			DSB_EMIT_SEED(offset, len);
 			i = offset + len + 3;
 		}
 	} else {
@@ -663,22 +675,11 @@ DN void seed_vector_scan(const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t
 			if (ebit(bits, i + 1)) { fwd = 1; if (ebit(bits, i + 2)) fwd = 2; }
 			uint32_t offset = (uint32_t)i + fwd, len = 1 + fwd;
 			len += run_ones_down(bits, i - 1, 61 - len);
-			sv[ns].offset = offset - len + 1; sv[ns].len = len; ns++;
+			DSB_EMIT_SEED(offset - len + 1, len);
 			i = (int)(offset - len) - 3;
 		}
 	}
-	uint32_t total = 0; int max_index = 0; uint32_t max_length = 0, index_end = 100;
-	for (uint32_t m = 0; m < ns; m++) {
-		sv[m].top = 0;
-		uint32_t key = (direction == D_FORWARD) ? sv[m].offset : n - sv[m].offset - sv[m].len;
-		if (key < index_end) {
-			if (max_length < sv[m].len) { max_length = sv[m].len; max_index = m; }
-			sv[max_index].top = 0;
-		} else {
-			sv[max_index].top = 1; index_end += 100; total += max_length;
-			max_index = m; max_length = sv[m].len;
-		}
-	}
+#undef DSB_EMIT_SEED
 	sv[max_index].top = 1;
 	total += max_length;
 	*ns_out = ns; *total_out = total;
