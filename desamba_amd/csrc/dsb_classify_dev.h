@@ -1577,7 +1577,7 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 			if (MODE == 2) { A[u] = ps.q_pos; B[u] = ps.t_pos; C[u] = ps.t_pos; }
 			else { A[u] = ps.q_pos + ps.len + 8; B[u] = ps.t_pos + ps.len + 8; C[u] = ps.t_pos + 600; }
 			D[u] = ps.q_pos - ps.t_pos; S[u] = ps.score;
-			if (pi < 0 && MODE != 2) A[u] = 0xffffffffu;
+			if (pi < 0 && MODE != 2) A[u] = 0x7fffffffu;        // fails the first test (signed distance past the node start)
 		}
 		if (hi - DSB_DP_UNROLL * DSB_WAVE >= 0) { DSB_FETCH_PREDS(nx, hi - DSB_DP_UNROLL * DSB_WAVE) }
 #pragma unroll
@@ -1587,14 +1587,16 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 #pragma unroll
 			for (int u = 0; u < DSB_DP_UNROLL; u++) {
 				if ((stopm >> j) & 1u) break;
-				bool skip, brk, ov;
-				if (MODE == 2) { skip = (A[u] < lq[j]) | (B[u] < lt[j]); brk = !skip & (lt[j] + 600 < C[u]); ov = (nq[j] > A[u]) | (nt[j] > B[u]); }
-				else { skip = (A[u] > lq[j]) | (B[u] > lt[j]); brk = !skip & (C[u] < lt[j]); ov = (A[u] > nq[j]) | (B[u] > nt[j]); }
-				int indel = (int)(D[u] - dl[j]); int ai = ABSV(indel);
-				int ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3));
-				int oq = (MODE == 2) ? (int)(nq[j] - A[u]) : (int)(A[u] - nq[j]);
-				int ot = (MODE == 2) ? (int)(nt[j] - B[u]) : (int)(B[u] - nt[j]);
-				if (ov) ns -= MAXV(oq, ot);
+				// sdp_judge with the common subexpressions folded: the limits are the node position + 6, so with
+				// oq/ot = how far the predecessor's end runs past the node's start, skip <=> max(oq, ot) > 6 and the
+				// overlap penalty is max(oq, ot, 0)
+				const int oq = (MODE == 2) ? (int)(nq[j] - A[u]) : (int)(A[u] - nq[j]);
+				const int ot = (MODE == 2) ? (int)(nt[j] - B[u]) : (int)(B[u] - nt[j]);
+				int ovl = MAXV(oq, ot); ovl = MAXV(ovl, 0);
+				const bool skip = ovl > 6;
+				const bool brk = !skip & ((MODE == 2) ? (lt[j] + 600 < C[u]) : (C[u] < lt[j]));
+				const int indel = (int)(D[u] - dl[j]); const int ai = ABSV(indel);
+				const int ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3)) - ovl;
 				bool ok = !skip & !brk & (ai <= 200);
 				uint64_t bm = dsb_ballot64(brk);
 				if (bm) {	// the reference stops at the newest predecessor that meets the distance cut

@@ -172,18 +172,20 @@ __global__ void __launch_bounds__(256) k_seed_probe(DsbDevIndex x, const DsbRead
 		if (lane == 0 && p1_local) atomicAdd(probe_counters, p1_local);
 	}
 }
-// the same probes for the reads list[0 .. gridDim.x) only, one block per read: the head start of the heaviest
-// reads (dsb_batch_run); the main launch writes the same words again
+// the same probes for the reads list[0 .. gridDim.x / DSB_HPROBE_SPLIT) only, DSB_HPROBE_SPLIT blocks per read: the
+// head start of the heaviest reads (dsb_batch_run); the main launch writes the same words again
+#define DSB_HPROBE_SPLIT 16
 __global__ void __launch_bounds__(256) k_seed_probe_reads(DsbDevIndex x, const DsbReadDesc *__restrict__ rd, const uint32_t *__restrict__ list,
                                                           const uint64_t *__restrict__ pk, uint64_t *__restrict__ bits, const uint8_t *__restrict__ summ, int summ_shift)
 {
-	const int lane = threadIdx.x & 63; const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)(threadIdx.x >> 6));
-	const uint32_t r = list[blockIdx.x];
+	const int lane = threadIdx.x & 63;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane((uint32_t)((blockIdx.x % DSB_HPROBE_SPLIT) * 4 + (threadIdx.x >> 6)));
+	const uint32_t r = list[blockIdx.x / DSB_HPROBE_SPLIT];
 	const uint32_t n_words = rd[r].n_words, n_items = 2 * n_words;
 	const int k = x.ek_len; const int sbm = x.single_base_max;
 	const uint64_t kmask = k >= 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
 	unsigned long long p1_local = 0;
-	for (uint32_t w0 = wave * DSB_PROBE_UN; w0 < n_items; w0 += 4 * DSB_PROBE_UN) {
+	for (uint32_t w0 = wave * DSB_PROBE_UN; w0 < n_items; w0 += 4 * DSB_HPROBE_SPLIT * DSB_PROBE_UN) {
 		DsbWordDesc wds[DSB_PROBE_UN]; bool have[DSB_PROBE_UN];
 #pragma unroll
 		for (int u = 0; u < DSB_PROBE_UN; u++) {
@@ -199,24 +201,26 @@ __global__ void __launch_bounds__(256) k_seed_probe_reads(DsbDevIndex x, const D
 // The batch ends when its slowest read ends, and the slow reads are the ones whose sparse DP explodes:
 // tandem-repeat-like reads, where every reference 9-mer matches many read positions.  k_repeat_score
 // estimates that cheaply -- the number of 12-mers of the forward strand that already occurred in the read,
-// via a 2-hash Bloom filter of 2^19 bits in LDS -- and k_order sorts the reads into 32 log2 buckets,
+// (every second one) via a 2-hash Bloom filter of 2^18 bits in LDS -- and k_order sorts the reads into 32 log2 buckets,
 // heaviest first.  Only the order of processing changes, never a result.
 __global__ void __launch_bounds__(256) k_repeat_score(const DsbReadDesc *rd, const uint64_t *pk, uint32_t *score)
 {
-	__shared__ uint32_t bloom[1u << 14];
+	// every second 12-mer into a 2^18-bit filter: same fill as all of them into 2^19 bits, half the work, and
+	// 32 KB of LDS lets four blocks share a CU
+	__shared__ uint32_t bloom[1u << 13];
 	__shared__ uint32_t dup;
 	DsbReadDesc d = rd[blockIdx.x];
-	for (uint32_t i = threadIdx.x; i < (1u << 14); i += 256) bloom[i] = 0;
+	for (uint32_t i = threadIdx.x; i < (1u << 13); i += 256) bloom[i] = 0;
 	if (threadIdx.x == 0) dup = 0;
 	__syncthreads();
 	const uint64_t *P = pk + d.pk_off;
 	uint32_t n = d.len >= 12 ? d.len - 12 + 1 : 0, mine = 0;
-	for (uint32_t p = threadIdx.x; p < n; p += 256) {
+	for (uint32_t p = 2 * threadIdx.x; p < n; p += 512) {
 		uint32_t w0 = p >> 5, sh = (p & 31) * 2;
 		uint64_t a = P[w0], b = P[w0 + 1];
 		uint64_t hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
 		uint64_t kmer = hi >> 40;                                  // 12 bases
-		uint32_t h1 = (uint32_t)(dsb_ph1(kmer) >> 20) & 0x7ffffu, h2 = (uint32_t)(dsb_ph2(kmer) >> 13) & 0x7ffffu;
+		uint32_t h1 = (uint32_t)(dsb_ph1(kmer) >> 20) & 0x3ffffu, h2 = (uint32_t)(dsb_ph2(kmer) >> 13) & 0x3ffffu;
 		uint32_t o1 = atomicOr(&bloom[h1 >> 5], 1u << (h1 & 31)), o2 = atomicOr(&bloom[h2 >> 5], 1u << (h2 & 31));
 		if ((o1 >> (h1 & 31)) & (o2 >> (h2 & 31)) & 1u) mine++;
 	}
@@ -347,7 +351,7 @@ struct dsb_ctx {
 	size_t n_reads; uint64_t n_words_total, total_bases, total_windows; uint32_t max_len;
 	int hist_max;
 	hipEvent_t ev[4]; dsb_timing timing; unsigned long long p1;
-	hipStream_t stream2; hipEvent_t ev_order, ev_heavy;   // the LPT ordering kernels (and the heaviest reads) run beside the seed probe
+	hipStream_t stream2; hipEvent_t ev_order, ev_heavy, ev_hprobe;   // the LPT ordering kernels (and the heaviest reads) run beside the seed probe
 	uint32_t *dbg_host, *dbg_dev;
 	dsb_opts opts;
 };
@@ -377,7 +381,7 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	c->opts.max_sec_N = opts ? opts->max_sec_N : 5; c->opts.n_slots = opts ? opts->n_slots : 0;
 	HIPCHK(hipStreamCreate(&c->stream));
 	for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
-	HIPCHK(hipStreamCreate(&c->stream2)); HIPCHK(hipEventCreate(&c->ev_order)); HIPCHK(hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming));
+	HIPCHK(hipStreamCreate(&c->stream2)); HIPCHK(hipEventCreate(&c->ev_order)); HIPCHK(hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_hprobe, hipEventDisableTiming));
 	// stage the index into HBM once
 	const DsbHostIndex *h = dsb_index_host(idx);
 	DsbDevIndex &dx = c->dx; memset(&dx, 0, sizeof dx);
@@ -427,7 +431,7 @@ extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 	hipFree(c->d_rd); hipFree(c->d_wd); hipFree(c->d_ascii); hipFree(c->d_bin); hipFree(c->d_pk); hipFree(c->d_bits);
 	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->d_score); hipFree(c->d_order);
 	for (int i = 0; i < 4; i++) hipEventDestroy(c->ev[i]);
-	hipEventDestroy(c->ev_order); hipEventDestroy(c->ev_heavy); hipStreamDestroy(c->stream2);
+	hipEventDestroy(c->ev_order); hipEventDestroy(c->ev_heavy); hipEventDestroy(c->ev_hprobe); hipStreamDestroy(c->stream2);
 	hipStreamDestroy(c->stream);
 	delete c;
 }
@@ -608,8 +612,10 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		if (n_heavy > n / 2) n_heavy = (unsigned)(n / 2);
 	}
 	if (n_heavy) {
-		HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_order, 0));
-		hipLaunchKernelGGL(k_seed_probe_reads, dim3(n_heavy), dim3(256), 0, c->stream2, c->dx, c->d_rd, (const uint32_t *)c->d_order, c->d_pk, c->d_bits, c->d_summ, c->summ_shift);
+		// their probes first, alone on the device (about a millisecond), then their classify launch on the second stream
+		hipLaunchKernelGGL(k_seed_probe_reads, dim3(n_heavy * DSB_HPROBE_SPLIT), dim3(256), 0, c->stream, c->dx, c->d_rd, (const uint32_t *)c->d_order, c->d_pk, c->d_bits, c->d_summ, c->summ_shift);
+		HIPCHK(hipEventRecord(c->ev_hprobe, c->stream));
+		HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_hprobe, 0));
 		hipLaunchKernelGGL(k_classify, dim3(n_heavy), dim3(64), 0, c->stream2, c->dx, c->d_rd, (uint32_t)n_heavy, (const unsigned int *)nullptr, (const uint32_t *)c->d_order,
 		                   c->d_bin, c->d_bits, c->arena, c->d_counters + 4, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout,
 		                   (uint32_t *)nullptr, 0u, (uint32_t)c->n_slots);
