@@ -167,6 +167,13 @@ DV uint32_t grp_excl_scan_u(uint32_t *red, int tid, uint32_t v, uint32_t *total)
 }
 #endif
 
+// words in LDS, addressed as LDS (ds_read / ds_cmpst / ds_add), not through generic pointers
+#ifdef DSB_HOST_EMU
+typedef uint32_t lds_u32;
+#else
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+#endif
+
 struct SDir { DsbSeed *seed_v; uint32_t l_seed_v; uint8_t *bin_read; const uint64_t *bits; uint32_t direction, total_score; };
 
 struct WCtx {
@@ -186,7 +193,7 @@ struct WCtx {
 	uint64_t *sortkey; uint32_t *sortidx;      // 2 x cap each (ping-pong)
 	uint8_t *win_mid, *win_right, *win_left;
 	uint32_t *red;             // LDS: DSB_GROUP/64+1 words for the group primitives
-	uint32_t *round_info;      // per-thread results of one island round of fast_classify (n | flag<<16 | ovf<<17)
+	uint32_t *round_info;      // per top island of fast_classify: lane | start<<8 | n<<16 | flag<<24 | ovf<<25
 	uint32_t dp_preds;         // predecessors scanned by the sparse DP of this read (heavy-read detection)
 	uint4 *ring;               // LDS: the most recent DSB_RING sparse-DP nodes of sdp_right/left ({t_pos,q_pos,len,score})
 	int status; int max_read_l;
@@ -718,13 +725,20 @@ DV int fast_island(WCtx &w, SDir *s_d, uint32_t read_len, uint32_t seed_idx)
 	int skip_next = 0;
 	uint32_t a_b_idx = w.n_anc;
 	for (int j = (int)sv.len - 1; j >= min_index;) {
-		if (LSPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
-		int kmer_index = sv.offset + j;
-		int string_index = kmer_index + l_ek - 1;
-		uint64_t prefixValue = prefix13(bin_read, string_index);
-		int n = bwt_MEM_search(x, bin_read + string_index, prefixValue, 2, 21 - 1, string_index, sp_set, m_r);
-		if (n == 0) { j -= 2; continue; }
-		j -= 3;
+		// Lanes walk different islands: search on until this lane has a MEM to map (or runs out of windows), so that
+		// the lanes of the wave reach the expensive map_seed below together instead of one or two at a time.
+		int n = 0, string_index = 0;
+		while (j >= min_index) {
+			if (LSPENT(w)) { w.status |= DSB_ST_TIMEOUT; j = min_index - 1; break; }
+			int kmer_index = sv.offset + j;
+			string_index = kmer_index + l_ek - 1;
+			uint64_t prefixValue = prefix13(bin_read, string_index);
+			n = bwt_MEM_search(x, bin_read + string_index, prefixValue, 2, 21 - 1, string_index, sp_set, m_r);
+			if (n == 0) { j -= 2; continue; }
+			j -= 3;
+			break;
+		}
+		if (n == 0) break;
 		int max_score = 0;
 		for (int q = 0; q < n; ++q) {
 			m_r[q].read_offset = string_index - m_r[q].match_len;
@@ -749,7 +763,7 @@ DV int fast_island(WCtx &w, SDir *s_d, uint32_t read_len, uint32_t seed_idx)
 DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 {
 	DsbSeed *sv_b = s_d->seed_v; uint32_t n_seed = s_d->l_seed_v;
-	const int lane = w.lane; uint32_t *const top_idx = w.top_idx;
+	const int lane = w.lane; uint32_t *const top_idx = w.top_idx; uint32_t *const info = w.round_info;
 	// indices of the top seeds, in order (lanes over seeds, ballot compaction)
 	uint32_t n_top = 0;
 	for (uint32_t b0 = 0; b0 < n_seed; b0 += DSB_WAVE) {
@@ -758,41 +772,59 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 		if (t) top_idx[n_top + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL))] = i;
 		n_top += (uint32_t)__popcll(m);
 	}
+	if (lane == 0) w.red[0] = 0;
 	wave_sync();
-	uint32_t skip_seed = 0xffffffffu;
-	DsbAnchor *main_anc = w.anc; uint64_t *main_sp = w.spset;
-	for (uint32_t base = 0; base < n_top; base += DSB_WAVE) {
-		uint32_t t = base + lane; bool valid = t < n_top;
-		uint32_t main_n = w.n_anc; int st_before = w.status;
-		const uint32_t my_sidx = valid ? top_idx[t] : 0xffffffffu;
-		w.anc = w.lane_anc + (size_t)lane * DSB_LANE_ANC_CAP; w.n_anc = 0; w.anc_cap = DSB_LANE_ANC_CAP;
-		w.spset = w.lane_spset + (size_t)lane * DSB_SPHASH;
-		int flag = valid ? fast_island(w, s_d, read_len, my_sidx) : 0;
+	if (n_top == 0) return;
+	DsbAnchor *const main_anc = w.anc; uint64_t *const main_sp = w.spset; const uint32_t main_n0 = w.n_anc;
+	// Phase 1: every lane walks islands into its own scratch (anchors, visited-row set), taking the next unwalked
+	// island from a counter in LDS when it is done with one -- island walks differ widely in length, and fixed
+	// rounds of 64 would wait for the longest of each round.  Per island: which lane, where in its scratch, how
+	// many anchors, the skip flag, and whether the scratch overflowed (then the island is redone at commit).
+	w.anc = w.lane_anc + (size_t)lane * DSB_LANE_ANC_CAP; w.n_anc = 0; w.anc_cap = DSB_LANE_ANC_CAP;
+	w.spset = w.lane_spset + (size_t)lane * DSB_SPHASH;
+	for (;;) {
+#ifdef DSB_HOST_EMU
+		const uint32_t t = w.red[0]++;
+#else
+		const uint32_t t = __hip_atomic_fetch_add((lds_u32 *)w.red, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+		if (t >= n_top) break;
+		const uint32_t start = w.n_anc; const int st_before = w.status;
+		int flag = fast_island(w, s_d, read_len, top_idx[t]);
 		int ovf = ((w.status & DSB_ST_ANC_OVF) && !(st_before & DSB_ST_ANC_OVF)) ? 1 : 0;
-		if (ovf) w.status &= ~DSB_ST_ANC_OVF;
-		uint32_t my_n = w.n_anc;
-		w.anc = main_anc; w.n_anc = main_n; w.anc_cap = DSB_ANC_CAP; w.spset = main_sp;
-		// each lane bumped its own copy of the set generation: continue from the largest so that no lane's stale
-		// entries can look current, and the group-uniform code below sees one value
-		w.sp_gen = (uint32_t)grp_max_i(w.red, lane, (int)w.sp_gen);
-		uint32_t n_round = MINV((uint32_t)DSB_WAVE, n_top - base);
+		if (ovf) { w.status &= ~DSB_ST_ANC_OVF; w.n_anc = start; }
+		info[t] = (uint32_t)lane | (start << 8) | ((w.n_anc - start) << 16) | ((uint32_t)flag << 24) | ((uint32_t)ovf << 25);
+	}
+	w.anc = main_anc; w.n_anc = main_n0; w.anc_cap = DSB_ANC_CAP; w.spset = main_sp;
+	// each lane bumped its own copy of the set generation: continue from the largest so that no lane's stale
+	// entries can look current, and the group-uniform code below sees one value
+	w.sp_gen = (uint32_t)grp_max_i(w.red, lane, (int)w.sp_gen);
+	wave_sync();
+	// Phase 2: commit in island order, 64 islands at a time.  A seed is skipped iff it directly follows (index + 1)
+	// a committed seed whose island raised the skip flag (src/cly.c:1530-1531) -- a bit recurrence over the
+	// islands -- and every lane then copies one island's anchors to their place in the list.
+	uint32_t skip_seed = 0xffffffffu;
+	for (uint32_t base = 0; base < n_top; base += DSB_WAVE) {
+		const uint32_t t = base + lane; const bool valid = t < n_top;
+		const uint32_t ri = valid ? info[t] : 0u, my_sidx = valid ? top_idx[t] : 0xffffffffu;
+		const uint32_t my_n = (ri >> 16) & 0xffu; const int flag = (ri >> 24) & 1, ovf = (ri >> 25) & 1;
+		const uint32_t main_n = w.n_anc;
+		const uint32_t n_round = MINV((uint32_t)DSB_WAVE, n_top - base);
 		bool committed = false;
 #if !defined(DSB_HOST_EMU) && DSB_GROUP == 64
-		{	// Commit in island order without walking the lanes one by one: a seed is skipped iff it directly follows
-			// (index + 1) a committed seed whose island raised the skip flag (src/cly.c:1530-1531) -- a bit recurrence
-			// over the lanes -- and every lane then copies its own anchors to its place in the list.
+		{
 			const uint64_t V = __ballot(valid), F = __ballot(valid && flag), O = __ballot(valid && ovf);
 			uint32_t prev = __shfl_up(my_sidx, 1);
 			bool adj = lane == 0 ? (my_sidx == skip_seed) : (my_sidx == prev + 1);
 			const uint64_t ADJ = __ballot(valid && adj);
 			if (O == 0) {
-				uint64_t S = ADJ & 1ULL;                                    // lane 0: skipped by the previous round's carry
+				uint64_t S = ADJ & 1ULL;                                    // lane 0: skipped by the previous chunk's carry
 				const uint64_t C = ADJ & (F << 1) & ~1ULL;
 				for (int l = 1; l < 64; l++) if (((C >> l) & 1ULL) && !((S >> (l - 1)) & 1ULL)) S |= 1ULL << l;
 				const bool keep = valid && !((S >> lane) & 1ULL);
 				uint32_t total, off = grp_excl_scan_u(w.red, lane, keep ? my_n : 0u, &total);
 				if (main_n + total <= DSB_ANC_CAP) {
-					const DsbAnchor *src = w.lane_anc + (size_t)lane * DSB_LANE_ANC_CAP;
+					const DsbAnchor *src = w.lane_anc + (size_t)(ri & 0xffu) * DSB_LANE_ANC_CAP + ((ri >> 8) & 0xffu);
 					if (keep) for (uint32_t k = 0; k < my_n; k++) main_anc[main_n + off + k] = src[k];
 					w.n_anc = main_n + total;
 					const uint64_t KF = F & V & ~S;                             // committed seeds that raise the skip flag
@@ -803,16 +835,14 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 		}
 #endif
 		if (!committed) {
-			w.round_info[lane] = my_n | ((uint32_t)flag << 16) | ((uint32_t)ovf << 17);
-			wave_sync();
 			for (uint32_t l = 0; l < n_round; l++) {
-				uint32_t sidx = top_idx[base + l];
-				uint32_t ri = w.round_info[l]; uint32_t n_l = ri & 0xffffu; int f_l = (ri >> 16) & 1, ovf_l = (ri >> 17) & 1;
+				const uint32_t sidx = top_idx[base + l], ri_l = info[base + l];
+				uint32_t n_l = (ri_l >> 16) & 0xffu; int f_l = (ri_l >> 24) & 1; const int ovf_l = (ri_l >> 25) & 1;
 				if (sidx == skip_seed) continue;
 				if (ovf_l) f_l = fast_island(w, s_d, read_len, sidx);
 				else {
 					if (w.n_anc + n_l > DSB_ANC_CAP) { w.status |= DSB_ST_ANC_OVF; n_l = 0; }
-					const DsbAnchor *src = w.lane_anc + (size_t)l * DSB_LANE_ANC_CAP;
+					const DsbAnchor *src = w.lane_anc + (size_t)(ri_l & 0xffu) * DSB_LANE_ANC_CAP + ((ri_l >> 8) & 0xffu);
 					for (uint32_t k = lane; k < n_l; k += DSB_WAVE) main_anc[w.n_anc + k] = src[k];
 					w.n_anc += n_l;
 				}
@@ -1185,12 +1215,6 @@ DV uint64_t ld_u64(const uint8_t *p)
 	__builtin_memcpy(&v, p, 8);
 	return v;
 }
-// the window table is addressed as LDS (ds_read / ds_cmpst), not through generic pointers
-#ifdef DSB_HOST_EMU
-typedef uint32_t lds_u32;
-#else
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-#endif
 DV uint32_t wtab_slot(uint32_t kmer, uint32_t slots) { return (uint32_t)(((uint64_t)(kmer * 2654435761u) * slots) >> 32); }
 // slots used for a window of n_q positions: load factor <= 0.5 for small windows, the whole table for big ones
 DV uint32_t wtab_size(uint32_t n_q) { uint32_t s = 2 * n_q; return s < 64u ? 64u : (s > DSB_WTAB_SLOTS ? DSB_WTAB_SLOTS : s); }

@@ -473,7 +473,7 @@ static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int n_s
 	a.off_lane_anc = o; o += al256((size_t)group * DSB_LANE_ANC_CAP * sizeof(DsbAnchor));
 	a.off_lane_sp = o;  o += al256((size_t)group * DSB_SPHASH * 8);
 	a.off_top = o;      o += al256(((size_t)(max_len >> 1) + 64) * 4);
-	a.off_round = o;    o += al256((size_t)group * 4);
+	a.off_round = o;    o += al256(((size_t)(max_len >> 1) + 64) * 4);
 	a.stride = al256(o);
 	*cur_slots = n_slots;
 	if (hipMalloc((void **)&a.base, a.stride * ((size_t)n_slots + DSB_HEAVY_SLOTS)) != hipSuccess) { a.base = nullptr; return DSB_ENOMEM; }

@@ -51,6 +51,7 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	add((size_t)2 * DSB_ANC_CAP * 8); add((size_t)2 * DSB_ANC_CAP * 4);  // 11,12
 	add(3 * DSB_REFWIN);                                                 // 13
 	add((size_t)DSB_LANE_ANC_CAP * sizeof(DsbAnchor)); add((size_t)DSB_SPHASH * 8); add(((size_t)(e->max_len >> 1) + 64) * 4);   // 14,15,16 (1 lane)
+	add(((size_t)(e->max_len >> 1) + 64) * 4);                           // 17 island records of fast_classify
 	e->arena.assign(o + 256, 0xCD);
 	memset(e->arena.data() + off[9], 0, DSB_SPHASH * 8); memset(e->arena.data() + off[15], 0, DSB_SPHASH * 8); e->w.sp_gen = 0;
 	uint8_t *s = e->arena.data(); WCtx &w = e->w;
@@ -62,7 +63,7 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	w.sortkey = (uint64_t *)(s + off[11]); w.sortidx = (uint32_t *)(s + off[12]);
 	w.win_mid = s + off[13]; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
 	static uint4 emu_ring[DSB_RING]; w.ring = emu_ring;
-	static uint32_t emu_red[4], emu_round[4]; w.red = emu_red; w.round_info = emu_round;
+	static uint32_t emu_red[4]; w.red = emu_red; w.round_info = (uint32_t *)(s + off[17]);
 	w.lane_anc = (DsbAnchor *)(s + off[14]); w.lane_spset = (uint64_t *)(s + off[15]); w.top_idx = (uint32_t *)(s + off[16]); w.anc_cap = DSB_ANC_CAP;
 }
 
