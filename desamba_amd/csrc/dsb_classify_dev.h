@@ -968,7 +968,7 @@ DN uint32_t *stable_sort_keys(WCtx &w, uint32_t n)
 }
 
 // chain_insert_M3 (src/cly.c:238-323): stable sort by (ref_ID, direction, ref_offset), then sparse DP per group
-#define DSB_RANKSORT_MAX 768
+#define DSB_RANKSORT_MAX (DSB_WTAB_SLOTS / 4)            /* 8-byte keys in the window table's LDS, at most half of it */
 DN void chain_sort_M3(WCtx &w)
 {
 	DsbAnchor *A = w.anc, *T = w.anc_tmp; const int32_t n = w.n_anc; const int lane = w.lane;
@@ -1009,7 +1009,7 @@ DN void chain_sort_M3(WCtx &w)
 }
 // ... and its serial part (one lane).  LDSMODE: the fields the DP touches were staged in LDS by chain_stage_M3
 // (q, t, mtch_len, then the score and predecessor arrays), n <= DSB_CHAINDP_LDS.
-#define DSB_CHAINDP_LDS 512
+#define DSB_CHAINDP_LDS (DSB_WTAB_SLOTS / 5 / 64 * 64)   /* five 4-byte arrays in the window table's LDS */
 #ifdef DSB_HOST_EMU
 typedef uint32_t lds_w32;
 #else
