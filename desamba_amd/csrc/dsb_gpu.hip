@@ -62,6 +62,14 @@ __global__ void __launch_bounds__(256) k_encode_bytes(const DsbReadDesc *rd, con
 	}
 }
 // one thread per packed word (32 bases, first base in the top bits); F words then R words, one zero pad word after each
+// 8 strand bytes (values 0..3, first base in the low byte) -> 16 bits, first base in the top bits
+__device__ __forceinline__ uint64_t pack8(uint64_t x)
+{
+	x = __builtin_bswap64(x);
+	x = (x | (x >> 6)) & 0x000F000F000F000FULL;
+	x = (x | (x >> 12)) & 0x000000FF000000FFULL;
+	return (x | (x >> 24)) & 0xFFFFULL;
+}
 __global__ void __launch_bounds__(256) k_encode_pack(const DsbReadDesc *rd, const uint8_t *bin, uint64_t *pk)
 {
 	DsbReadDesc d = rd[blockIdx.x];
@@ -71,7 +79,12 @@ __global__ void __launch_bounds__(256) k_encode_pack(const DsbReadDesc *rd, cons
 		uint32_t strand_r = t >= nw, wi = strand_r ? t - nw : t;
 		const uint8_t *S = strand_r ? F + L : F;
 		uint64_t v = 0;
-		for (uint32_t b = 0; b < 32; b++) { uint32_t p = wi * 32 + b; v = (v << 2) | (p < L ? S[p] : 0u); }
+		if (wi * 32 + 32 <= L) {        // a full word: four unaligned 8-byte loads
+			uint64_t q[4];
+			__builtin_memcpy(q, S + wi * 32, 32);
+			v = (pack8(q[0]) << 48) | (pack8(q[1]) << 32) | (pack8(q[2]) << 16) | pack8(q[3]);
+		} else
+			for (uint32_t b = 0; b < 32; b++) { uint32_t p = wi * 32 + b; v = (v << 2) | (p < L ? S[p] : 0u); }
 		pk[d.pk_off + t] = v;
 	}
 }
