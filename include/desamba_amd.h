@@ -71,10 +71,14 @@ typedef struct { uint32_t offset, len; uint8_t top; uint8_t pad[3]; } dsb_seed;
 
 /* per-batch device timings (HIP events on the ctx's stream), milliseconds */
 typedef struct {
-	float encode_ms, seed_probe_ms, classify_ms, total_ms;
+	float encode_ms, seed_probe_ms, classify_ms, total_ms;   /* classify_ms: the main k_classify launch */
 	uint64_t windows;      /* exist-kmer windows probed in table 0 (= P0 of SURVEY.md 8d) */
 	uint64_t probes_t1;    /* probes that continued to table 1 (= P1) */
 	uint64_t bases;
+	float order_ms;        /* scoring + ordering of the reads (longest first) + the probes of the early launch */
+	float tail_ms;         /* time the batch waited for the early launch (heaviest reads, second stream) after the main one */
+	uint32_t n_early;      /* reads that went through the early launch */
+	uint32_t pad;
 } dsb_timing;
 
 /* load_idx (src/idx.c:1103-1160, src/bwt.c:68-104): read <dir>/deSAMBA.* into host memory */
