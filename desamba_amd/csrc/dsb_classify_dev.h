@@ -1288,8 +1288,39 @@ DV uint64_t bin2kmer9(const uint8_t *s) { uint64_t v = 0;
 #define DSB_SDP_KEEP 3
 #define DSB_DP_UNROLL 4
 #define DSB_RING 16      /* recent DP nodes kept in LDS: the in-batch predecessors of the batched DP */
-struct SdpArgs { uint32_t q_bg, q_ed; const uint8_t *q_str, *t_str; uint32_t t_len, t_st; const lds_u32 *tab; uint32_t n_q; };
+struct SdpArgs { uint32_t q_bg, q_ed; const uint8_t *q_str, *t_str; uint32_t t_len, t_st; const lds_u32 *tab; uint32_t n_q; uint32_t *bm; };
 
+// one window position q_pos holding the 9-mer of reference position i: the two exact-match extensions and,
+// if the match qualifies, the node (src/cly.c:2390-2436)
+template <bool FWD, bool WRITE>
+DV void sdp_emit(const SdpArgs &a, int i, const uint8_t *c_t, uint32_t q_pos, DsbSms *out, uint32_t out_cap, uint32_t &cnt)
+{
+	if (FWD) {
+		int back_len = MEM_search(a.q_str + q_pos - 1, c_t - 1, false, 4);
+		if (back_len < 4 || i == 4) {
+			uint32_t max_search = a.q_ed - q_pos - 1;
+			max_search = MINV(max_search, a.t_len - i - 1) + 50;
+			int fwd = MEM_search(a.q_str + q_pos + 9, c_t + 9, true, max_search);
+			int total = back_len + fwd + 1;
+			if (total >= 4) {
+				if (WRITE && cnt < out_cap) { DsbSms *p = out + cnt; p->len = total; p->q_pos = q_pos - back_len; p->t_pos = i - back_len + a.t_st; }
+				cnt++;
+			}
+		}
+	} else {
+		int fwd = MEM_search(a.q_str + q_pos + 9, c_t + 9, true, 4);
+		if (fwd < 4 || i == 4) {
+			uint32_t max_search = q_pos;
+			max_search = MINV((long)max_search, (long)(c_t - a.t_str)) + 50;
+			int back_len = MEM_search(a.q_str + q_pos - 1, c_t - 1, false, max_search);
+			int total = back_len + fwd + 1;
+			if (total >= 4) {
+				if (WRITE && cnt < out_cap) { DsbSms *p = out + cnt; p->len = total; p->q_pos = q_pos - back_len; p->t_pos = (uint32_t)((long)(c_t - a.t_str) - back_len + a.t_st); }
+				cnt++;
+			}
+		}
+	}
+}
 template <bool FWD, bool WRITE>
 DV uint32_t sdp_visit(uint32_t &lsteps, int &st, const SdpArgs &a, int i, DsbSms *out, uint32_t out_cap)
 {
@@ -1320,55 +1351,29 @@ DV uint32_t sdp_visit(uint32_t &lsteps, int &st, const SdpArgs &a, int i, DsbSms
 		if (++lsteps > DSB_STEP_LIMIT) { st |= DSB_ST_TIMEOUT; break; }
 		uint32_t e = a.tab[sl];
 		if (e == DSB_WTAB_EMPTY) break;
-		if ((e >> 12) == k32) { if (nc < DSB_SDP_CAND) cand[nc++] = a.q_bg + (e & 0xfffu); else many = true; }
+		if ((e >> 12) == k32) { if (nc < DSB_SDP_CAND) cand[nc++] = a.q_bg + (e & 0xfffu); else { many = true; break; } }
 		sl = sl + 1 == slots ? 0 : sl + 1;
 	}
-	if (!many)
-		for (int u = 1; u < nc; u++) { uint32_t v = cand[u]; int z = u - 1; while (z >= 0 && cand[z] > v) { cand[z + 1] = cand[z]; z--; } cand[z + 1] = v; }
-	int64_t last = -1; int ci = 0;
-	for (;;) {
-		uint32_t q_pos;
-		if (!many) { if (ci >= nc) break; q_pos = cand[ci++]; }
-		else {	// more than DSB_SDP_CAND positions: repeated selection of the next larger one
-			int64_t best = -1;
-			for (uint32_t sl = sl0;;) {
-				if (++lsteps > DSB_STEP_LIMIT) { st |= DSB_ST_TIMEOUT; break; }
-				uint32_t e = a.tab[sl];
-				if (e == DSB_WTAB_EMPTY) break;
-				if ((e >> 12) == k32) { int64_t qp = (int64_t)a.q_bg + (e & 0xfffu); if (qp > last && (best < 0 || qp < best)) best = qp; }
-				sl = sl + 1 == slots ? 0 : sl + 1;
-			}
-			if (best < 0) break;
-			q_pos = (uint32_t)best; last = best;
+	if (many) {
+		// more than DSB_SDP_CAND window positions hold the 9-mer (repeats): a bitmap of the window, one bit per position
+		// (word w of this lane at bm[w * DSB_WAVE + lane], in the arena's sort scratch, idle here), filled by a
+		// second walk of the chain and read out in ascending order with ctz -- linear in the chain length
+		uint32_t *const bm = a.bm; const uint32_t nbw = (a.n_q + 31) >> 5;
+		for (uint32_t w_ = 0; w_ < nbw; w_++) bm[w_ * DSB_WAVE] = 0;
+		for (uint32_t sl = sl0;;) {
+			if (++lsteps > DSB_STEP_LIMIT) { st |= DSB_ST_TIMEOUT; break; }
+			uint32_t e = a.tab[sl];
+			if (e == DSB_WTAB_EMPTY) break;
+			if ((e >> 12) == k32) { uint32_t r = e & 0xfffu; bm[(r >> 5) * DSB_WAVE] |= 1u << (r & 31); }
+			sl = sl + 1 == slots ? 0 : sl + 1;
 		}
-		{
-			if (FWD) {
-				int back_len = MEM_search(a.q_str + q_pos - 1, c_t - 1, false, 4);
-				if (back_len < 4 || i == 4) {
-					uint32_t max_search = a.q_ed - q_pos - 1;
-					max_search = MINV(max_search, a.t_len - i - 1) + 50;
-					int fwd = MEM_search(a.q_str + q_pos + 9, c_t + 9, true, max_search);
-					int total = back_len + fwd + 1;
-					if (total >= 4) {
-						if (WRITE && cnt < out_cap) { DsbSms *p = out + cnt; p->len = total; p->q_pos = q_pos - back_len; p->t_pos = i - back_len + a.t_st; }
-						cnt++;
-					}
-				}
-			} else {
-				int fwd = MEM_search(a.q_str + q_pos + 9, c_t + 9, true, 4);
-				if (fwd < 4 || i == 4) {
-					uint32_t max_search = q_pos;
-					max_search = MINV((long)max_search, (long)(c_t - a.t_str)) + 50;
-					int back_len = MEM_search(a.q_str + q_pos - 1, c_t - 1, false, max_search);
-					int total = back_len + fwd + 1;
-					if (total >= 4) {
-						if (WRITE && cnt < out_cap) { DsbSms *p = out + cnt; p->len = total; p->q_pos = q_pos - back_len; p->t_pos = (uint32_t)((long)(c_t - a.t_str) - back_len + a.t_st); }
-						cnt++;
-					}
-				}
-			}
-		}
+		for (uint32_t w_ = 0; w_ < nbw; w_++)
+			for (uint32_t cur = bm[w_ * DSB_WAVE]; cur; cur &= cur - 1)
+				sdp_emit<FWD, WRITE>(a, i, c_t, a.q_bg + 32 * w_ + (uint32_t)__builtin_ctz(cur), out, out_cap, cnt);
+		return cnt;
 	}
+	for (int u = 1; u < nc; u++) { uint32_t v = cand[u]; int z = u - 1; while (z >= 0 && cand[z] > v) { cand[z + 1] = cand[z]; z--; } cand[z + 1] = v; }
+	for (int ci = 0; ci < nc; ci++) sdp_emit<FWD, WRITE>(a, i, c_t, cand[ci], out, out_cap, cnt);
 	return cnt;
 }
 
@@ -1410,7 +1415,7 @@ DV uint32_t sdp_nq(uint32_t L, uint32_t q_bg, uint32_t q_ed)
 DN uint32_t sdp_match_n(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len,
                         uint32_t t_st, bool isForward)
 {
-	SdpArgs a; a.q_bg = q_bg; a.q_ed = q_ed; a.q_str = q_str; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st; a.tab = (const lds_u32 *)w.wtab;
+	SdpArgs a; a.q_bg = q_bg; a.q_ed = q_ed; a.q_str = q_str; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st; a.tab = (const lds_u32 *)w.wtab; a.bm = reinterpret_cast<uint32_t *>(w.sortkey) + w.lane;
 	a.n_q = sdp_nq(w.L, q_bg, q_ed);
 	if (a.n_q > DSB_WTAB_MAXQ) { w.status |= DSB_ST_SMS_OVF; return n_sms; }     // cannot happen: windows are <= 2001 wide
 	uint32_t t_kmer_num = t_len - 9 + 1;
