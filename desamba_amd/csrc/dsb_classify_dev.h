@@ -1288,7 +1288,7 @@ DV uint64_t bin2kmer9(const uint8_t *s) { uint64_t v = 0;
 #define DSB_SDP_KEEP 3
 #define DSB_DP_UNROLL 4
 #define DSB_RING 16      /* recent DP nodes kept in LDS: the in-batch predecessors of the batched DP */
-struct SdpArgs { uint32_t q_bg, q_ed; const uint8_t *q_str, *t_str; uint32_t t_len, t_st; const lds_u32 *tab; uint32_t n_q; uint32_t *bm; };
+struct SdpArgs { uint32_t q_bg, q_ed; const uint8_t *q_str, *t_str; uint32_t t_len, t_st; const lds_u32 *tab; uint32_t n_q; uint32_t *bm; uint4 *lnodes; };
 
 // one window position q_pos holding the 9-mer of reference position i: the two exact-match extensions and,
 // if the match qualifies, the node (src/cly.c:2390-2436)
@@ -1385,7 +1385,7 @@ DN uint32_t sdp_match_t(WCtx &w, const SdpArgs a, uint32_t n_sms)
 	uint32_t n_pos = (t_kmer_num - 4 + 3) / 4;                      // i = 4, 8, ... < t_kmer_num
 	// the context lives in memory (it is shared by reference with non-inlined callers): work on copies
 	const int lane = w.lane; uint32_t *const red = w.red; DsbSms *const sms = w.sms;
-	uint32_t lsteps = w.lsteps; int st = 0;
+	uint32_t lsteps = w.lsteps, mirror_bad = 0; int st = 0;
 	for (uint32_t g = 0; g < n_pos; g += DSB_WAVE) {
 		uint32_t pI = g + lane; bool valid = pI < n_pos; int i = 4 + 4 * (int)pI;
 		DsbSms keep[DSB_SDP_KEEP];
@@ -1394,14 +1394,20 @@ DN uint32_t sdp_match_t(WCtx &w, const SdpArgs a, uint32_t n_sms)
 		if (total == 0) continue;
 		if (n_sms + total > DSB_SMS_CAP) { st |= DSB_ST_SMS_OVF; break; }
 		DsbSms *dst = sms + n_sms + off;
-		if (cnt <= DSB_SDP_KEEP) { for (uint32_t k = 0; k < cnt; k++) { dst[k].len = keep[k].len; dst[k].q_pos = keep[k].q_pos; dst[k].t_pos = keep[k].t_pos; } }
-		else sdp_visit<FWD, true>(lsteps, st, a, i, dst, 0xffffffffu);
+		if (cnt <= DSB_SDP_KEEP) {
+			for (uint32_t k = 0; k < cnt; k++) {
+				dst[k].len = keep[k].len; dst[k].q_pos = keep[k].q_pos; dst[k].t_pos = keep[k].t_pos;
+				// the first 64 nodes of the list are mirrored in LDS for the in-register DP of sdp_middle_M2
+				if (a.lnodes && n_sms + off + k < 64u) { uint4 r; r.x = keep[k].t_pos; r.y = keep[k].q_pos; r.z = keep[k].len; r.w = 0; a.lnodes[n_sms + off + k] = r; }
+			}
+		} else sdp_visit<FWD, true>(lsteps, st, a, i, dst, 0xffffffffu);
+		if (a.lnodes && dsb_ballot64(cnt > DSB_SDP_KEEP)) mirror_bad = 0x80000000u;
 		n_sms += total;
 		wave_sync();
 	}
 	w.lsteps = lsteps;
 	if (st) w.status |= st;
-	return n_sms;
+	return n_sms | mirror_bad;      // bit 31: some nodes are missing from the LDS mirror
 }
 
 // read positions sdp_match can return: q_bg <= pos <= q_ed, and pos has a 9-mer (pos <= L - 9)
@@ -1413,9 +1419,9 @@ DV uint32_t sdp_nq(uint32_t L, uint32_t q_bg, uint32_t q_ed)
 
 // appends the nodes to w.sms[n_sms...] and returns the new count (w.n_sms is not touched)
 DN uint32_t sdp_match_n(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len,
-                        uint32_t t_st, bool isForward)
+                        uint32_t t_st, bool isForward, uint4 *lnodes)
 {
-	SdpArgs a; a.q_bg = q_bg; a.q_ed = q_ed; a.q_str = q_str; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st; a.tab = (const lds_u32 *)w.wtab; a.bm = reinterpret_cast<uint32_t *>(w.sortkey) + w.lane;
+	SdpArgs a; a.lnodes = lnodes; a.q_bg = q_bg; a.q_ed = q_ed; a.q_str = q_str; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st; a.tab = (const lds_u32 *)w.wtab; a.bm = reinterpret_cast<uint32_t *>(w.sortkey) + w.lane;
 	a.n_q = sdp_nq(w.L, q_bg, q_ed);
 	if (a.n_q > DSB_WTAB_MAXQ) { w.status |= DSB_ST_SMS_OVF; return n_sms; }     // cannot happen: windows are <= 2001 wide
 	uint32_t t_kmer_num = t_len - 9 + 1;
@@ -1427,7 +1433,7 @@ DV void sdp_match(WCtx &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, c
                   int tbl, uint32_t t_st, bool isForward)
 {
 	(void)key_len; (void)tbl;
-	w.n_sms = sdp_match_n(w, w.n_sms, q_bg, q_ed, q_str, t_str, t_len, t_st, isForward);
+	w.n_sms = sdp_match_n(w, w.n_sms, q_bg, q_ed, q_str, t_str, t_len, t_st, isForward, nullptr) & 0x7fffffffu;
 }
 
 DV void ring_put(WCtx &w, uint32_t idx, uint32_t t_pos, uint32_t q_pos, uint32_t len, uint32_t score)
@@ -1681,10 +1687,12 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 	const int lane = w.lane; const uint32_t L = w.L;
 	DsbAnchor ca = A[c_a];
 	const uint64_t t_offset = x->refinfo[ca.ref_ID].seq_offset;
+	// the chain is a linked list: the anchor after next is loaded one gap ahead, off the critical path
+	DsbAnchor pa = A[ca.pre != -1 ? ca.pre : c_a];
 	for (;;) {
 		const int32_t pre_a = ca.pre;
 		if (pre_a == -1) { score += ca.mtch_len - 9 + 1; break; }
-		const DsbAnchor pa = A[pre_a];
+		const DsbAnchor nxt = A[pa.pre != -1 ? pa.pre : pre_a];
 		const int pre_mch = pa.mtch_len;
 		const int pre_refoffset = pa.ref_offset - 3;
 		const int total_ref_len = ca.ref_offset - (pre_refoffset + pre_mch) + 3;
@@ -1692,7 +1700,7 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 		// has to go through the general path
 		DsbSms first; first.score = score; first.q_pos = pa.index_in_read; first.t_pos = pa.ref_offset; first.len = pa.mtch_len - 9 + 1;
 		DsbSms last; last.score = 0; last.q_pos = ca.index_in_read; last.t_pos = ca.ref_offset; last.len = ca.mtch_len - 9 + 1;
-		uint32_t n_sms = 1;
+		uint32_t n_sms = 1; uint4 *lnodes = nullptr; bool mirror = false;
 		if (total_ref_len > 12) {
 			uint8_t *ref = win;
 			if (total_ref_len >= 2000) { w.status |= DSB_ST_TIMEOUT; w.n_sms = 0; return 0; }   // the reference aborts here (xassert, src/cly.c:2473)
@@ -1705,15 +1713,17 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 			const uint32_t n_q = sdp_nq(L, q_bg, q_ed), slots = wtab_size(n_q);
 			const int32_t q_lo = (int32_t)q_bg - 16, q_hi = (int32_t)q_ed + 80;
 			const uint32_t q_bytes = q_hi > q_lo ? (uint32_t)(q_hi - q_lo + 7) & ~7u : 0u, t_bytes = ((uint32_t)total_ref_len + 64 + 7) & ~7u;
-			if (n_q > 0 && q_bytes && q_lo >= -(int32_t)DSB_QPAD_L + 8 && 4 * slots + q_bytes + 8 + t_bytes + 8 <= 4 * DSB_WTAB_SLOTS) {
+			if (n_q > 0 && q_bytes && q_lo >= -(int32_t)DSB_QPAD_L + 8 && 4 * slots + q_bytes + 8 + t_bytes + 8 + 1024 <= 4 * DSB_WTAB_SLOTS) {
 				uint8_t *lq = reinterpret_cast<uint8_t *>(wtab + slots), *lt = lq + q_bytes + 8;
+				lnodes = reinterpret_cast<uint4 *>(lt + t_bytes + (((4 * slots + q_bytes + t_bytes) & 8u) ? 0 : 8));   // 16-byte aligned: the table starts 16-aligned
 				for (uint32_t k = 8 * lane; k < q_bytes; k += 8 * DSB_WAVE) *reinterpret_cast<uint64_t *>(lq + k) = ld_u64(q_str + q_lo + (int32_t)k);
 				ref = lt; qs = lq - q_lo;
 			}
 			get_ref_wave(x->refbin, lane, ref, ref_offset, total_ref_len);
 			for (int k = total_ref_len + lane; k < total_ref_len + 64; k += DSB_WAVE) ref[k] = DSB_TPAD_VAL;   // reads reach <= 58 past the window
 			wave_sync();
-			n_sms = sdp_match_n(w, n_sms, q_bg, q_ed, qs, ref, total_ref_len, pre_refoffset + pre_mch, true);
+			n_sms = sdp_match_n(w, n_sms, q_bg, q_ed, qs, ref, total_ref_len, pre_refoffset + pre_mch, true, lnodes);
+			mirror = lnodes != nullptr && !(n_sms >> 31); n_sms &= 0x7fffffffu;
 		}
 		n_sms++;                                                     // the last node
 		if (n_sms > DSB_SMS_CAP) { w.status |= DSB_ST_SMS_OVF; n_sms = DSB_SMS_CAP; }
@@ -1725,7 +1735,7 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 				// no distance cut), wave max; nothing is written back -- the list is local to this gap.
 				const uint32_t nn = n_sms;
 				DsbSms me; me.t_pos = me.q_pos = me.len = 0;
-				if (lane == 0) me = first; else if ((uint32_t)lane == nn - 1) me = last; else if ((uint32_t)lane < nn) me = S[lane];
+				if (lane == 0) me = first; else if ((uint32_t)lane == nn - 1) me = last; else if ((uint32_t)lane < nn) { if (mirror) { uint4 r = lnodes[lane]; me.t_pos = r.x; me.q_pos = r.y; me.len = r.z; } else me = S[lane]; }
 				me.score = (lane == 0) ? (uint32_t)score : 0u;
 				for (uint32_t ci = 1; ci < nn; ci++) {
 					DsbSms cs; cs.t_pos = dsb_shfl(me.t_pos, (int)ci); cs.q_pos = dsb_shfl(me.q_pos, (int)ci); cs.len = dsb_shfl(me.len, (int)ci); cs.score = 0;
@@ -1760,7 +1770,7 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 				}
 			}
 		}
-		ca = pa;
+		ca = pa; pa = nxt;
 	}
 	w.n_sms = 0;
 	return score - 10000;
