@@ -106,21 +106,35 @@ DV void wave_sync()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 DV int grp_first(uint32_t *, int, bool p) { uint64_t m = __ballot(p); return m ? (int)__builtin_ctzll(m) : 64; }
+// Wave-wide max and exclusive prefix sum with DPP row operations (no LDS crossbar, no waits): within quads,
+// across the row of 16, then row_bcast:15 / row_bcast:31 carry row totals upwards; lane 63 holds the result.
+#define DSB_DPP(old, src, ctrl, rmask, bmask, bc) __builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, rmask, bmask, bc)
 DV int grp_max_i(uint32_t *, int, int v)
 {
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) { int u = __shfl_xor(v, o); v = u > v ? u : v; }
-	return v;
+	int r = v, t;
+	t = DSB_DPP(r, r, 0xb1, 0xf, 0xf, false); r = t > r ? t : r;       // quad_perm:[1,0,3,2]
+	t = DSB_DPP(r, r, 0x4e, 0xf, 0xf, false); r = t > r ? t : r;       // quad_perm:[2,3,0,1]
+	t = DSB_DPP(r, r, 0x124, 0xf, 0xf, false); r = t > r ? t : r;      // row_ror:4
+	t = DSB_DPP(r, r, 0x128, 0xf, 0xf, false); r = t > r ? t : r;      // row_ror:8 -> every lane: max of its row
+	t = DSB_DPP(r, r, 0x142, 0xa, 0xf, false); r = t > r ? t : r;      // row_bcast:15 into rows 1, 3
+	t = DSB_DPP(r, r, 0x143, 0xc, 0xf, false); r = t > r ? t : r;      // row_bcast:31 into rows 2, 3
+	return __builtin_amdgcn_readlane(r, 63);
 }
-DV uint32_t grp_excl_scan_u(uint32_t *, int lane, uint32_t v, uint32_t *total)
+DV uint32_t grp_excl_scan_u(uint32_t *, int, uint32_t v, uint32_t *total)
 {
-	uint32_t inc = v;
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
-	*total = __shfl(inc, 63);
-	return inc - v;
+	uint32_t s = v;
+	s += (uint32_t)DSB_DPP(0, v, 0x111, 0xf, 0xf, true);                 // row_shr:1
+	s += (uint32_t)DSB_DPP(0, v, 0x112, 0xf, 0xf, true);                 // row_shr:2
+	s += (uint32_t)DSB_DPP(0, v, 0x113, 0xf, 0xf, true);                 // row_shr:3 -> own + 3 lower neighbours of the row
+	s += (uint32_t)DSB_DPP(0, s, 0x114, 0xf, 0xe, true);                 // row_shr:4, banks 1..3
+	s += (uint32_t)DSB_DPP(0, s, 0x118, 0xf, 0xc, true);                 // row_shr:8, banks 2..3 -> inclusive scan of the row
+	s += (uint32_t)DSB_DPP(0, s, 0x142, 0xa, 0xf, true);                 // row_bcast:15 into rows 1, 3
+	s += (uint32_t)DSB_DPP(0, s, 0x143, 0xc, 0xf, true);                 // row_bcast:31 into rows 2, 3 -> inclusive scan of the wave
+	*total = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
+	return s - v;
 }
-#define dsb_shfl(v, l) __shfl(v, l)
+// every use reads one lane, the same for the whole wave: v_readlane
+template <class T> DV T dsb_shfl(T v, int l) { static_assert(sizeof(T) == 4, "32-bit values only"); return (T)__builtin_amdgcn_readlane((int)v, l); }
 #define dsb_ballot64(p) __ballot(p)
 #define DSB_RFL(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
 #else
