@@ -95,6 +95,7 @@ DV uint32_t grp_excl_scan_u(uint32_t *, int, uint32_t v, uint32_t *total) { *tot
 template <class T> static inline T dsb_shfl(T v, int) { return v; }
 #define dsb_ballot64(p) ((p) ? 1ULL : 0ULL)
 #define DSB_RFL(v) (v)
+#define DSB_RFL64(v) (v)
 #elif DSB_GROUP == 64
 DV void wave_sync()
 {	// The 64 lanes of one wavefront exchange data through memory (LDS or global).  A wavefront's memory
@@ -137,8 +138,10 @@ DV uint32_t grp_excl_scan_u(uint32_t *, int, uint32_t v, uint32_t *total)
 template <class T> DV T dsb_shfl(T v, int l) { static_assert(sizeof(T) == 4, "32-bit values only"); return (T)__builtin_amdgcn_readlane((int)v, l); }
 #define dsb_ballot64(p) __ballot(p)
 #define DSB_RFL(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
+#define DSB_RFL64(v) (((uint64_t)DSB_RFL((uint32_t)((uint64_t)(v) >> 32)) << 32) | (uint64_t)DSB_RFL((uint32_t)(v)))
 #else
 #define DSB_RFL(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
+#define DSB_RFL64(v) (((uint64_t)DSB_RFL((uint32_t)((uint64_t)(v) >> 32)) << 32) | (uint64_t)DSB_RFL((uint32_t)(v)))
 #define dsb_ballot64(p) ((unsigned long long)__syncthreads_or(p))
 DV void wave_sync() { __syncthreads(); }
 // red: DSB_GROUP/64 + 1 words of LDS
@@ -617,7 +620,10 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 
 // ---- seeds from the exist-kmer bit vector (search_exist_kmer_M2 + get_seed_vector_M2,
 // src/cly.c:1071-1234).  The probe kernel has answered get_exist_kmer for every window.
-DV int ebit(const uint64_t *bits, uint32_t i) { return (int)((bits[i >> 6] >> (i & 63)) & 1ULL); }
+// The scan runs on one lane; a word read back through readfirstlane is a scalar, and so is everything computed
+// from it: the scan's arithmetic and branches then go to the scalar unit instead of one-lane vector instructions.
+DV uint64_t sbits(const uint64_t *bits, uint32_t w) { uint64_t v = bits[w]; return DSB_RFL64(v); }
+DV int ebit(const uint64_t *bits, uint32_t i) { return (int)((sbits(bits, i >> 6) >> (i & 63)) & 1ULL); }
 
 // number of consecutive set bits at positions start, start+1, ... (< n), at most maxc
 DV uint32_t run_ones_up(const uint64_t *bits, uint32_t n, uint32_t start, uint32_t maxc)
@@ -625,7 +631,7 @@ DV uint32_t run_ones_up(const uint64_t *bits, uint32_t n, uint32_t start, uint32
 	uint32_t c = 0;
 	while (c < maxc && start < n) {
 		uint32_t b = start & 63;
-		uint64_t x = ~(bits[start >> 6] >> b);              // zeros where the run continues
+		uint64_t x = ~(sbits(bits, start >> 6) >> b);       // zeros where the run continues
 		uint32_t avail = 64 - b, r = x ? (uint32_t)__builtin_ctzll(x) : 64u;
 		if (r > avail) r = avail;
 		if (r > n - start) r = n - start;
@@ -641,7 +647,7 @@ DV uint32_t run_ones_down(const uint64_t *bits, int start, uint32_t maxc)
 	uint32_t c = 0;
 	while (c < maxc && start >= 0) {
 		uint32_t b = (uint32_t)start & 63;
-		uint64_t x = ~(bits[start >> 6] << (63 - b));
+		uint64_t x = ~(sbits(bits, (uint32_t)start >> 6) << (63 - b));
 		uint32_t avail = b + 1, r = x ? (uint32_t)__builtin_clzll(x) : 64u;
 		if (r > avail) r = avail;
 		if (r > maxc - c) r = maxc - c;
@@ -652,8 +658,12 @@ DV uint32_t run_ones_down(const uint64_t *bits, int start, uint32_t maxc)
 }
 #define DSB_M3 0x9249249249249249ULL      /* bits 0,3,6,...,63 */
 
-DN void seed_vector_scan(const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t direction, uint32_t *ns_out, uint32_t *total_out)
+DN void seed_vector_scan(const uint64_t *bits_, uint32_t n_, DsbSeed *sv_, uint32_t direction_, uint32_t *ns_out, uint32_t *total_out)
 {
+	// arguments of a non-inlined function arrive in vector registers and count as divergent: make them scalars
+	// (one lane runs this) so that the scan below compiles to scalar instructions and branches
+	const uint64_t *bits = (const uint64_t *)DSB_RFL64((uint64_t)bits_); DsbSeed *sv = (DsbSeed *)DSB_RFL64((uint64_t)sv_);
+	const uint32_t n = DSB_RFL(n_), direction = DSB_RFL(direction_);
 	// Same scan as search_exist_kmer_M2 (probe every 3rd window, extend back <= 2, forward to len 61,
 	// resume 3 past the seed), but 64 windows per load: the next probe hit is a ctz over the word
 	// masked to the probe phase, the extensions are run-length counts.  The top-seed marking of
@@ -674,7 +684,7 @@ DN void seed_vector_scan(const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t
 		uint32_t i = 3 - 1;
 		while (i < n) {
 			uint32_t b = i & 63;
-			uint64_t x = (bits[i >> 6] >> b) & DSB_M3;
+			uint64_t x = (sbits(bits, i >> 6) >> b) & DSB_M3;
 			if (!x) { i += ((64 - b + 2) / 3) * 3; continue; }
 			i += (uint32_t)__builtin_ctzll(x);
 			if (i >= n) break;
@@ -689,7 +699,7 @@ DN void seed_vector_scan(const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t
 		int i = (int)n - 3;
 		while (i >= 0) {
 			uint32_t b = (uint32_t)i & 63;
-			uint64_t x = (bits[i >> 6] << (63 - b)) & DSB_M3;
+			uint64_t x = (sbits(bits, (uint32_t)i >> 6) << (63 - b)) & DSB_M3;
 			if (!x) { i -= (int)(((b + 1 + 2) / 3) * 3); continue; }
 			i -= (int)__builtin_clzll(x);
 			uint32_t fwd = 0;
