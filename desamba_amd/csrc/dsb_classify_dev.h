@@ -210,7 +210,7 @@ struct WCtx {
 	uint64_t *sortkey; uint32_t *sortidx;      // 2 x cap each (ping-pong)
 	uint8_t *win_mid, *win_right, *win_left;
 	uint32_t *red;             // LDS: DSB_GROUP/64+1 words for the group primitives
-	uint32_t *round_info;      // per top island of fast_classify: lane | start<<8 | n<<16 | flag<<24 | ovf<<25
+	uint32_t *round_info;      // per top island of fast_classify: lane | start<<6 | n<<16 | flag<<26 | ovf<<27
 	uint32_t dp_preds;         // predecessors scanned by the sparse DP of this read (heavy-read detection)
 	uint4 *ring;               // LDS: the most recent DSB_RING sparse-DP nodes of sdp_right/left ({t_pos,q_pos,len,score})
 	int status; int max_read_l;
@@ -783,7 +783,9 @@ DV int fast_island(WCtx &w, SDir *s_d, uint32_t read_len, uint32_t seed_idx)
 // one per lane, each into its own scratch (anchors, visited-row set); the results are then committed in
 // island order exactly as the reference would have produced them.  An island whose anchors do not fit
 // its lane scratch is redone by the whole wave straight into the anchor array.
-#define DSB_LANE_ANC_CAP 192
+#ifndef DSB_LANE_ANC_CAP
+#define DSB_LANE_ANC_CAP 192       /* < 1024: the island records hold start and count in 10 bits each */
+#endif
 DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 {
 	DsbSeed *sv_b = s_d->seed_v; uint32_t n_seed = s_d->l_seed_v;
@@ -814,10 +816,12 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 #endif
 		if (t >= n_top) break;
 		const uint32_t start = w.n_anc; const int st_before = w.status;
+		// a full scratch: an overflowing walk would overwrite its last slot, which belongs to an earlier island
+		if (start >= DSB_LANE_ANC_CAP) { info[t] = (uint32_t)lane | (start << 6) | (1u << 27); continue; }
 		int flag = fast_island(w, s_d, read_len, top_idx[t]);
 		int ovf = ((w.status & DSB_ST_ANC_OVF) && !(st_before & DSB_ST_ANC_OVF)) ? 1 : 0;
 		if (ovf) { w.status &= ~DSB_ST_ANC_OVF; w.n_anc = start; }
-		info[t] = (uint32_t)lane | (start << 8) | ((w.n_anc - start) << 16) | ((uint32_t)flag << 24) | ((uint32_t)ovf << 25);
+		info[t] = (uint32_t)lane | (start << 6) | ((w.n_anc - start) << 16) | ((uint32_t)flag << 26) | ((uint32_t)ovf << 27);
 	}
 	w.anc = main_anc; w.n_anc = main_n0; w.anc_cap = DSB_ANC_CAP; w.spset = main_sp;
 	// each lane bumped its own copy of the set generation: continue from the largest so that no lane's stale
@@ -831,7 +835,7 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 	for (uint32_t base = 0; base < n_top; base += DSB_WAVE) {
 		const uint32_t t = base + lane; const bool valid = t < n_top;
 		const uint32_t ri = valid ? info[t] : 0u, my_sidx = valid ? top_idx[t] : 0xffffffffu;
-		const uint32_t my_n = (ri >> 16) & 0xffu; const int flag = (ri >> 24) & 1, ovf = (ri >> 25) & 1;
+		const uint32_t my_n = (ri >> 16) & 0x3ffu; const int flag = (ri >> 26) & 1, ovf = (ri >> 27) & 1;
 		const uint32_t main_n = w.n_anc;
 		const uint32_t n_round = MINV((uint32_t)DSB_WAVE, n_top - base);
 		bool committed = false;
@@ -848,7 +852,7 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 				const bool keep = valid && !((S >> lane) & 1ULL);
 				uint32_t total, off = grp_excl_scan_u(w.red, lane, keep ? my_n : 0u, &total);
 				if (main_n + total <= DSB_ANC_CAP) {
-					const DsbAnchor *src = w.lane_anc + (size_t)(ri & 0xffu) * DSB_LANE_ANC_CAP + ((ri >> 8) & 0xffu);
+					const DsbAnchor *src = w.lane_anc + (size_t)(ri & 0x3fu) * DSB_LANE_ANC_CAP + ((ri >> 6) & 0x3ffu);
 					if (keep) for (uint32_t k = 0; k < my_n; k++) main_anc[main_n + off + k] = src[k];
 					w.n_anc = main_n + total;
 					const uint64_t KF = F & V & ~S;                             // committed seeds that raise the skip flag
@@ -861,12 +865,12 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 		if (!committed) {
 			for (uint32_t l = 0; l < n_round; l++) {
 				const uint32_t sidx = top_idx[base + l], ri_l = info[base + l];
-				uint32_t n_l = (ri_l >> 16) & 0xffu; int f_l = (ri_l >> 24) & 1; const int ovf_l = (ri_l >> 25) & 1;
+				uint32_t n_l = (ri_l >> 16) & 0x3ffu; int f_l = (ri_l >> 26) & 1; const int ovf_l = (ri_l >> 27) & 1;
 				if (sidx == skip_seed) continue;
 				if (ovf_l) f_l = fast_island(w, s_d, read_len, sidx);
 				else {
 					if (w.n_anc + n_l > DSB_ANC_CAP) { w.status |= DSB_ST_ANC_OVF; n_l = 0; }
-					const DsbAnchor *src = w.lane_anc + (size_t)(ri_l & 0xffu) * DSB_LANE_ANC_CAP + ((ri_l >> 8) & 0xffu);
+					const DsbAnchor *src = w.lane_anc + (size_t)(ri_l & 0x3fu) * DSB_LANE_ANC_CAP + ((ri_l >> 6) & 0x3ffu);
 					for (uint32_t k = lane; k < n_l; k += DSB_WAVE) main_anc[w.n_anc + k] = src[k];
 					w.n_anc += n_l;
 				}
@@ -1628,7 +1632,7 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 		// per predecessor (one per lane and unrolled group), shared by all nodes of the batch:
 		//   MODE 1: A = q_pos+len+8, B = t_pos+len+8, C = t_pos+600;  MODE 2: A = q_pos, B = t_pos, C = t_pos
 		//   D = q_pos - t_pos, S = score.  Lanes past the start of the list carry values that fail the first test.
-		uint32_t A[DSB_DP_UNROLL], B[DSB_DP_UNROLL], C[DSB_DP_UNROLL], D[DSB_DP_UNROLL], S[DSB_DP_UNROLL];
+		uint32_t A[DSB_DP_UNROLL], B[DSB_DP_UNROLL], C[DSB_DP_UNROLL], D[DSB_DP_UNROLL], S[DSB_DP_UNROLL]; bool wrapped[DSB_DP_UNROLL];
 #pragma unroll
 		for (int u = 0; u < DSB_DP_UNROLL; u++) {
 			int32_t pi = hi - u * DSB_WAVE - w.lane;
@@ -1637,6 +1641,7 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 			else { A[u] = ps.q_pos + ps.len + 8; B[u] = ps.t_pos + ps.len + 8; C[u] = ps.t_pos + 600; }
 			D[u] = ps.q_pos - ps.t_pos; S[u] = ps.score;
 			if (pi < 0 && MODE != 2) A[u] = 0x7fffffffu;        // fails the first test (signed distance past the node start)
+			wrapped[u] = dsb_ballot64((int)(A[u] | B[u] | C[u]) < 0) != 0;
 		}
 		if (hi - DSB_DP_UNROLL * DSB_WAVE >= 0) { DSB_FETCH_PREDS(nx, hi - DSB_DP_UNROLL * DSB_WAVE) }
 #pragma unroll
@@ -1648,14 +1653,24 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 				if ((stopm >> j) & 1u) break;
 				// sdp_judge with the common subexpressions folded: the limits are the node position + 6, so with
 				// oq/ot = how far the predecessor's end runs past the node's start, skip <=> max(oq, ot) > 6 and the
-				// overlap penalty is max(oq, ot, 0)
+				// overlap penalty is max(oq, ot, 0).  The reference compares these coordinates as unsigned numbers,
+				// and a chain can start at q = -1 (wrapped): a chunk holding such a value takes the literal form.
 				const int oq = (MODE == 2) ? (int)(nq[j] - A[u]) : (int)(A[u] - nq[j]);
 				const int ot = (MODE == 2) ? (int)(nt[j] - B[u]) : (int)(B[u] - nt[j]);
-				int ovl = MAXV(oq, ot); ovl = MAXV(ovl, 0);
-				const bool skip = ovl > 6;
-				const bool brk = !skip & ((MODE == 2) ? (lt[j] + 600 < C[u]) : (C[u] < lt[j]));
 				const int indel = (int)(D[u] - dl[j]); const int ai = ABSV(indel);
-				const int ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3)) - ovl;
+				bool skip, brk; int ns;
+				if (wrapped[u]) {
+					bool ov;
+					if (MODE == 2) { skip = (A[u] < lq[j]) | (B[u] < lt[j]); brk = !skip & (lt[j] + 600 < C[u]); ov = (nq[j] > A[u]) | (nt[j] > B[u]); }
+					else { skip = (A[u] > lq[j]) | (B[u] > lt[j]); brk = !skip & (C[u] < lt[j]); ov = (A[u] > nq[j]) | (B[u] > nt[j]); }
+					ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3));
+					if (ov) ns -= MAXV(oq, ot);
+				} else {
+					int ovl = MAXV(oq, ot); ovl = MAXV(ovl, 0);
+					skip = ovl > 6;
+					brk = !skip & ((MODE == 2) ? (lt[j] + 600 < C[u]) : (C[u] < lt[j]));
+					ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3)) - ovl;
+				}
 				bool ok = !skip & !brk & (ai <= 200);
 				uint64_t bm = dsb_ballot64(brk);
 				if (bm) {	// the reference stops at the newest predecessor that meets the distance cut

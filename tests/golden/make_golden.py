@@ -35,6 +35,12 @@ def main():
     if os.path.exists(heavy):
         run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx, heavy, "-o", os.path.join(OUT, "heavy.ubfree.sam")])
         run([os.path.join(REF, "deSAMBA"), "classify", "-t", "1", idx, heavy, "-o", os.path.join(OUT, "heavy.stock.sam")])
+    # read 2464 of the same generator (seed 1): its best chain starts at q = -1 (wrapped, unsigned), which the left
+    # extension's predecessor tests compare as an unsigned number
+    wrapq = os.path.join(OUT, "wrapq.fq")
+    if os.path.exists(wrapq):
+        run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx, wrapq, "-o", os.path.join(OUT, "wrapq.ubfree.sam")])
+        run([os.path.join(REF, "deSAMBA"), "classify", "-t", "1", idx, wrapq, "-o", os.path.join(OUT, "wrapq.stock.sam")])
     # the smallest reproducer of the stock reference's history dependence
     appc = os.path.join(OUT, "appc.fq")
     with open(appc, "w") as f:

@@ -36,7 +36,7 @@ def test_demo_reads(emu, oracle, demo):
     _cmp(emu, oracle, D.read_fastq(demo["fastq"], 400), check_stages=True)
 
 
-@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy"])
+@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq"])
 def test_synthetic(emu, oracle, name):
     import desamba_amd as D
     _cmp(emu, oracle, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")), check_stages=(name in ("ngs150", "appc")))
@@ -46,3 +46,14 @@ def test_edge_cases(emu, oracle):
     recs = [(b"short", b"ACGT" * 9, None), (b"min", b"ACGTTGCA" * 5, None), (b"polyA", b"A" * 300, None),
             (b"allN", b"N" * 200, None), (b"lower", b"acgtnnacgt" * 30, None), (b"l39", b"A" * 39, None), (b"empty", b"", None)]
     _cmp(emu, oracle, recs, check_stages=True)
+
+
+def test_random_long_reads(emu, oracle, demo, tmp_path):
+    """600 fresh 50 kbp ONT reads: wide enough to meet the rare paths (chains starting at q = -1, lane-scratch
+    overflow of the island walk, repeats) that the small golden sets do not reach"""
+    import subprocess
+    from conftest import ROOT
+    import desamba_amd as D
+    fq = tmp_path / "ont50k.fq"
+    subprocess.check_call([os.path.join(ROOT, "tools", "readsim"), demo["index"], str(fq), "600", "50000", "0.15", "1", "ont"])
+    _cmp(emu, oracle, D.read_fastq(str(fq)))

@@ -43,14 +43,14 @@ def test_demo_sam_md5(gpu, demo, golden_md5):
     assert hashlib.md5(sam).hexdigest() == golden_md5
 
 
-@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy"])
+@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq"])
 def test_synthetic_golden_sam(gpu, name):
     D, idx, ctx = gpu
     hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))
     assert sam == open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read()
 
 
-@pytest.mark.parametrize("name", ["heavy", "ont5k_e25"])
+@pytest.mark.parametrize("name", ["heavy", "ont5k_e25", "wrapq"])
 def test_heavy_first_launch(gpu, name, monkeypatch):
     """the early launch of the heaviest reads (second stream, own slots) must not change any result"""
     D, idx, ctx = gpu
@@ -79,7 +79,7 @@ def test_long_reads_vs_oracle(gpu, demo, oracle, tmp_path):
     import subprocess
     D, idx, ctx = gpu
     fq = tmp_path / "ont50k.fq"
-    subprocess.check_call([os.path.join(ROOT, "tools", "readsim"), demo["index"], str(fq), "96", "50000", "0.15", "4242", "ont"])
+    subprocess.check_call([os.path.join(ROOT, "tools", "readsim"), demo["index"], str(fq), "1536", "50000", "0.15", "4242", "ont"])
     recs = D.read_fastq(str(fq))
     hits, _ = classify_all(D, ctx, recs)
     hist = 0
