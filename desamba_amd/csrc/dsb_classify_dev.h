@@ -1606,7 +1606,7 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 	// per node of the batch (group-uniform, kept in scalar registers): limits and the terms of sdp_judge that do
 	// not depend on the predecessor
 	uint32_t lq[DSB_DPB], lt[DSB_DPB], dl[DSB_DPB], nq[DSB_DPB], nt[DSB_DPB], nl[DSB_DPB]; int best[DSB_DPB];
-	uint32_t stopm = 0, preds = 0;
+	uint32_t stopm = 0, preds = 0, wnm = 0;
 #pragma unroll
 	for (int j = 0; j < DSB_DPB; j++) {
 		uint32_t q_, t_; sdp_limits<MODE>(b.nd[j], q_, t_);
@@ -1615,8 +1615,9 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 		if (MODE == 2) { nq[j] = lq[j] + 6; nt[j] = lt[j] + 6; } else { nq[j] = DSB_RFL(b.nd[j].q_pos); nt[j] = DSB_RFL(b.nd[j].t_pos); }
 		best[j] = -2147483647 - 1;
 		if ((uint32_t)j >= b.K) stopm |= 1u << j;
+		if ((int)(lq[j] | lt[j] | nq[j] | nt[j] | (lt[j] + 600)) < 0) wnm |= 1u << j;     // wrapped (negative) node coordinates
 	}
-	stopm = DSB_RFL(stopm);
+	stopm = DSB_RFL(stopm); wnm = DSB_RFL(wnm);
 	const int32_t n0 = (int32_t)b.n0;
 	// predecessors are fetched one iteration ahead (4 x 64 nodes in flight while the previous 4 x 64 are judged)
 	DsbSms nx[DSB_DP_UNROLL];
@@ -1659,7 +1660,7 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 				const int ot = (MODE == 2) ? (int)(nt[j] - B[u]) : (int)(B[u] - nt[j]);
 				const int indel = (int)(D[u] - dl[j]); const int ai = ABSV(indel);
 				bool skip, brk; int ns;
-				if (wrapped[u]) {
+				if (wrapped[u] || ((wnm >> j) & 1u)) {
 					bool ov;
 					if (MODE == 2) { skip = (A[u] < lq[j]) | (B[u] < lt[j]); brk = !skip & (lt[j] + 600 < C[u]); ov = (nq[j] > A[u]) | (nt[j] > B[u]); }
 					else { skip = (A[u] > lq[j]) | (B[u] > lt[j]); brk = !skip & (C[u] < lt[j]); ov = (A[u] > nq[j]) | (B[u] > nt[j]); }

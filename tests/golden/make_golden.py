@@ -36,7 +36,8 @@ def main():
         run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx, heavy, "-o", os.path.join(OUT, "heavy.ubfree.sam")])
         run([os.path.join(REF, "deSAMBA"), "classify", "-t", "1", idx, heavy, "-o", os.path.join(OUT, "heavy.stock.sam")])
     # read 2464 of the same generator (seed 1): its best chain starts at q = -1 (wrapped, unsigned), which the left
-    # extension's predecessor tests compare as an unsigned number
+    # extension's predecessor tests compare as an unsigned number; and an NGS read hanging over the start of the
+    # first reference, whose left extension works on negative (wrapped) reference coordinates
     wrapq = os.path.join(OUT, "wrapq.fq")
     if os.path.exists(wrapq):
         run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx, wrapq, "-o", os.path.join(OUT, "wrapq.ubfree.sam")])
