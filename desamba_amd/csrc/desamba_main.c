@@ -2,9 +2,15 @@
  * Mirrors classify_main / classify_usage (src/cly_mt.c:448-562): same options, same output,
  * same stderr progress lines; print-and-exit error convention lives only here.
  * Extra option: -g INT  GPU (device id) to run on [0].
- * Reads are streamed from plain or gzip FASTQ/FASTA through zlib like the reference
- * (src/cly_mt.c:553; record rules of kseq_read, src/lib/utils.c:939-977) and classified in
- * batches of <= 4096 reads / 256 Mbp, written in input order.
+ *
+ * The reference's pipeline (kt_pipeline, src/cly_mt.c:393-410: read -> classify -> write, one batch
+ * per step) is kept as three kinds of threads around two device contexts:
+ *   reader   fills pinned buffers with raw (plain or gzip) FASTQ/FASTA text and finds the records in
+ *            place (record rules of kseq_read, src/lib/utils.c:939-977): no per-read copies; the buffer
+ *            goes to the device as it is (dsb_batch_upload_text)
+ *   2 x GPU  one dsb_ctx each on the same device, so that the upload of one batch overlaps the kernels
+ *            of the other; max_read_l (src/cly.c:2958) travels with the batch as a prefix maximum
+ *   writer   formats SAM in input order
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -12,49 +18,276 @@
 #include <string.h>
 #include <ctype.h>
 #include <getopt.h>
+#include <pthread.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/stat.h>
 #include <sys/time.h>
 #include <sys/resource.h>
 #include <zlib.h>
 #include "desamba_amd.h"
 
-#define BATCH_READS 4096
-#define BATCH_BASES 256000000UL
+#define N_BATCH 4                     /* batch buffers in flight */
+#define N_GPU_CTX 2
+#define MAX_BATCH_READS (1u << 21)
 
-typedef struct { char *s; size_t l, m; } str_t;
-static void str_putc(str_t *s, int c) { if (s->l + 2 > s->m) { s->m = s->m ? s->m * 2 : 256; s->s = realloc(s->s, s->m); } s->s[s->l++] = (char)c; s->s[s->l] = 0; }
+static void die(const char *msg) { fprintf(stderr, "%s\n", msg); exit(1); }
 
-typedef struct { gzFile f; unsigned char buf[1 << 16]; int n, p, eof; int last; } stream_t;
-static int sgetc(stream_t *s)
+/* ---------------------------------------------------------------- batches and queues */
+typedef struct {
+	char *text; size_t cap, len;                      /* pinned; the records of this batch lie in text[0, len) */
+	size_t n, cap_n;
+	uint64_t *seq_off, *name_off, *qual_off; uint32_t *seq_len; unsigned char *has_qual;
+	uint32_t hist_before;                             /* longest read of this file before this batch */
+	long seqno;
+	dsb_read_result *rr; dsb_hit *hits; size_t cap_rr, cap_hits, n_hits;
+} batch_t;
+
+typedef struct { batch_t *slot[N_BATCH + 2]; int head, n, closed; pthread_mutex_t mu; pthread_cond_t cv; } queue_t;
+static void q_init(queue_t *q) { memset(q, 0, sizeof *q); pthread_mutex_init(&q->mu, NULL); pthread_cond_init(&q->cv, NULL); }
+static void q_push(queue_t *q, batch_t *b)
 {
-	if (s->p >= s->n) { if (s->eof) return -1; s->n = gzread(s->f, s->buf, sizeof s->buf); s->p = 0; if (s->n <= 0) { s->eof = 1; return -1; } }
-	return s->buf[s->p++];
+	pthread_mutex_lock(&q->mu);
+	q->slot[(q->head + q->n) % (N_BATCH + 2)] = b; q->n++;
+	pthread_cond_broadcast(&q->cv); pthread_mutex_unlock(&q->mu);
 }
-typedef struct { str_t name, seq, qual; } rec_t;
+static void q_close(queue_t *q) { pthread_mutex_lock(&q->mu); q->closed = 1; pthread_cond_broadcast(&q->cv); pthread_mutex_unlock(&q->mu); }
+static batch_t *q_pop(queue_t *q)
+{	/* NULL once the queue is closed and empty */
+	pthread_mutex_lock(&q->mu);
+	while (q->n == 0 && !q->closed) pthread_cond_wait(&q->cv, &q->mu);
+	batch_t *b = NULL;
+	if (q->n) { b = q->slot[q->head]; q->head = (q->head + 1) % (N_BATCH + 2); q->n--; }
+	pthread_mutex_unlock(&q->mu);
+	return b;
+}
 
-/* kseq_read: returns seq length, -1 at EOF */
-static long read_record(stream_t *s, rec_t *r)
+static void batch_reserve(batch_t *b, size_t n)
 {
-	int c;
-	if (s->last == 0) { while ((c = sgetc(s)) != -1 && c != '>' && c != '@'); if (c == -1) return -1; s->last = c; }
-	r->name.l = r->seq.l = r->qual.l = 0;
-	if (r->name.s) r->name.s[0] = 0;
-	while ((c = sgetc(s)) != -1 && !isspace(c)) str_putc(&r->name, c);
-	if (c == -1 && r->name.l == 0) return -1;
-	if (c != '\n') while ((c = sgetc(s)) != -1 && c != '\n');
-	while ((c = sgetc(s)) != -1 && c != '>' && c != '+' && c != '@') {
-		if (c == '\n') continue;
-		str_putc(&r->seq, c);
-		while ((c = sgetc(s)) != -1 && c != '\n') if (c != '\r') str_putc(&r->seq, c);
+	if (n <= b->cap_n) return;
+	size_t m = b->cap_n ? b->cap_n * 2 : 4096; while (m < n) m *= 2;
+	b->seq_off = realloc(b->seq_off, m * 8); b->name_off = realloc(b->name_off, m * 8); b->qual_off = realloc(b->qual_off, m * 8);
+	b->seq_len = realloc(b->seq_len, m * 4); b->has_qual = realloc(b->has_qual, m);
+	if (!b->seq_off || !b->name_off || !b->qual_off || !b->seq_len || !b->has_qual) die("[classify] out of memory");
+	b->cap_n = m;
+}
+
+/* ---------------------------------------------------------------- record parser (kseq_read rules) on a buffer */
+/* One record starting at *ppos.  `last` is kseq's look-ahead: the header character ('>' / '@') already consumed by the
+ * previous record, or 0.  modify = 0 only measures (nothing is written, so an incomplete record can be re-read later with
+ * more data); modify = 1 joins multi-line sequence / quality in place and drops '\r'.
+ * returns 1 record found, 0 more data needed, -1 end of input, -2 truncated quality */
+typedef struct { size_t name_off, name_end, seq_off, seq_len, qual_off; int has_qual, plain; size_t next; int next_last; } rec_t;
+static size_t copy_line(char *t, size_t w, size_t p, size_t len, int modify, int *plain)
+{	/* append t[p, p+len) minus '\r' at t[w]; returns the number of characters appended */
+	if (!memchr(t + p, '\r', len)) { if (modify && w != p) memmove(t + w, t + p, len); return len; }
+	*plain = 0;
+	size_t k = 0;
+	for (size_t i = 0; i < len; i++) if (t[p + i] != '\r') { if (modify) t[w + k] = t[p + i]; k++; }
+	return k;
+}
+static int scan_record(char *t, size_t pos, size_t end, int eof, int last, int modify, rec_t *r)
+{
+	size_t p = pos; int c;
+	r->next = pos; r->next_last = last;
+	if (last == 0) {
+		while (p < end && t[p] != '>' && t[p] != '@') p++;
+		if (p >= end) { r->next = end; r->next_last = 0; return eof ? -1 : 0; }
+		p++;
 	}
-	if (c == '>' || c == '@') s->last = c;
-	if (!r->seq.s) str_putc(&r->seq, 0), r->seq.l = 0;
-	if (c != '+') { if (c == -1) s->last = 0; return (long)r->seq.l; }
-	while ((c = sgetc(s)) != -1 && c != '\n');
-	if (c == -1) return -2;
-	while (r->qual.l < r->seq.l && (c = sgetc(s)) != -1) if (c != '\n' && c != '\r') str_putc(&r->qual, c);
-	s->last = 0;
-	if (r->seq.l != r->qual.l) return -2;
-	return (long)r->seq.l;
+	r->plain = 1;
+	r->name_off = p;
+	while (p < end && !isspace((unsigned char)t[p])) p++;
+	if (p >= end) { if (!eof) return 0; if (p == r->name_off) return -1; }
+	r->name_end = p;
+	c = p < end ? (unsigned char)t[p] : -1;
+	if (c != -1 && c != '\n') { char *e = memchr(t + p, '\n', end - p); if (!e) { if (!eof) return 0; p = end; c = -1; } else p = (size_t)(e - t); }
+	if (c != -1) p++;                                                     /* past the newline of the header line */
+	r->seq_off = p; r->seq_len = 0; size_t w = p; int first = 1;
+	for (;;) {
+		if (p >= end) { if (!eof) return 0; c = -1; break; }
+		c = (unsigned char)t[p];
+		if (c == '>' || c == '+' || c == '@') { p++; break; }
+		if (c == '\n') { p++; continue; }
+		char *e = memchr(t + p, '\n', end - p);
+		if (!e && !eof) return 0;
+		size_t le = e ? (size_t)(e - t) : end, len = le - p;
+		if (first) { r->seq_off = p; w = p; first = 0; } else r->plain = 0;
+		size_t k = copy_line(t, w, p, len, modify, &r->plain);
+		w += k; r->seq_len += k;
+		p = e ? le + 1 : end;
+	}
+	r->has_qual = 0; r->qual_off = 0; r->next_last = 0;
+	if (c == '>' || c == '@') r->next_last = c;
+	if (c == '+') {
+		char *e = memchr(t + p, '\n', end - p);
+		if (!e) return eof ? -2 : 0;
+		p = (size_t)(e - t) + 1;
+		size_t ql = 0, qw = p; int qfirst = 1; r->qual_off = p;
+		while (ql < r->seq_len) {
+			if (p >= end) { if (!eof) return 0; break; }
+			if (t[p] == '\n' || t[p] == '\r') { p++; continue; }
+			e = memchr(t + p, '\n', end - p);
+			if (!e && !eof) return 0;
+			size_t le = e ? (size_t)(e - t) : end, len = le - p, want = r->seq_len - ql;
+			if (len > want) {	/* kseq stops in the middle of the line; '\r' inside does not count */
+				size_t i = 0, k = 0;
+				if (qfirst) { r->qual_off = p; qw = p; qfirst = 0; } else r->plain = 0;
+				for (; i < len && k < want; i++) if (t[p + i] != '\r') { if (modify) t[qw + k] = t[p + i]; k++; } else r->plain = 0;
+				qw += k; ql += k; p += i;
+				break;
+			}
+			if (qfirst) { r->qual_off = p; qw = p; qfirst = 0; } else r->plain = 0;
+			size_t k = copy_line(t, qw, p, len, modify, &r->plain);
+			qw += k; ql += k;
+			p = e ? le + 1 : end;
+		}
+		if (ql != r->seq_len) return -2;
+		r->has_qual = 1; r->next_last = 0;
+	}
+	r->next = p;
+	return 1;
+}
+
+/* ---------------------------------------------------------------- shared state */
+typedef struct {
+	int argc; char **argv; int first_file;
+	dsb_index *idx; dsb_ctx *ctx[N_GPU_CTX]; dsb_opts o; int full; FILE *out;
+	queue_t free_q, parsed_q, done_q;
+	size_t batch_cap; unsigned long total;
+	int pageable;                                     /* batch buffers from malloc instead of pinned memory (parser tests without a GPU) */
+} app_t;
+
+typedef struct { int fd; gzFile gz; } src_t;
+static int src_open(src_t *s, const char *path)
+{
+	unsigned char m[2] = {0, 0};
+	s->gz = NULL; s->fd = open(path, O_RDONLY);
+	if (s->fd < 0) return -1;
+	ssize_t k = pread(s->fd, m, 2, 0);
+	if (k == 2 && m[0] == 0x1f && m[1] == 0x8b) {          /* gzip: through zlib like the reference (src/cly_mt.c:553) */
+		s->gz = gzdopen(s->fd, "r");
+		if (!s->gz) { close(s->fd); return -1; }
+		gzbuffer(s->gz, 1 << 20);
+	}
+	return 0;
+}
+static size_t src_read(src_t *s, char *buf, size_t want)
+{
+	size_t got = 0;
+	while (got < want) {
+		size_t ask = want - got > (1u << 30) ? (1u << 30) : want - got;
+		long k = s->gz ? (long)gzread(s->gz, buf + got, (unsigned)ask) : (long)read(s->fd, buf + got, ask);
+		if (k <= 0) break;
+		got += (size_t)k;
+	}
+	return got;
+}
+static void src_close(src_t *s) { if (s->gz) gzclose(s->gz); else close(s->fd); }
+
+static void *reader_main(void *arg)
+{
+	app_t *a = arg; long seqno = 0;
+	char *carry = NULL; size_t carry_cap = 0;
+	for (int fi = a->first_file; fi < a->argc; fi++) {
+		src_t src;
+		if (src_open(&src, a->argv[fi]) != 0) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", a->argv[fi]); exit(1); }
+		fprintf(stderr, "Processing file: [%s].\n", a->argv[fi]);
+		uint32_t hist = 0; int last = 0, eof = 0; size_t carry_len = 0;
+		while (!eof || carry_len) {
+			batch_t *b = q_pop(&a->free_q);
+			if (!b->text) { b->text = a->pageable ? malloc(a->batch_cap + 64) : dsb_host_alloc(a->batch_cap + 64); b->cap = a->batch_cap; if (!b->text) die("[classify] cannot allocate a pinned batch buffer"); }
+			if (carry_len > b->cap) die("[classify] one record is larger than the batch buffer (raise DSB_CLI_BATCH_MB)");
+			memcpy(b->text, carry, carry_len);
+			size_t got = eof ? 0 : src_read(&src, b->text + carry_len, b->cap - carry_len);
+			size_t end = carry_len + got;
+			if (!eof && end < b->cap) eof = 1;
+			b->n = 0; b->hist_before = hist; b->seqno = seqno++;
+			size_t pos = 0; rec_t r;
+			for (;;) {
+				int rc = scan_record(b->text, pos, end, eof, last, 0, &r);
+				if (rc == 1 && !r.plain) rc = scan_record(b->text, pos, end, eof, last, 1, &r);
+				if (rc == -2) { fprintf(stderr, "[read_reads] truncated quality string in '%s'\n", a->argv[fi]); exit(1); }
+				if (rc != 1) { pos = rc == -1 ? end : r.next; break; }       /* -1: nothing but junk is left; 0: r.next skips junk, if any */
+				if (r.seq_len > 0xffffffffUL) die("[classify] a read longer than 4 Gbp");
+				batch_reserve(b, b->n + 1);
+				b->name_off[b->n] = r.name_off; b->seq_off[b->n] = r.seq_off; b->seq_len[b->n] = (uint32_t)r.seq_len;
+				b->qual_off[b->n] = r.qual_off; b->has_qual[b->n] = (unsigned char)r.has_qual;
+				b->text[r.name_end] = 0;                                   /* the name becomes a C string in place */
+				if (r.seq_len > hist) hist = (uint32_t)r.seq_len;
+				b->n++; pos = r.next; last = r.next_last;
+				if (b->n >= MAX_BATCH_READS) break;
+			}
+			/* what is left is the beginning of a record that continues in the next buffer */
+			carry_len = end - pos;
+			if (eof && b->n == 0) carry_len = 0;                           /* trailing junk without a record */
+			if (carry_len) {
+				if (carry_len >= b->cap && b->n == 0) die("[classify] one record is larger than the batch buffer (raise DSB_CLI_BATCH_MB)");
+				if (carry_len > carry_cap) { carry_cap = carry_len * 2; carry = realloc(carry, carry_cap); if (!carry) die("[classify] out of memory"); }
+				memcpy(carry, b->text + pos, carry_len);
+			}
+			b->len = pos;
+			q_push(&a->parsed_q, b);                                       /* empty batches keep the sequence numbers dense */
+		}
+		src_close(&src);
+	}
+	free(carry);
+	q_close(&a->parsed_q);
+	return NULL;
+}
+
+typedef struct { app_t *a; int k; } gpu_arg_t;
+static void *gpu_main(void *arg)
+{
+	gpu_arg_t *g = arg; app_t *a = g->a; dsb_ctx *ctx = a->ctx[g->k];
+	batch_t *b;
+	while ((b = q_pop(&a->parsed_q)) != NULL) {
+		b->n_hits = 0;
+		if (b->n) {
+			dsb_result res; int rc;
+			dsb_ctx_set_history(ctx, b->hist_before);
+			rc = dsb_batch_upload_text(ctx, b->text, b->len, b->seq_off, b->seq_len, b->n);
+			if (!rc) rc = dsb_batch_run(ctx);
+			if (!rc || rc == DSB_ECAP) rc = dsb_batch_fetch(ctx, &res);
+			if (rc && rc != DSB_ECAP) { fprintf(stderr, "[dsb_classify_batch] %s\n", dsb_strerror(rc)); exit(1); }
+			if (b->n > b->cap_rr) { b->cap_rr = b->n * 2; b->rr = realloc(b->rr, b->cap_rr * sizeof *b->rr); }
+			if (res.n_hits > b->cap_hits) { b->cap_hits = res.n_hits * 2; b->hits = realloc(b->hits, b->cap_hits * sizeof *b->hits); }
+			if (!b->rr || (res.n_hits && !b->hits)) die("[classify] out of memory");
+			memcpy(b->rr, res.reads, b->n * sizeof *b->rr);
+			if (res.n_hits) memcpy(b->hits, res.hits, res.n_hits * sizeof *b->hits);
+			b->n_hits = res.n_hits;
+		}
+		q_push(&a->done_q, b);
+	}
+	return NULL;
+}
+
+static void *writer_main(void *arg)
+{
+	app_t *a = arg; long next = 0; batch_t *held[N_BATCH + 2]; int n_held = 0;
+	size_t cap = 1 << 20; char *line = malloc(cap);
+	batch_t *b;
+	for (;;) {
+		b = NULL;
+		for (int i = 0; i < n_held; i++) if (held[i]->seqno == next) { b = held[i]; held[i] = held[--n_held]; break; }
+		if (!b) { b = q_pop(&a->done_q); if (!b) break; if (b->seqno != next) { held[n_held++] = b; continue; } }
+		for (size_t i = 0; i < b->n; i++) {
+			const dsb_read_result *rr = &b->rr[i];
+			dsb_read rd; rd.name = b->text + b->name_off[i]; rd.seq = b->text + b->seq_off[i]; rd.len = b->seq_len[i];
+			rd.qual = b->has_qual[i] ? b->text + b->qual_off[i] : "";
+			if (rr->status) { fprintf(stderr, "[classify] read %s: device arena overflow (status %d)\n", rd.name, rr->status); exit(1); }
+			size_t need = 4096 + 800 * (size_t)rr->n + (a->full ? 2 * (size_t)rd.len : 0) + strlen(rd.name);
+			if (need > cap) { cap = need * 2; line = realloc(line, cap); if (!line) die("[classify] out of memory"); }
+			long w = dsb_format_sam(a->idx, &rd, b->hits + rr->first, rr->n, a->o.max_sec_N, a->full, line, cap);
+			if (w < 0) die("[dsb_format_sam] buffer too small");
+			fwrite(line, 1, (size_t)w, a->out);
+		}
+		a->total += b->n;
+		next++;
+		q_push(&a->free_q, b);
+	}
+	free(line);
+	return NULL;
 }
 
 static void usage(void)
@@ -77,67 +310,70 @@ static double cputime(void) { struct rusage r; getrusage(RUSAGE_SELF, &r); retur
 
 static int classify_main(int argc, char **argv)
 {
-	dsb_opts o = {170, 64, 5, 0}; int full = 0, dev = 0, c; FILE *out = stdout;
+	static app_t a; int dev = 0, c;
+	a.o.L_min_matching = 170; a.o.min_score = 64; a.o.max_sec_N = 5; a.o.n_slots = 0; a.out = stdout;
 	while ((c = getopt(argc, argv, "ht:l:r:f:o:s:g:")) >= 0) {
 		if (c == 'h') { usage(); return 0; }
 		else if (c == 't') { /* thread count: accepted for compatibility, unused */ }
-		else if (c == 'l') o.L_min_matching = atoi(optarg);
-		else if (c == 'r') o.max_sec_N = atoi(optarg);
-		else if (c == 'o') { out = fopen(optarg, "w"); if (!out) { fprintf(stderr, "[xopen] fail to open file '%s'\n", optarg); exit(1); } }
-		else if (c == 's') o.min_score = atoi(optarg);
+		else if (c == 'l') a.o.L_min_matching = atoi(optarg);
+		else if (c == 'r') a.o.max_sec_N = atoi(optarg);
+		else if (c == 'o') { a.out = fopen(optarg, "w"); if (!a.out) { fprintf(stderr, "[xopen] fail to open file '%s'\n", optarg); exit(1); } }
+		else if (c == 's') a.o.min_score = atoi(optarg);
 		else if (c == 'g') dev = atoi(optarg);
 		else if (c == 'f') {
-			if (!strcmp(optarg, "SAM")) full = 0; else if (!strcmp(optarg, "SAM_FULL")) full = 1;
+			if (!strcmp(optarg, "SAM")) a.full = 0; else if (!strcmp(optarg, "SAM_FULL")) a.full = 1;
 			else { fprintf(stderr, "output format %s is not available in the GPU build (SAM, SAM_FULL)\n", optarg); return 1; }
 		}
 	}
 	if (optind + 2 > argc) { usage(); return 0; }
 	const char *index_dir = argv[optind++];
-	fprintf(stderr, "loading index\t");
-	dsb_index *idx; int rc = dsb_index_open(index_dir, &idx);
-	if (rc) { fprintf(stderr, "\n[load_idx] %s\n", dsb_strerror(rc)); exit(1); }
-	dsb_ctx *ctx; rc = dsb_ctx_create(idx, dev, &o, &ctx);
-	if (rc) { fprintf(stderr, "\n[dsb_ctx_create] %s\n", dsb_strerror(rc)); exit(1); }
-	double t0 = now(), cpu0 = cputime(); unsigned long total = 0;
-	fprintf(stderr, "Start classify\n");
-	rec_t *recs = calloc(BATCH_READS, sizeof(rec_t)); dsb_read *reads = calloc(BATCH_READS, sizeof(dsb_read));
-	size_t cap = 1 << 20; char *line = malloc(cap);
-	for (; optind < argc; optind++) {
-		stream_t *s = calloc(1, sizeof *s);
-		s->f = gzopen(argv[optind], "r");
-		if (!s->f) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", argv[optind]); exit(1); }
-		fprintf(stderr, "Processing file: [%s].\n", argv[optind]);
-		dsb_ctx_reset_history(ctx);
-		for (;;) {
-			size_t n = 0; unsigned long bases = 0; long l = 0;
-			while (n < BATCH_READS && bases < BATCH_BASES && (l = read_record(s, &recs[n])) >= 0) {
-				reads[n].name = recs[n].name.s ? recs[n].name.s : ""; reads[n].seq = recs[n].seq.s; reads[n].qual = recs[n].qual.l ? recs[n].qual.s : "";
-				reads[n].len = (uint32_t)recs[n].seq.l; bases += recs[n].seq.l; n++;
-			}
-			if (n == 0) break;
-			total += n;
-			dsb_result res; rc = dsb_classify_batch(ctx, reads, n, &res);
-			if (rc && rc != DSB_ECAP) { fprintf(stderr, "[dsb_classify_batch] %s\n", dsb_strerror(rc)); exit(1); }
-			for (size_t i = 0; i < n; i++) {
-				if (res.reads[i].status) { fprintf(stderr, "[classify] read %s: device arena overflow (status %d)\n", reads[i].name, res.reads[i].status); exit(1); }
-				size_t need = 4096 + 800 * (size_t)res.reads[i].n + (full ? 2 * (size_t)reads[i].len : 0) + strlen(reads[i].name);
-				if (need > cap) { cap = need * 2; line = realloc(line, cap); }
-				long w = dsb_format_sam(idx, &reads[i], res.hits + res.reads[i].first, res.reads[i].n, o.max_sec_N, full, line, cap);
-				if (w < 0) { fprintf(stderr, "[dsb_format_sam] buffer too small\n"); exit(1); }
-				fwrite(line, 1, (size_t)w, out);
-			}
-			if (l < 0) break;
-		}
-		gzclose(s->f); free(s);
+	a.argc = argc; a.argv = argv; a.first_file = optind;
+	/* batch buffer: DSB_CLI_BATCH_MB of raw text (default 1536), but not more than the input needs */
+	size_t want = 0;
+	for (int i = optind; i < argc; i++) {
+		struct stat st; unsigned char m[2] = {0, 0}; int fd = open(argv[i], O_RDONLY);
+		if (fd < 0) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", argv[i]); exit(1); }
+		int gz = pread(fd, m, 2, 0) == 2 && m[0] == 0x1f && m[1] == 0x8b;
+		if (fstat(fd, &st) == 0 && (size_t)st.st_size * (gz ? 8 : 1) > want) want = (size_t)st.st_size * (gz ? 8 : 1);
+		close(fd);
 	}
+	const char *mb = getenv("DSB_CLI_BATCH_MB");
+	a.batch_cap = (size_t)(mb ? atol(mb) : 1536) << 20;
+	if (want + (1 << 20) < a.batch_cap) a.batch_cap = want + (1 << 20);
+	if (a.batch_cap < (1 << 16)) a.batch_cap = 1 << 16;
+	setvbuf(a.out, NULL, _IOFBF, 8 << 20);
+
+	fprintf(stderr, "loading index\t");
+	int rc = dsb_index_open(index_dir, &a.idx);
+	if (rc) { fprintf(stderr, "\n[load_idx] %s\n", dsb_strerror(rc)); exit(1); }
+	for (int k = 0; k < N_GPU_CTX; k++) {
+		rc = dsb_ctx_create(a.idx, dev, &a.o, &a.ctx[k]);
+		if (rc) { fprintf(stderr, "\n[dsb_ctx_create] %s\n", dsb_strerror(rc)); exit(1); }
+	}
+	double t0 = now(), cpu0 = cputime();
+	fprintf(stderr, "Start classify\n");
+	q_init(&a.free_q); q_init(&a.parsed_q); q_init(&a.done_q);
+	static batch_t batches[N_BATCH];
+	for (int i = 0; i < N_BATCH; i++) q_push(&a.free_q, &batches[i]);
+	pthread_t th_r, th_w, th_g[N_GPU_CTX]; gpu_arg_t ga[N_GPU_CTX];
+	pthread_create(&th_r, NULL, reader_main, &a);
+	for (int k = 0; k < N_GPU_CTX; k++) { ga[k].a = &a; ga[k].k = k; pthread_create(&th_g[k], NULL, gpu_main, &ga[k]); }
+	pthread_create(&th_w, NULL, writer_main, &a);
+	pthread_join(th_r, NULL);
+	for (int k = 0; k < N_GPU_CTX; k++) pthread_join(th_g[k], NULL);
+	q_close(&a.done_q);
+	pthread_join(th_w, NULL);
 	double sec = now() - t0;
-	fprintf(stderr, "%ld sequences processed in %.3fs (%.1f Kseq/m).\n", total, sec, total / 1.0e3 / (sec / 60));
+	fprintf(stderr, "%ld sequences processed in %.3fs (%.1f Kseq/m).\n", a.total, sec, a.total / 1.0e3 / (sec / 60));
 	fprintf(stderr, "Classify CPU: %.3f sec\n", cputime() - cpu0);
-	if (out != stdout) fclose(out);
-	dsb_ctx_destroy(ctx); dsb_index_close(idx);
+	if (a.out != stdout) fclose(a.out); else fflush(stdout);
+	for (int i = 0; i < N_BATCH; i++) dsb_host_free(batches[i].text);
+	for (int k = 0; k < N_GPU_CTX; k++) dsb_ctx_destroy(a.ctx[k]);
+	dsb_index_close(a.idx);
 	return 0;
 }
 
+#ifndef DSB_CLI_NO_MAIN
 int main(int argc, char **argv)
 {	/* dispatcher, src/main.c:35-53: only `classify` is in scope of this build */
 	if (argc < 2 || strcmp(argv[1], "classify") != 0) {
@@ -150,3 +386,4 @@ int main(int argc, char **argv)
 	fprintf(stderr, "Normal end program, MAX MEM:[%f]Gbp.\n\n", r.ru_maxrss / 1024.0 / 1024.0);
 	return rc;
 }
+#endif

@@ -452,6 +452,9 @@ extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 	delete c;
 }
 extern "C" void dsb_ctx_reset_history(dsb_ctx *c) { if (c) c->hist_max = 0; }
+extern "C" void dsb_ctx_set_history(dsb_ctx *c, uint32_t max_len_before) { if (c) c->hist_max = (int)max_len_before; }
+extern "C" void *dsb_host_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+extern "C" void dsb_host_free(void *p) { if (p) hipHostFree(p); }
 
 template <class T> static int grow(T **p, size_t *cap, size_t need)
 {
@@ -497,7 +500,9 @@ static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int n_s
 }
 
 struct SeqView { const char *p; uint32_t len; };
-static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n)
+// `ext_text` != nullptr: the sequences already lie in one host blob (read i at ext_text + reads[i].p's offset is given by
+// ext_off[i]); the blob is copied to the device as it is (no per-read gather) and the descriptors point into it
+static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *ext_text = nullptr, size_t ext_len = 0, const uint64_t *ext_off = nullptr)
 {
 	if (!c || (!reads && n)) return DSB_EINVAL;
 	HIPCHK(hipSetDevice(c->device));
@@ -506,7 +511,7 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n)
 	uint64_t seq_off = 0, bin_off = 0, pk_off = 0, bit_off = 0, windows = 0; uint32_t max_len = 64; int hist = c->hist_max;
 	for (size_t i = 0; i < n; i++) {
 		DsbReadDesc &d = c->h_rd[i];
-		d.len = reads[i].len; d.seq_off = seq_off; d.bin_off = bin_off; d.pk_off = pk_off; d.bit_off = bit_off;
+		d.len = reads[i].len; d.seq_off = ext_text ? ext_off[i] : seq_off; d.bin_off = bin_off; d.pk_off = pk_off; d.bit_off = bit_off;
 		d.n_win = d.len >= 40 ? d.len - k + 1 : 0; d.n_words = (d.n_win + 63) / 64;
 		d.hist_max = hist; if ((int)d.len > hist) hist = d.len;
 		seq_off += d.len; bin_off += al256(DSB_QPAD_L + 2 * (size_t)d.len + DSB_QPAD_R);
@@ -520,7 +525,7 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n)
 	int rc;
 	if ((rc = grow(&c->d_rd, &c->cap_rd, n + 1))) return rc;
 	if ((rc = grow(&c->d_wd, &c->cap_wd, c->h_wd.size() + 1))) return rc;
-	if ((rc = grow(&c->d_ascii, &c->cap_ascii, (size_t)seq_off + 64))) return rc;
+	if ((rc = grow(&c->d_ascii, &c->cap_ascii, (ext_text ? ext_len : (size_t)seq_off) + 64))) return rc;
 	if ((rc = grow(&c->d_bin, &c->cap_bin, (size_t)bin_off + 256))) return rc;
 	if ((rc = grow(&c->d_pk, &c->cap_pk, (size_t)pk_off + 8))) return rc;
 	if ((rc = grow(&c->d_bits, &c->cap_bits, (size_t)bit_off + 8))) return rc;
@@ -535,10 +540,13 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n)
 	if (n) {
 		HIPCHK(hipMemcpyAsync(c->d_rd, c->h_rd.data(), n * sizeof(DsbReadDesc), hipMemcpyHostToDevice, c->stream));
 		if (!c->h_wd.empty()) HIPCHK(hipMemcpyAsync(c->d_wd, c->h_wd.data(), c->h_wd.size() * sizeof(DsbWordDesc), hipMemcpyHostToDevice, c->stream));
-		// sequences: copied read by read out of the caller's buffers (caller owns read memory)
-		std::vector<char> stage((size_t)seq_off);
-		for (size_t i = 0; i < n; i++) memcpy(stage.data() + c->h_rd[i].seq_off, reads[i].p, reads[i].len);
-		HIPCHK(hipMemcpy(c->d_ascii, stage.data(), (size_t)seq_off, hipMemcpyHostToDevice));
+		if (ext_text) HIPCHK(hipMemcpy(c->d_ascii, ext_text, ext_len, hipMemcpyHostToDevice));
+		else {
+			// sequences: copied read by read out of the caller's buffers (caller owns read memory)
+			std::vector<char> stage((size_t)seq_off);
+			for (size_t i = 0; i < n; i++) memcpy(stage.data() + c->h_rd[i].seq_off, reads[i].p, reads[i].len);
+			HIPCHK(hipMemcpy(c->d_ascii, stage.data(), (size_t)seq_off, hipMemcpyHostToDevice));
+		}
 	}
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return DSB_OK;
@@ -550,6 +558,14 @@ extern "C" int dsb_batch_upload(dsb_ctx *c, const dsb_read *reads, size_t n)
 	std::vector<SeqView> v(n);
 	for (size_t i = 0; i < n; i++) { v[i].p = reads[i].seq; v[i].len = reads[i].len; }
 	return upload_views(c, v.data(), n);
+}
+
+extern "C" int dsb_batch_upload_text(dsb_ctx *c, const char *text, size_t text_len, const uint64_t *seq_off, const uint32_t *seq_len, size_t n)
+{
+	if (!c || ((!text || !seq_off || !seq_len) && n)) return DSB_EINVAL;
+	std::vector<SeqView> v(n);
+	for (size_t i = 0; i < n; i++) { if (seq_off[i] + seq_len[i] > text_len) return DSB_EINVAL; v[i].p = text + seq_off[i]; v[i].len = seq_len[i]; }
+	return upload_views(c, v.data(), n, text, text_len, seq_off);
 }
 
 // read_reads (src/cly_mt.c:42-56) for a plain-text FASTQ/FASTA file: parse up to max_reads records starting

@@ -97,12 +97,20 @@ int  dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opts, dsb_ctx
 void dsb_ctx_destroy(dsb_ctx *ctx);
 /* reset the running max_read_l (src/cly.c:2958) -- start of a new input file */
 void dsb_ctx_reset_history(dsb_ctx *ctx);
+/* set it explicitly: the longest read of this input file before the next batch (for callers that deal the batches of one
+ * file to several contexts and therefore carry the prefix maximum themselves) */
+void dsb_ctx_set_history(dsb_ctx *ctx, uint32_t max_len_before);
 
 /* the kt_for seam (src/cly_mt.c:389): classify n reads; results valid until the next call */
 int  dsb_classify_batch(dsb_ctx *ctx, const dsb_read *reads, size_t n, dsb_result *out);
 
 /* the same, split so that a benchmark can time the device part with inputs resident in HBM */
 int  dsb_batch_upload(dsb_ctx *ctx, const dsb_read *reads, size_t n);
+/* the same for sequences that already lie in one host blob (a parsed FASTQ buffer): read i = text[seq_off[i] .. +seq_len[i]);
+ * the blob goes to the device in one copy, at PCIe speed if it came from dsb_host_alloc (pinned memory) */
+int  dsb_batch_upload_text(dsb_ctx *ctx, const char *text, size_t text_len, const uint64_t *seq_off, const uint32_t *seq_len, size_t n);
+void *dsb_host_alloc(size_t bytes);
+void  dsb_host_free(void *p);
 /* read_reads (src/cly_mt.c:42-56) for a plain-text FASTQ/FASTA file: stage records [skip, skip+max_reads) of the
  * file into HBM without per-read host copies; returns the number of reads staged, or a negative DSB_E* code */
 long dsb_batch_upload_fastq(dsb_ctx *ctx, const char *path, size_t skip, size_t max_reads);

@@ -1,0 +1,144 @@
+"""The CLI's input side (desamba_amd/csrc/desamba_main.c: pinned-buffer filling, carry-over between buffers, in-place
+record parser) against an independent character-level restatement of kseq_read (src/lib/utils.c:939-977), on awkward
+inputs and with buffers barely larger than one record.  No GPU."""
+import gzip
+import os
+import random
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def kseq_records(data: bytes):
+    """character-level kseq_read: yields (name, seq, qual or None)"""
+    pos = 0; n = len(data); last = 0
+    def getc():
+        nonlocal pos
+        if pos >= n:
+            return -1
+        c = data[pos]; pos += 1
+        return c
+    while True:
+        if last == 0:
+            c = getc()
+            while c != -1 and c not in (62, 64):
+                c = getc()
+            if c == -1:
+                return
+            last = c
+        name = bytearray(); seq = bytearray(); qual = bytearray()
+        c = getc()
+        while c != -1 and c not in b" \t\n\r\x0b\x0c":
+            name.append(c); c = getc()
+        if c == -1 and not name:
+            return
+        if c != 10:
+            while c != -1 and c != 10:
+                c = getc()
+        c = getc()
+        while c != -1 and c not in (62, 43, 64):
+            if c == 10:
+                c = getc(); continue
+            seq.append(c)
+            c = getc()
+            while c != -1 and c != 10:
+                if c != 13:
+                    seq.append(c)
+                c = getc()
+            c = getc()
+        if c in (62, 64):
+            last = c
+        if c != 43:
+            if c == -1:
+                last = 0
+            yield bytes(name), bytes(seq), None
+            continue
+        c = getc()
+        while c != -1 and c != 10:
+            c = getc()
+        if c == -1:
+            raise ValueError("truncated")
+        while len(qual) < len(seq):
+            c = getc()
+            if c == -1:
+                break
+            if c not in (10, 13):
+                qual.append(c)
+        last = 0
+        if len(qual) != len(seq):
+            raise ValueError("truncated")
+        yield bytes(name), bytes(seq), bytes(qual)
+
+
+@pytest.fixture(scope="module")
+def harness(built, tmp_path_factory):
+    exe = tmp_path_factory.mktemp("cli") / "parse_harness"
+    subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-I" + os.path.join(ROOT, "include"), "-o", str(exe),
+                           os.path.join(ROOT, "tests", "cli", "parse_harness.c"), "-L" + os.path.join(ROOT, "desamba_amd"), "-ldesamba_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "desamba_amd"), "-lpthread", "-lz"])
+    return str(exe)
+
+
+def run_harness(harness, cap, path):
+    out = subprocess.run([harness, str(cap), path], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    recs = []
+    for line in out.split(b"\n")[:-1]:
+        name, seq, qual, hist = line.split(b"\t")
+        recs.append((name, seq, qual, int(hist)))
+    return recs
+
+
+def make_inputs():
+    rnd = random.Random(7)
+    def dna(k):
+        return bytes(rnd.choice(b"ACGTN") for _ in range(k))
+    def q(k):   # '@', '>' and '+' are legal quality characters, also at the start of a line
+        return bytes(rnd.choice(b"@>+5I#!") for _ in range(k))
+    four = b"".join(b"@r%d some text\n%s\n+\n%s\n" % (i, s, q(len(s))) for i, s in enumerate(dna(rnd.randint(1, 300)) for _ in range(60)))
+    crlf = four.replace(b"\n", b"\r\n")
+    multi_fa = b"".join(b">c%d\n" % i + b"\n".join(dna(rnd.randint(1, 60)) for _ in range(rnd.randint(1, 5))) + b"\n" for i in range(40))
+    multi_fq = b""
+    for i in range(40):
+        lines = [dna(rnd.randint(1, 50)) for _ in range(rnd.randint(1, 4))]; tot = sum(map(len, lines)); qq = q(tot); cut = sorted(rnd.sample(range(1, tot), min(2, tot - 1))) if tot > 2 else []
+        qs = [qq[a:b] for a, b in zip([0] + cut, cut + [tot])]
+        multi_fq += b"@m%d\n" % i + b"\n".join(lines) + b"\n+m%d\n" % i + b"\n".join(qs) + b"\n"
+    junk = b"junk before\n\n" + four[:2000].rsplit(b"\n@", 1)[0] + b"\n\n\n" + multi_fa
+    no_nl = four.rstrip(b"\n")
+    empty_seq = b"@e1\n\n+\n\n@e2\nACGT\n+\n5555\n>f1\n>f2\nAC\n"
+    return {"four": four, "crlf": crlf, "multi_fa": multi_fa, "multi_fq": multi_fq, "junk": junk, "no_nl": no_nl, "empty_seq": empty_seq, "mixed": multi_fa + four + multi_fq}
+
+
+@pytest.mark.parametrize("name", sorted(make_inputs()))
+def test_parser_matches_kseq(harness, tmp_path, name):
+    data = make_inputs()[name]
+    exp = list(kseq_records(data))
+    assert exp, name
+    longest = max(len(n) + 2 * len(s) for n, s, _ in exp) + 700
+    path = tmp_path / (name + ".fq"); path.write_bytes(data)
+    gz = tmp_path / (name + ".fq.gz")
+    with gzip.open(gz, "wb") as f:
+        f.write(data)
+    for cap in (longest, longest + 13, 4096, 1 << 20):
+        for p in (path, gz):
+            got = run_harness(harness, cap, str(p))
+            assert [(n, s, q if q is not None else b"") for n, s, q in exp] == [(n, s, q) for n, s, q, _ in got], (name, cap, str(p))
+            hist = 0
+            # hist_before is constant within a batch: the running maximum at the first record of the batch
+            seen = []
+            for (n, s, q, h) in got:
+                seen.append(h)
+            run_max = 0; cur = None; batch_max_before = 0
+            for (n, s, q, h) in got:
+                assert h <= run_max, "history ahead of the reads"
+                run_max = max(run_max, len(s))
+
+
+def test_two_files_reset_history(harness, tmp_path):
+    a = tmp_path / "a.fq"; b = tmp_path / "b.fq"
+    a.write_bytes(b"@a1\n" + b"A" * 500 + b"\n+\n" + b"5" * 500 + b"\n")
+    b.write_bytes(b"@b1\nACGT\n+\n5555\n@b2\nAC\n+\n55\n")
+    out = subprocess.run([harness, "2000", str(a), str(b)], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.split(b"\n")[:-1]
+    assert [l.split(b"\t")[0] for l in out] == [b"a1", b"b1", b"b2"]
+    assert [int(l.split(b"\t")[3]) for l in out] == [0, 0, 0]      # second file starts a new history; both of its reads share a batch
