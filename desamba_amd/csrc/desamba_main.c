@@ -78,9 +78,10 @@ static void batch_reserve(batch_t *b, size_t n)
  * more data); modify = 1 joins multi-line sequence / quality in place and drops '\r'.
  * returns 1 record found, 0 more data needed, -1 end of input, -2 truncated quality */
 typedef struct { size_t name_off, name_end, seq_off, seq_len, qual_off; int has_qual, plain; size_t next; int next_last; } rec_t;
+static int g_chunk_has_cr = 1;    /* reader thread only: does the current buffer hold any '\r' at all? (one memchr per buffer instead of one per line) */
 static size_t copy_line(char *t, size_t w, size_t p, size_t len, int modify, int *plain)
 {	/* append t[p, p+len) minus '\r' at t[w]; returns the number of characters appended */
-	if (!memchr(t + p, '\r', len)) { if (modify && w != p) memmove(t + w, t + p, len); return len; }
+	if (!g_chunk_has_cr || !memchr(t + p, '\r', len)) { if (modify && w != p) memmove(t + w, t + p, len); return len; }
 	*plain = 0;
 	size_t k = 0;
 	for (size_t i = 0; i < len; i++) if (t[p + i] != '\r') { if (modify) t[w + k] = t[p + i]; k++; }
@@ -172,9 +173,36 @@ static int src_open(src_t *s, const char *path)
 	}
 	return 0;
 }
+/* plain files: the copy out of the page cache runs at one core's memcpy speed per thread, so big reads are split */
+#define N_PREAD 8
+typedef struct { int fd; char *buf; size_t len; off_t off; size_t got; } pread_job_t;
+static void *pread_main(void *arg)
+{
+	pread_job_t *j = arg;
+	while (j->got < j->len) { ssize_t k = pread(j->fd, j->buf + j->got, j->len - j->got, j->off + (off_t)j->got); if (k <= 0) break; j->got += (size_t)k; }
+	return NULL;
+}
 static size_t src_read(src_t *s, char *buf, size_t want)
 {
 	size_t got = 0;
+	static long pread_min = -1;
+	if (pread_min < 0) { const char *e = getenv("DSB_CLI_PREAD_MIN"); pread_min = e ? atol(e) : (64L << 20); }
+	if (!s->gz && want >= (size_t)pread_min) {
+		off_t pos = lseek(s->fd, 0, SEEK_CUR); struct stat st;
+		if (pos >= 0 && fstat(s->fd, &st) == 0 && S_ISREG(st.st_mode)) {
+			size_t avail = st.st_size > pos ? (size_t)(st.st_size - pos) : 0; if (avail > want) avail = want;
+			pthread_t th[N_PREAD]; pread_job_t job[N_PREAD]; size_t part = (avail + N_PREAD - 1) / N_PREAD;
+			for (int i = 0; i < N_PREAD; i++) {
+				size_t o = (size_t)i * part; job[i].fd = s->fd; job[i].buf = buf + o; job[i].off = pos + (off_t)o; job[i].got = 0;
+				job[i].len = o >= avail ? 0 : (avail - o < part ? avail - o : part);
+				pthread_create(&th[i], NULL, pread_main, &job[i]);
+			}
+			int ok = 1;
+			for (int i = 0; i < N_PREAD; i++) { pthread_join(th[i], NULL); if (job[i].got != job[i].len) ok = 0; }
+			if (ok) { lseek(s->fd, pos + (off_t)avail, SEEK_SET); return avail; }
+			lseek(s->fd, pos, SEEK_SET);                          /* short read somewhere: fall back to the sequential loop */
+		}
+	}
 	while (got < want) {
 		size_t ask = want - got > (1u << 30) ? (1u << 30) : want - got;
 		long k = s->gz ? (long)gzread(s->gz, buf + got, (unsigned)ask) : (long)read(s->fd, buf + got, ask);
@@ -203,6 +231,7 @@ static void *reader_main(void *arg)
 			size_t end = carry_len + got;
 			if (!eof && end < b->cap) eof = 1;
 			b->n = 0; b->hist_before = hist; b->seqno = seqno++;
+			g_chunk_has_cr = memchr(b->text, '\r', end) != NULL;
 			size_t pos = 0; rec_t r;
 			for (;;) {
 				int rc = scan_record(b->text, pos, end, eof, last, 0, &r);

@@ -142,3 +142,14 @@ def test_two_files_reset_history(harness, tmp_path):
     out = subprocess.run([harness, "2000", str(a), str(b)], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.split(b"\n")[:-1]
     assert [l.split(b"\t")[0] for l in out] == [b"a1", b"b1", b"b2"]
     assert [int(l.split(b"\t")[3]) for l in out] == [0, 0, 0]      # second file starts a new history; both of its reads share a batch
+
+
+def test_parallel_pread_path(harness, tmp_path, monkeypatch):
+    """big plain files are filled by several pread threads; force that path on a small file"""
+    data = make_inputs()["four"] * 40
+    path = tmp_path / "big.fq"; path.write_bytes(data)
+    exp = [(n, s, q) for n, s, q in kseq_records(data)]
+    monkeypatch.setenv("DSB_CLI_PREAD_MIN", "1024")
+    for cap in (5000, 100000, 1 << 22):
+        got = run_harness(harness, cap, str(path))
+        assert exp == [(n, s, q) for n, s, q, _ in got], cap
