@@ -19,11 +19,15 @@ python3 - "$tag" "$reads" <<'EOF'
 import csv, glob, json, sys, collections
 tag, reads = sys.argv[1], int(sys.argv[2])
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
+disp = collections.defaultdict(lambda: collections.defaultdict(set))
 for f in glob.glob("gpurun_out/pmc_%s_*/**/*counter_collection.csv" % tag, recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
         if k.startswith("k_"):
-            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
-json.dump({"workload": "%d x 50 kbp ONT reads, bench.py --steps 1 --warmup 0" % reads, "counters": acc}, open("gpurun_out/pmc_%s.json" % tag, "w"), indent=1, sort_keys=True)
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[k][r["Counter_Name"]].add(r["Dispatch_Id"])
+for k in acc:                     # per launch: average over the dispatches of the kernel
+    for c in acc[k]:
+        acc[k][c] /= max(len(disp[k][c]), 1)
+json.dump({"workload": "%d x 50 kbp ONT reads, bench.py --steps 1 --warmup 0; per-launch averages" % reads, "counters": acc}, open("gpurun_out/pmc_%s.json" % tag, "w"), indent=1, sort_keys=True)
 print(json.dumps(acc.get("k_classify", {}), indent=1, sort_keys=True))
 EOF
