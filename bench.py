@@ -147,9 +147,6 @@ def main():
         dt = float(t.item())
     res = ctx.fetch(strict=False)
     bases = ctx.timing().bases
-    # outside the timed region: the seed lookup once more as a kernel of its own (in the step it runs fused into
-    # k_classify), for the roofline line of the kernel the north star names
-    probe_alone_ms = min(ctx.probe_standalone() for _ in range(2)) if rank == 0 else 0.0
     n_bad = sum(1 for i in range(n_up) if res.reads[i].status != 0)
     n_mapped = sum(1 for i in range(n_up) if res.reads[i].n > 0)
     dev_us = sorted(res.reads[i].device_us for i in range(n_up))
@@ -161,20 +158,16 @@ def main():
         gbp = bases * world * a.steps / dt / 1e9
         tm = ctx.timing()
         probe_s = probe_ms / steps / 1e3; classify_s = classify_ms / steps / 1e3
-        fused = probe_s < 0.5e-3                      # no separate k_seed_probe in the step
         # algorithmic bytes
         seed_bytes = tm.bases + 64.0 * (tm.windows + tm.probes_t1)
-        # classify: per-bp work rates measured by the oracle's counters on this workload; the main k_classify
-        # launch handles all reads but the n_early heaviest (none when the lookup is fused)
+        # classify kernel: per-bp work rates measured by the oracle's counters on this workload
+        # (the main k_classify launch handles all reads but the n_early heaviest, which run beside the seed probe)
         cls_bytes = tm.bases * (64 * 0.1368 + 16 * 0.01137 + 24 * 0.00624 + 1.2542 / 4 + 2.0) * (a.reads_per_gpu - tm.n_early) / a.reads_per_gpu
-        if fused:
-            cls_bytes += seed_bytes
         dom_is_cls = classify_s >= probe_s
-        seed_t = probe_alone_ms / 1e3 if fused else probe_s
-        roof_seed = {"kernel": "k_seed_probe" + (" (standalone launch outside the timed step; fused into k_classify in the step)" if fused else ""), "bound": "hbm",
-                     "achieved": seed_bytes / seed_t / 1e9 if seed_t > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "ms": seed_t * 1e3}
+        roof_seed = {"kernel": "k_seed_probe", "bound": "hbm", "achieved": seed_bytes / probe_s / 1e9 if probe_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "traffic": None, "ms": probe_s * 1e3}
         roof_seed["frac"] = roof_seed["achieved"] / HBM_PEAK_GBS
-        roof_cls = {"kernel": "k_classify" + (" (seed lookup fused)" if fused else ""), "bound": "hbm", "achieved": cls_bytes / classify_s / 1e9 if classify_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
+        roof_cls = {"kernel": "k_classify", "bound": "hbm", "achieved": cls_bytes / classify_s / 1e9 if classify_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "traffic": None, "ms": classify_s * 1e3}
         roof_cls["frac"] = roof_cls["achieved"] / HBM_PEAK_GBS
         # HBM-side traffic per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command (separate passes,

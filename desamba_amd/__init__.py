@@ -50,7 +50,7 @@ class DsbTiming(C.Structure):
 
 EXPORTS = ["dsb_index_open", "dsb_index_close", "dsb_index_n_ref", "dsb_index_ref_name", "dsb_index_ref_len", "dsb_index_ek_len",
            "dsb_index_occ_host", "dsb_ctx_create", "dsb_ctx_destroy", "dsb_ctx_reset_history", "dsb_classify_batch",
-           "dsb_batch_upload", "dsb_batch_upload_fastq", "dsb_batch_upload_text", "dsb_ctx_set_history", "dsb_host_alloc", "dsb_host_free", "dsb_batch_run", "dsb_batch_fetch", "dsb_batch_timing", "dsb_batch_probe_standalone", "dsb_batch_seeds", "dsb_batch_exist_bits",
+           "dsb_batch_upload", "dsb_batch_upload_fastq", "dsb_batch_upload_text", "dsb_ctx_set_history", "dsb_host_alloc", "dsb_host_free", "dsb_batch_run", "dsb_batch_fetch", "dsb_batch_timing", "dsb_batch_seeds", "dsb_batch_exist_bits",
            "dsb_format_sam", "dsb_strerror", "dsb_version"]
 
 _lib = None
@@ -80,7 +80,6 @@ def lib():
     L.dsb_batch_run.argtypes = [C.c_void_p]
     L.dsb_batch_fetch.argtypes = [C.c_void_p, C.POINTER(DsbResult)]
     L.dsb_batch_timing.argtypes = [C.c_void_p, C.POINTER(DsbTiming)]
-    L.dsb_batch_probe_standalone.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.dsb_batch_seeds.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(DsbSeed), C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.dsb_batch_exist_bits.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint32)]
     L.dsb_format_sam.argtypes = [C.c_void_p, C.POINTER(DsbRead), C.POINTER(DsbHit), C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
@@ -197,14 +196,6 @@ class Ctx:
         t = DsbTiming()
         lib().dsb_batch_timing(self.h, C.byref(t))
         return t
-
-    def probe_standalone(self):
-        """ms of the seed lookup of the last batch run as a kernel of its own (measurement only)"""
-        ms = C.c_float(0)
-        rc = lib().dsb_batch_probe_standalone(self.h, C.byref(ms))
-        if rc != 0:
-            raise DsbError(rc, "dsb_batch_probe_standalone")
-        return ms.value
 
     def seeds(self, read, strand):
         cap = (self.reads[read].len >> 1) + 64

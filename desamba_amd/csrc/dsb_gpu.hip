@@ -261,9 +261,6 @@ struct DsbSlotArena {
 	uint32_t max_len;                             // longest read the arena was sized for
 };
 
-// fused seed lookup: pk == nullptr -> the hit bits were written by k_seed_probe before the launch
-struct DsbFusedProbe { const uint64_t *pk; const uint8_t *summ; int summ_shift; unsigned long long *p1; };
-
 // One kernel body, two instantiations.  Work items come from an atomic counter; with `list` == nullptr
 // item k is read k, otherwise read list[k] (the longest-processing-time-first order of k_order).
 #ifndef DSB_WAVES_PER_EU
@@ -272,8 +269,7 @@ struct DsbFusedProbe { const uint64_t *pk; const uint8_t *summ; int summ_shift; 
 #define DSB_DEFINE_CLASSIFY(KNAME, NS, THREADS)                                                                         \
 __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,   \
         const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout,  \
-        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg, uint32_t item_base, uint32_t slot_base,  \
-        DsbFusedProbe fp)                                                                                               \
+        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg, uint32_t item_base, uint32_t slot_base)  \
 {                                                                                                                       \
 	const int lane = threadIdx.x;                                                                                       \
 	const uint32_t slot_id = slot_base + blockIdx.x;            /* arena slot (and debug row) of this wave */          \
@@ -325,22 +321,6 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 		uint64_t tacc0[14]; if (w.dbg) for (int i = 0; i < 14; i++) tacc0[i] = w.tacc[i];                               \
 		if (w.dbg && lane == 0) { w.dbg[2] = r; w.dbg[0] = 100; }                                                       \
 		w.bin = bin + d.bin_off + DSB_QPAD_L; w.L = d.len; w.status = 0; w.max_read_l = d.hist_max;                     \
-		if (fp.pk && d.n_words) {   /* fused seed lookup: this wave probes the windows of its own read (probe_un) */      \
-			const int k_ = x.ek_len, sbm_ = x.single_base_max;                                                          \
-			const uint64_t kmask_ = k_ >= 32 ? ~0ULL : ((1ULL << (2 * k_)) - 1ULL);                                     \
-			unsigned long long p1_ = 0; const uint32_t n_items_ = 2 * d.n_words;                                        \
-			for (uint32_t w0 = 0; w0 < n_items_; w0 += DSB_PROBE_UN) {                                                  \
-				DsbWordDesc wds[DSB_PROBE_UN]; bool have[DSB_PROBE_UN];                                                 \
-				_Pragma("unroll") for (int u = 0; u < DSB_PROBE_UN; u++) {                                              \
-					uint32_t it = w0 + u; have[u] = it < n_items_;                                                      \
-					wds[u].read = r; wds[u].word = it >= d.n_words ? ((it - d.n_words) | 0x80000000u) : it;             \
-				}                                                                                                       \
-				probe_un(x, rd, fp.pk, const_cast<uint64_t *>(bits), wds, have, lane, k_, sbm_, kmask_, fp.summ, fp.summ_shift, p1_); \
-			}                                                                                                           \
-			for (int o = 32; o > 0; o >>= 1) p1_ += __shfl_down(p1_, o);                                                \
-			if (lane == 0 && p1_ && fp.p1) atomicAdd(fp.p1, p1_);                                                       \
-			NS::wave_sync();                                                                                            \
-		}                                                                                                               \
 		uint32_t fast = NS::classify_read(w, bits + d.bit_off, bits + d.bit_off + d.n_words);                           \
 		if (w.boosted) __builtin_amdgcn_s_setprio(0);                                                                   \
 		/* publish the hits of this read */                                                                             \
@@ -656,15 +636,8 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	// Head start for the tail: the kernel's duration is the duration of its heaviest read (tandem repeats: minutes of
 	// sparse DP on the CPU, ~0.2 s here).  The first n_heavy reads of the LPT order get their probes and their own
 	// k_classify launch on the second stream right away, beside the main seed probe, instead of after it.
-	// DSB_FUSED_PROBE=1: the seed lookup runs inside k_classify (every wave probes the windows of its read right before it
-	// classifies it) instead of k_seed_probe + the early launch below.  Measured equal (284 ms fused vs 83 + 201 ms): the
-	// two phases compete for the same request path rather than filling each other's gaps, so the separate, separately
-	// measurable kernel stays the default.
-	static const int fused = getenv("DSB_FUSED_PROBE") ? atoi(getenv("DSB_FUSED_PROBE")) : 0;
-	DsbFusedProbe fp; fp.pk = fused ? c->d_pk : nullptr; fp.summ = c->d_summ; fp.summ_shift = c->summ_shift; fp.p1 = (unsigned long long *)(c->d_counters + 2);
-	DsbFusedProbe fp_off; fp_off.pk = nullptr; fp_off.summ = nullptr; fp_off.summ_shift = 0; fp_off.p1 = nullptr;
 	unsigned n_heavy = 0;
-	if (!dbg && !fused && c->n_words_total) {
+	if (!dbg && c->n_words_total) {
 		const char *hv = getenv("DSB_HEAVY_FIRST");
 		n_heavy = hv ? (unsigned)atoi(hv) : (n >= 4096 ? (unsigned)(n / 64) : 0u);
 		if (n_heavy > DSB_HEAVY_SLOTS) n_heavy = DSB_HEAVY_SLOTS;
@@ -679,10 +652,10 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_hprobe, 0));
 		hipLaunchKernelGGL(k_classify_early, dim3(n_heavy), dim3(64), 0, c->stream2, c->dx, c->d_rd, (uint32_t)n_heavy, (const unsigned int *)nullptr, (const uint32_t *)c->d_order,
 		                   c->d_bin, c->d_bits, c->arena, c->d_counters + 4, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout,
-		                   (uint32_t *)nullptr, 0u, (uint32_t)c->n_slots, fp_off);
+		                   (uint32_t *)nullptr, 0u, (uint32_t)c->n_slots);
 		HIPCHK(hipEventRecord(c->ev_heavy, c->stream2));
 	}
-	if (c->n_words_total && !fused) {
+	if (c->n_words_total) {
 		uint64_t waves = (c->n_words_total + DSB_PROBE_UN - 1) / DSB_PROBE_UN; unsigned blocks = (unsigned)((waves + 3) / 4);
 		if (blocks > 256u * 32u) blocks = 256u * 32u;       // >= 8 blocks of 4 waves per CU, grid-stride beyond
 		hipLaunchKernelGGL(k_seed_probe, dim3(blocks), dim3(256), 0, c->stream, c->dx, c->d_rd, c->d_wd, c->n_words_total, c->d_pk, c->d_bits,
@@ -697,7 +670,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		// counters: [0] work, [1] hits, [2..3] u64 table-1 probes
 		hipLaunchKernelGGL(k_classify, dim3(slots), dim3(64), 0, c->stream, c->dx, c->d_rd, (uint32_t)n, (const unsigned int *)nullptr, (const uint32_t *)c->d_order,
 		                   c->d_bin, c->d_bits, c->arena, c->d_counters, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout,
-		                   dbgp, (uint32_t)n_heavy, 0u, fp);
+		                   dbgp, (uint32_t)n_heavy, 0u);
 		HIPCHK(hipEventRecord(c->ev_cls, c->stream));
 		if (n_heavy) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_heavy, 0));
 		if (dbg) {
@@ -742,25 +715,6 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	HIPCHK(hipMemcpy(&c->p1, c->d_counters + 2, 8, hipMemcpyDeviceToHost));
 
 	c->timing.windows = c->total_windows; c->timing.probes_t1 = c->p1; c->timing.bases = c->total_bases;
-	return DSB_OK;
-}
-
-// the seed lookup of the current batch as a kernel of its own (k_seed_probe), timed: measurement only -- the batch must
-// have been run (its packed reads are in HBM); the hit bits it writes are the ones already there
-extern "C" int dsb_batch_probe_standalone(dsb_ctx *c, float *ms)
-{
-	if (!c || !ms) return DSB_EINVAL;
-	*ms = 0.f;
-	if (!c->n_reads || !c->n_words_total) return DSB_OK;
-	HIPCHK(hipSetDevice(c->device));
-	uint64_t waves = (c->n_words_total + DSB_PROBE_UN - 1) / DSB_PROBE_UN; unsigned blocks = (unsigned)((waves + 3) / 4);
-	if (blocks > 256u * 32u) blocks = 256u * 32u;
-	HIPCHK(hipEventRecord(c->ev[0], c->stream));
-	hipLaunchKernelGGL(k_seed_probe, dim3(blocks), dim3(256), 0, c->stream, c->dx, c->d_rd, c->d_wd, c->n_words_total, c->d_pk, c->d_bits,
-	                   (unsigned long long *)nullptr, c->d_summ, c->summ_shift);
-	HIPCHK(hipEventRecord(c->ev[1], c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
-	hipEventElapsedTime(ms, c->ev[0], c->ev[1]);
 	return DSB_OK;
 }
 

@@ -117,9 +117,6 @@ long dsb_batch_upload_fastq(dsb_ctx *ctx, const char *path, size_t skip, size_t 
 int  dsb_batch_run(dsb_ctx *ctx);                       /* all kernels, synchronous */
 int  dsb_batch_fetch(dsb_ctx *ctx, dsb_result *out);
 int  dsb_batch_timing(const dsb_ctx *ctx, dsb_timing *t);
-/* measurement only: the seed lookup of the batch last run as a kernel of its own (by default it runs fused into the
- * classify kernel), HIP-event time in ms */
-int  dsb_batch_probe_standalone(dsb_ctx *ctx, float *ms);
 /* stage dumps of the last run: seeds of one read strand (1 = forward, 0 = reverse) */
 int  dsb_batch_seeds(dsb_ctx *ctx, size_t read, int strand, dsb_seed *out, size_t cap, uint32_t *n, uint32_t *total_score);
 /* exist-kmer hit bits of one read strand, one byte per window */
