@@ -29,8 +29,9 @@
 
 #define N_BATCH 4                     /* batch buffers in flight */
 #define N_GPU_CTX 2
-#define MAX_BATCH_READS (1u << 21)
+#define MAX_BATCH_READS (1u << 23)
 
+static double now(void);
 static void die(const char *msg) { fprintf(stderr, "%s\n", msg); exit(1); }
 
 /* ---------------------------------------------------------------- batches and queues */
@@ -213,6 +214,102 @@ static size_t src_read(src_t *s, char *buf, size_t want)
 }
 static void src_close(src_t *s) { if (s->gz) gzclose(s->gz); else close(s->fd); }
 
+/* ---------------------------------------------------------------- parallel parse of one buffer (plain 4-line FASTQ)
+ * The buffer is cut at guessed record starts ("\n@", a '+' line two lines later, quality as long as the sequence), every
+ * piece is parsed by its own thread without touching the text, and the pieces are accepted only if each one ends exactly
+ * where the next was guessed to start -- i.e. if the sequential kseq parse would have produced the same records.
+ * Anything else (multi-line records, '\r', a wrong guess) falls back to the sequential loop. */
+#define N_PARSE 8
+typedef struct {
+	char *t; size_t start, limit, end; int eof, is_last;
+	size_t n, cap; uint64_t *name_off, *name_end, *seq_off, *qual_off; uint32_t *seq_len; unsigned char *has_qual;
+	size_t end_pos; int ok;
+} seg_t;
+static size_t guess_record_start(const char *t, size_t from, size_t end)
+{
+	size_t lim = from + (4u << 20) < end ? from + (4u << 20) : end;
+	for (size_t p = from; p < lim;) {
+		const char *nl = memchr(t + p, '\n', lim - p);
+		if (!nl) break;
+		size_t c = (size_t)(nl - t) + 1; p = c;
+		if (c >= end || t[c] != '@') continue;
+		const char *e1 = memchr(t + c, '\n', end - c); if (!e1) break;
+		const char *e2 = memchr(e1 + 1, '\n', end - (size_t)(e1 + 1 - t)); if (!e2) break;
+		if ((size_t)(e2 + 1 - t) >= end || e2[1] != '+') continue;
+		const char *e3 = memchr(e2 + 1, '\n', end - (size_t)(e2 + 1 - t)); if (!e3) break;
+		const char *e4 = memchr(e3 + 1, '\n', end - (size_t)(e3 + 1 - t));
+		size_t ql = (e4 ? (size_t)(e4 - e3) : end - (size_t)(e3 - t)) - 1, sl = (size_t)(e2 - e1) - 1;
+		if (ql == sl && sl > 0) return c;
+	}
+	return (size_t)-1;
+}
+static void *parse_main(void *arg)
+{
+	seg_t *g = arg; size_t pos = g->start; rec_t r;
+	g->ok = 1; g->n = 0;
+	for (;;) {
+		if (!g->is_last && pos >= g->limit) break;
+		int rc = scan_record(g->t, pos, g->end, g->is_last ? g->eof : 0, 0, 0, &r);
+		if (rc == 0 && g->is_last) { pos = r.next; break; }                       /* the rest continues in the next buffer */
+		if (rc == -1 && g->is_last) { pos = g->end; break; }
+		if (rc != 1 || !r.plain || r.next_last != 0 || r.seq_len > 0xffffffffUL) { g->ok = 0; break; }
+		if (g->n == g->cap) {
+			size_t m = g->cap ? g->cap * 2 : 4096;
+			g->name_off = realloc(g->name_off, m * 8); g->name_end = realloc(g->name_end, m * 8); g->seq_off = realloc(g->seq_off, m * 8);
+			g->qual_off = realloc(g->qual_off, m * 8); g->seq_len = realloc(g->seq_len, m * 4); g->has_qual = realloc(g->has_qual, m);
+			if (!g->name_off || !g->name_end || !g->seq_off || !g->qual_off || !g->seq_len || !g->has_qual) { g->ok = 0; break; }
+			g->cap = m;
+		}
+		g->name_off[g->n] = r.name_off; g->name_end[g->n] = r.name_end; g->seq_off[g->n] = r.seq_off; g->qual_off[g->n] = r.qual_off;
+		g->seq_len[g->n] = (uint32_t)r.seq_len; g->has_qual[g->n] = (unsigned char)r.has_qual; g->n++;
+		pos = r.next;
+	}
+	g->end_pos = pos;
+	return NULL;
+}
+/* returns 1 and fills the batch (records of text[0, *pos_out)) if the parallel parse is valid, 0 otherwise (nothing changed) */
+static int parse_parallel(batch_t *b, size_t end, int eof, uint32_t *hist, size_t *pos_out)
+{
+	static long pmin = -1; static seg_t seg[N_PARSE];
+	if (pmin < 0) { const char *e = getenv("DSB_CLI_PPARSE_MIN"); pmin = e ? atol(e) : (32L << 20); }
+	if (end < (size_t)pmin || g_chunk_has_cr) return 0;
+	size_t start[N_PARSE + 1]; int np = 1; start[0] = 0;
+	for (int k = 1; k < N_PARSE; k++) {
+		size_t from = end / N_PARSE * (size_t)k; if (from <= start[np - 1]) continue;
+		size_t g = guess_record_start(b->text, from, end);
+		if (g == (size_t)-1) break;
+		if (g > start[np - 1]) start[np++] = g;
+	}
+	if (np < 2) return 0;
+	start[np] = end;
+	pthread_t th[N_PARSE];
+	for (int k = 0; k < np; k++) {
+		seg[k].t = b->text; seg[k].start = start[k]; seg[k].limit = start[k + 1]; seg[k].end = end; seg[k].eof = eof; seg[k].is_last = k == np - 1;
+		pthread_create(&th[k], NULL, parse_main, &seg[k]);
+	}
+	int ok = 1;
+	for (int k = 0; k < np; k++) { pthread_join(th[k], NULL); if (!seg[k].ok) ok = 0; }
+	/* each piece must end where the sequential parse would start the next record: only separators up to the guessed '@' */
+	for (int k = 0; ok && k + 1 < np; k++) {
+		if (seg[k].end_pos > start[k + 1]) { ok = 0; break; }
+		for (size_t p = seg[k].end_pos; p < start[k + 1]; p++) if (b->text[p] == '>' || b->text[p] == '@') { ok = 0; break; }
+	}
+	if (!ok) return 0;
+	size_t total = 0; for (int k = 0; k < np; k++) total += seg[k].n;
+	batch_reserve(b, total + 1);
+	size_t n = 0; uint32_t h = *hist;
+	for (int k = 0; k < np; k++)
+		for (size_t i = 0; i < seg[k].n; i++, n++) {
+			b->name_off[n] = seg[k].name_off[i]; b->seq_off[n] = seg[k].seq_off[i]; b->seq_len[n] = seg[k].seq_len[i];
+			b->qual_off[n] = seg[k].qual_off[i]; b->has_qual[n] = seg[k].has_qual[i];
+			b->text[seg[k].name_end[i]] = 0;
+			if (seg[k].seq_len[i] > h) h = seg[k].seq_len[i];
+		}
+	b->n = n; *hist = h; *pos_out = seg[np - 1].end_pos;
+	if (getenv("DSB_CLI_TRACE")) fprintf(stderr, "[reader] buffer of %zu bytes parsed in %d pieces, %zu records\n", end, np, n);
+	return 1;
+}
+
 static void *reader_main(void *arg)
 {
 	app_t *a = arg; long seqno = 0;
@@ -227,12 +324,15 @@ static void *reader_main(void *arg)
 			if (!b->text) { b->text = a->pageable ? malloc(a->batch_cap + 64) : dsb_host_alloc(a->batch_cap + 64); b->cap = a->batch_cap; if (!b->text) die("[classify] cannot allocate a pinned batch buffer"); }
 			if (carry_len > b->cap) die("[classify] one record is larger than the batch buffer (raise DSB_CLI_BATCH_MB)");
 			memcpy(b->text, carry, carry_len);
+			double t_r0 = now();
 			size_t got = eof ? 0 : src_read(&src, b->text + carry_len, b->cap - carry_len);
+			double t_r1 = now();
 			size_t end = carry_len + got;
 			if (!eof && end < b->cap) eof = 1;
 			b->n = 0; b->hist_before = hist; b->seqno = seqno++;
 			g_chunk_has_cr = memchr(b->text, '\r', end) != NULL;
 			size_t pos = 0; rec_t r;
+			if (last == 0 && parse_parallel(b, end, eof, &hist, &pos)) goto parsed;
 			for (;;) {
 				int rc = scan_record(b->text, pos, end, eof, last, 0, &r);
 				if (rc == 1 && !r.plain) rc = scan_record(b->text, pos, end, eof, last, 1, &r);
@@ -247,6 +347,8 @@ static void *reader_main(void *arg)
 				b->n++; pos = r.next; last = r.next_last;
 				if (b->n >= MAX_BATCH_READS) break;
 			}
+		parsed:
+			if (getenv("DSB_CLI_TRACE")) fprintf(stderr, "[reader] batch %ld: %zu bytes, fill %.3f s, parse %.3f s, %zu reads\n", b->seqno, end, t_r1 - t_r0, now() - t_r1, b->n);
 			/* what is left is the beginning of a record that continues in the next buffer */
 			carry_len = end - pos;
 			if (eof && b->n == 0) carry_len = 0;                           /* trailing junk without a record */
@@ -274,10 +376,14 @@ static void *gpu_main(void *arg)
 		b->n_hits = 0;
 		if (b->n) {
 			dsb_result res; int rc;
+			double t0 = now(), t1, t2;
 			dsb_ctx_set_history(ctx, b->hist_before);
 			rc = dsb_batch_upload_text(ctx, b->text, b->len, b->seq_off, b->seq_len, b->n);
+			t1 = now();
 			if (!rc) rc = dsb_batch_run(ctx);
+			t2 = now();
 			if (!rc || rc == DSB_ECAP) rc = dsb_batch_fetch(ctx, &res);
+			if (getenv("DSB_CLI_TRACE")) fprintf(stderr, "[gpu %d] batch %ld: upload %.3f s, run %.3f s, fetch %.3f s\n", g->k, b->seqno, t1 - t0, t2 - t1, now() - t2);
 			if (rc && rc != DSB_ECAP) { fprintf(stderr, "[dsb_classify_batch] %s\n", dsb_strerror(rc)); exit(1); }
 			if (b->n > b->cap_rr) { b->cap_rr = b->n * 2; b->rr = realloc(b->rr, b->cap_rr * sizeof *b->rr); }
 			if (res.n_hits > b->cap_hits) { b->cap_hits = res.n_hits * 2; b->hits = realloc(b->hits, b->cap_hits * sizeof *b->hits); }

@@ -108,6 +108,13 @@ __global__ void __launch_bounds__(256) k_ek_summary(const uint8_t *ek0, uint64_t
 	summ[t] = (uint8_t)o;
 }
 
+// the (read, word) work list of k_seed_probe, written on the device: read r owns entries [bit_off, bit_off + 2 n_words)
+__global__ void __launch_bounds__(256) k_build_wd(const DsbReadDesc *rd, DsbWordDesc *wd)
+{
+	const DsbReadDesc d = rd[blockIdx.x];
+	for (uint32_t t = threadIdx.x; t < 2 * d.n_words; t += 256) { DsbWordDesc w; w.read = blockIdx.x; w.word = t < d.n_words ? t : ((t - d.n_words) | 0x80000000u); wd[d.bit_off + t] = w; }
+}
+
 // DSB_PROBE_UN word descriptors per wave iteration: the loads of each stage (packed words, summary, table 0,
 // table 1) are issued for all of them before the first is consumed, so a wave keeps UN gathers in flight.
 #define DSB_PROBE_UN 4
@@ -507,7 +514,7 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 	if (!c || (!reads && n)) return DSB_EINVAL;
 	HIPCHK(hipSetDevice(c->device));
 	const int k = c->dx.ek_len;
-	c->h_rd.resize(n); c->h_wd.clear();
+	c->h_rd.resize(n);
 	uint64_t seq_off = 0, bin_off = 0, pk_off = 0, bit_off = 0, windows = 0; uint32_t max_len = 64; int hist = c->hist_max;
 	for (size_t i = 0; i < n; i++) {
 		DsbReadDesc &d = c->h_rd[i];
@@ -518,28 +525,27 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 		pk_off += 2 * ((d.len + 31) / 32 + 1); bit_off += 2 * (size_t)d.n_words;
 		if (d.len > max_len) max_len = d.len;
 		windows += 2 * (uint64_t)d.n_win;
-		for (uint32_t s = 0; s < 2; s++) for (uint32_t wI = 0; wI < d.n_words; wI++) { DsbWordDesc wdsc; wdsc.read = (uint32_t)i; wdsc.word = wI | (s << 31); c->h_wd.push_back(wdsc); }
 	}
 	c->hist_max = hist;
-	c->n_reads = n; c->n_words_total = c->h_wd.size(); c->total_bases = seq_off; c->total_windows = windows; c->max_len = max_len;
+	c->n_reads = n; c->n_words_total = bit_off; c->total_bases = seq_off; c->total_windows = windows; c->max_len = max_len;
 	int rc;
 	if ((rc = grow(&c->d_rd, &c->cap_rd, n + 1))) return rc;
-	if ((rc = grow(&c->d_wd, &c->cap_wd, c->h_wd.size() + 1))) return rc;
+	if ((rc = grow(&c->d_wd, &c->cap_wd, (size_t)bit_off + 1))) return rc;
 	if ((rc = grow(&c->d_ascii, &c->cap_ascii, (ext_text ? ext_len : (size_t)seq_off) + 64))) return rc;
 	if ((rc = grow(&c->d_bin, &c->cap_bin, (size_t)bin_off + 256))) return rc;
 	if ((rc = grow(&c->d_pk, &c->cap_pk, (size_t)pk_off + 8))) return rc;
 	if ((rc = grow(&c->d_bits, &c->cap_bits, (size_t)bit_off + 8))) return rc;
 	if ((rc = grow(&c->d_rout, &c->cap_rout, n + 1))) return rc;
 	if ((rc = grow(&c->d_hout, &c->cap_hout, 16 * n + 4096))) return rc;
-	// reads in flight: one wavefront each; default 8 waves per SIMD's worth, bounded by the batch
-	int want = c->opts.n_slots > 0 ? c->opts.n_slots : 256 * 4 * 4;
+	// reads in flight: one wavefront each; default = what is resident at once (12 waves per CU: LDS), bounded by the batch
+	int want = c->opts.n_slots > 0 ? c->opts.n_slots : 256 * 12;
 	if ((size_t)want > n) want = (int)(n ? n : 1);
 	if ((rc = size_arena(c->arena, &c->n_slots, max_len, want > c->n_slots ? want : c->n_slots, 64))) return rc;
 	if ((rc = grow(&c->d_score, &c->cap_score, n + 1))) return rc;
 	if ((rc = grow(&c->d_order, &c->cap_order, n + 1))) return rc;
 	if (n) {
 		HIPCHK(hipMemcpyAsync(c->d_rd, c->h_rd.data(), n * sizeof(DsbReadDesc), hipMemcpyHostToDevice, c->stream));
-		if (!c->h_wd.empty()) HIPCHK(hipMemcpyAsync(c->d_wd, c->h_wd.data(), c->h_wd.size() * sizeof(DsbWordDesc), hipMemcpyHostToDevice, c->stream));
+		if (bit_off) hipLaunchKernelGGL(k_build_wd, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_rd, c->d_wd);
 		if (ext_text) HIPCHK(hipMemcpy(c->d_ascii, ext_text, ext_len, hipMemcpyHostToDevice));
 		else {
 			// sequences: copied read by read out of the caller's buffers (caller owns read memory)

@@ -153,3 +153,21 @@ def test_parallel_pread_path(harness, tmp_path, monkeypatch):
     for cap in (5000, 100000, 1 << 22):
         got = run_harness(harness, cap, str(path))
         assert exp == [(n, s, q) for n, s, q, _ in got], cap
+
+
+@pytest.mark.parametrize("name", ["four", "mixed", "multi_fq", "junk", "no_nl", "crlf"])
+def test_parallel_parse_path(harness, tmp_path, monkeypatch, name):
+    """buffers above a threshold are cut at guessed record starts and parsed by several threads; the result must be the
+    sequential one whether the guess holds (4-line FASTQ) or the code has to fall back (anything else)"""
+    data = make_inputs()[name] * 25
+    path = tmp_path / "p.fq"; path.write_bytes(data)
+    exp = [(n, s, q if q is not None else b"") for n, s, q in kseq_records(data)]
+    monkeypatch.setenv("DSB_CLI_PPARSE_MIN", "2000")
+    longest = max(len(n) + 2 * len(s) for n, s, _ in exp) + 700
+    for cap in (longest * 12, 60000, 1 << 23):
+        got = run_harness(harness, cap, str(path))
+        assert exp == [(n, s, q) for n, s, q, _ in got], (name, cap)
+        run_max = 0
+        for (n, s, q, h) in got:
+            assert h <= run_max
+            run_max = max(run_max, len(s))
