@@ -397,31 +397,47 @@ static void *gpu_main(void *arg)
 	return NULL;
 }
 
+/* SAM text of the reads [lo, hi) of a batch into one growing buffer (one formatter thread per slice) */
+#define N_FORMAT 8
+typedef struct { app_t *a; batch_t *b; size_t lo, hi; char *buf; size_t len, cap; } fmt_job_t;
+static void *format_main(void *arg)
+{
+	fmt_job_t *j = arg; app_t *a = j->a; batch_t *b = j->b;
+	j->len = 0;
+	for (size_t i = j->lo; i < j->hi; i++) {
+		const dsb_read_result *rr = &b->rr[i];
+		dsb_read rd; rd.name = b->text + b->name_off[i]; rd.seq = b->text + b->seq_off[i]; rd.len = b->seq_len[i];
+		rd.qual = b->has_qual[i] ? b->text + b->qual_off[i] : "";
+		if (rr->status) { fprintf(stderr, "[classify] read %s: device arena overflow (status %d)\n", rd.name, rr->status); exit(1); }
+		size_t need = 4096 + 800 * (size_t)rr->n + (a->full ? 2 * (size_t)rd.len : 0) + strlen(rd.name);
+		if (j->len + need > j->cap) { j->cap = (j->len + need) * 2; j->buf = realloc(j->buf, j->cap); if (!j->buf) die("[classify] out of memory"); }
+		long w = dsb_format_sam(a->idx, &rd, b->hits + rr->first, rr->n, a->o.max_sec_N, a->full, j->buf + j->len, j->cap - j->len);
+		if (w < 0) die("[dsb_format_sam] buffer too small");
+		j->len += (size_t)w;
+	}
+	return NULL;
+}
+
 static void *writer_main(void *arg)
 {
 	app_t *a = arg; long next = 0; batch_t *held[N_BATCH + 2]; int n_held = 0;
-	size_t cap = 1 << 20; char *line = malloc(cap);
+	static fmt_job_t job[N_FORMAT];
 	batch_t *b;
 	for (;;) {
 		b = NULL;
 		for (int i = 0; i < n_held; i++) if (held[i]->seqno == next) { b = held[i]; held[i] = held[--n_held]; break; }
 		if (!b) { b = q_pop(&a->done_q); if (!b) break; if (b->seqno != next) { held[n_held++] = b; continue; } }
-		for (size_t i = 0; i < b->n; i++) {
-			const dsb_read_result *rr = &b->rr[i];
-			dsb_read rd; rd.name = b->text + b->name_off[i]; rd.seq = b->text + b->seq_off[i]; rd.len = b->seq_len[i];
-			rd.qual = b->has_qual[i] ? b->text + b->qual_off[i] : "";
-			if (rr->status) { fprintf(stderr, "[classify] read %s: device arena overflow (status %d)\n", rd.name, rr->status); exit(1); }
-			size_t need = 4096 + 800 * (size_t)rr->n + (a->full ? 2 * (size_t)rd.len : 0) + strlen(rd.name);
-			if (need > cap) { cap = need * 2; line = realloc(line, cap); if (!line) die("[classify] out of memory"); }
-			long w = dsb_format_sam(a->idx, &rd, b->hits + rr->first, rr->n, a->o.max_sec_N, a->full, line, cap);
-			if (w < 0) die("[dsb_format_sam] buffer too small");
-			fwrite(line, 1, (size_t)w, a->out);
+		int nt = b->n >= 4096 ? N_FORMAT : 1; pthread_t th[N_FORMAT]; size_t part = (b->n + (size_t)nt - 1) / (size_t)nt;
+		for (int t = 0; t < nt; t++) {
+			job[t].a = a; job[t].b = b; job[t].lo = (size_t)t * part < b->n ? (size_t)t * part : b->n; job[t].hi = job[t].lo + part < b->n ? job[t].lo + part : b->n;
+			if (nt > 1) pthread_create(&th[t], NULL, format_main, &job[t]); else format_main(&job[t]);
 		}
+		for (int t = 0; t < nt; t++) { if (nt > 1) pthread_join(th[t], NULL); fwrite(job[t].buf, 1, job[t].len, a->out); }
 		a->total += b->n;
 		next++;
 		q_push(&a->free_q, b);
 	}
-	free(line);
+	for (int t = 0; t < N_FORMAT; t++) free(job[t].buf);
 	return NULL;
 }
 
@@ -472,8 +488,8 @@ static int classify_main(int argc, char **argv)
 		if (fstat(fd, &st) == 0 && (size_t)st.st_size * (gz ? 8 : 1) > want) want = (size_t)st.st_size * (gz ? 8 : 1);
 		close(fd);
 	}
-	const char *mb = getenv("DSB_CLI_BATCH_MB");
-	a.batch_cap = (size_t)(mb ? atol(mb) : 1536) << 20;
+	const char *mb = getenv("DSB_CLI_BATCH_MB"), *kb = getenv("DSB_CLI_BATCH_KB");     /* KB: tests */
+	a.batch_cap = kb ? (size_t)atol(kb) << 10 : (size_t)(mb ? atol(mb) : 1536) << 20;
 	if (want + (1 << 20) < a.batch_cap) a.batch_cap = want + (1 << 20);
 	if (a.batch_cap < (1 << 16)) a.batch_cap = 1 << 16;
 	setvbuf(a.out, NULL, _IOFBF, 8 << 20);

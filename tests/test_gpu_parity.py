@@ -138,6 +138,31 @@ def test_cli_drop_in(gpu, demo, golden_md5, tmp_path):
     assert hashlib.md5(open(out, "rb").read()).hexdigest() == golden_md5
 
 
+def test_cli_many_batches_files_and_gzip(gpu, tmp_path, monkeypatch):
+    """the CLI pipeline with buffers of 256 KB (dozens of batches alternating between the two device contexts, records
+    carried over buffer ends), several input files (history restarts per file) and gzip input"""
+    import gzip
+    import subprocess
+    names = ["ont20k", "ngs150", "pb", "appc", "wrapq"]
+    exp = b"".join(open(os.path.join(GOLDEN, "synth", n + ".ubfree.sam"), "rb").read() for n in names)
+    files = []
+    for i, n in enumerate(names):
+        src = os.path.join(GOLDEN, "synth", n + ".fq")
+        if i % 2:
+            dst = tmp_path / (n + ".fq.gz")
+            with gzip.open(dst, "wb") as f:
+                f.write(open(src, "rb").read())
+            files.append(str(dst))
+        else:
+            files.append(src)
+    monkeypatch.setenv("DSB_CLI_BATCH_KB", "256")
+    out = tmp_path / "out.sam"
+    from conftest import ROOT as R
+    subprocess.check_call([os.path.join(R, "desamba_amd", "bin", "deSAMBA"), "classify", os.path.join(R, "data", "demo", "index")] + files + ["-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    assert out.read_bytes() == exp
+
+
 def test_full_size_batch_properties(gpu, demo, oracle, tmp_path):
     """BASELINE-size reads (50 kbp) in a batch large enough to exercise the work queue, the work ordering and
     many waves per CU: (1) a shuffled copy of the batch gives the same per-read hits (order independence),
