@@ -402,9 +402,9 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	c->idx = idx; c->device = device_id;
 	c->opts.L_min_matching = opts ? opts->L_min_matching : 170; c->opts.min_score = opts ? opts->min_score : 64;
 	c->opts.max_sec_N = opts ? opts->max_sec_N : 5; c->opts.n_slots = opts ? opts->n_slots : 0;
-	HIPCHK(hipStreamCreate(&c->stream));
+	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));   // contexts on one device overlap each other's copies and kernels
 	for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
-	HIPCHK(hipStreamCreate(&c->stream2)); HIPCHK(hipEventCreate(&c->ev_order)); HIPCHK(hipEventCreate(&c->ev_cls)); HIPCHK(hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_hprobe, hipEventDisableTiming));
+	HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)); HIPCHK(hipEventCreate(&c->ev_order)); HIPCHK(hipEventCreate(&c->ev_cls)); HIPCHK(hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_hprobe, hipEventDisableTiming));
 	// stage the index into HBM once
 	const DsbHostIndex *h = dsb_index_host(idx);
 	DsbDevIndex &dx = c->dx; memset(&dx, 0, sizeof dx);
@@ -546,12 +546,13 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 	if (n) {
 		HIPCHK(hipMemcpyAsync(c->d_rd, c->h_rd.data(), n * sizeof(DsbReadDesc), hipMemcpyHostToDevice, c->stream));
 		if (bit_off) hipLaunchKernelGGL(k_build_wd, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_rd, c->d_wd);
-		if (ext_text) HIPCHK(hipMemcpy(c->d_ascii, ext_text, ext_len, hipMemcpyHostToDevice));
+		if (ext_text) HIPCHK(hipMemcpyAsync(c->d_ascii, ext_text, ext_len, hipMemcpyHostToDevice, c->stream));
 		else {
 			// sequences: copied read by read out of the caller's buffers (caller owns read memory)
 			std::vector<char> stage((size_t)seq_off);
 			for (size_t i = 0; i < n; i++) memcpy(stage.data() + c->h_rd[i].seq_off, reads[i].p, reads[i].len);
-			HIPCHK(hipMemcpy(c->d_ascii, stage.data(), (size_t)seq_off, hipMemcpyHostToDevice));
+			HIPCHK(hipMemcpyAsync(c->d_ascii, stage.data(), (size_t)seq_off, hipMemcpyHostToDevice, c->stream));
+			HIPCHK(hipStreamSynchronize(c->stream));       // `stage` goes out of scope
 		}
 	}
 	HIPCHK(hipStreamSynchronize(c->stream));
@@ -718,7 +719,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	hipEventElapsedTime(&c->timing.tail_ms, c->ev_cls, c->ev[3]);           // waiting for the early launch, if it is still running
 	c->timing.n_early = c->n_early;
 	hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[3]);
-	HIPCHK(hipMemcpy(&c->p1, c->d_counters + 2, 8, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpyAsync(&c->p1, c->d_counters + 2, 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
 
 	c->timing.windows = c->total_windows; c->timing.probes_t1 = c->p1; c->timing.bases = c->total_bases;
 	return DSB_OK;
@@ -732,12 +733,13 @@ extern "C" int dsb_batch_fetch(dsb_ctx *c, dsb_result *out)
 	c->h_rout.resize(n); c->res_reads.resize(n);
 	unsigned int cnt[2] = {0, 0};
 	if (n) {
-		HIPCHK(hipMemcpy(cnt, c->d_counters, 8, hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(c->h_rout.data(), c->d_rout, n * sizeof(DsbReadOut), hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpyAsync(cnt, c->d_counters, 8, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipMemcpyAsync(c->h_rout.data(), c->d_rout, n * sizeof(DsbReadOut), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
 	}
 	size_t nh = cnt[1] < c->cap_hout ? cnt[1] : c->cap_hout;
 	c->h_hout.resize(nh);
-	if (nh) HIPCHK(hipMemcpy(c->h_hout.data(), c->d_hout, nh * sizeof(DsbHitOut), hipMemcpyDeviceToHost));
+	if (nh) { HIPCHK(hipMemcpyAsync(c->h_hout.data(), c->d_hout, nh * sizeof(DsbHitOut), hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
 	// pack hits in read order
 	c->res_hits.clear(); c->res_hits.reserve(nh);
 	int worst = DSB_OK;
