@@ -253,8 +253,17 @@ DV uint64_t d_hash64_2(uint64_t key)
 // ---- rank query, one 64-B line (reference: occ, src/bwt.c:43-65) ---------------------------
 DV uint64_t fm_occ(const DsbDevIndex *x, uint64_t r, uint32_t &c)
 {
+	// the index lives in global memory: say so (a generic pointer makes these FLAT loads, which also occupy the LDS queue)
+#ifdef DSB_HOST_EMU
 	const uint4 *bp = reinterpret_cast<const uint4 *>(x->fm + (r >> 7));
-	uint4 a0 = bp[0], a1 = bp[1], a2 = bp[2], a3 = bp[3];
+#else
+	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+	const __attribute__((address_space(1))) u32x4 *bp = (const __attribute__((address_space(1))) u32x4 *)(x->fm + (r >> 7));
+#endif
+	const auto b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+	uint4 a0, a1, a2, a3;
+	a0.x = b0.x; a0.y = b0.y; a0.z = b0.z; a0.w = b0.w; a1.x = b1.x; a1.y = b1.y; a1.z = b1.z; a1.w = b1.w;
+	a2.x = b2.x; a2.y = b2.y; a2.z = b2.z; a2.w = b2.w; a3.x = b3.x; a3.y = b3.y; a3.z = b3.z; a3.w = b3.w;
 	uint32_t off = (uint32_t)r & 127u;
 	uint64_t p0[2] = {((uint64_t)a1.y << 32) | a1.x, ((uint64_t)a1.w << 32) | a1.z};
 	uint64_t p1[2] = {((uint64_t)a2.y << 32) | a2.x, ((uint64_t)a2.w << 32) | a2.z};
@@ -281,20 +290,31 @@ DV uint64_t fm_occ(const DsbDevIndex *x, uint64_t r, uint32_t &c)
 
 // ---- get_ref (src/cly.c:435-466); small windows are fetched redundantly by every lane ------
 DV void get_ref_small(const uint8_t *txt, uint8_t *out, int64_t off, int32_t length, bool fwd)
-{
+{	// up to 24 bases per unaligned 8-byte load of the 2-bit text (4 KiB zero pad behind it), first base of a byte in its top bits
 	if (off < 0) off = 0;
 	if (length < 0) length = 0;
-	uint64_t o = (uint64_t)off >> 2; uint32_t odd = off & 3;
-	if (fwd)
-		for (uint32_t k = 0; k < (uint32_t)length; k++) {
-			out[k] = (txt[o] >> (6 - 2 * odd)) & 3;
-			if (odd == 3) { odd = 0; o++; } else odd++;
+	if (fwd) {
+		for (int32_t k0 = 0; k0 < length; k0 += 24) {
+			const uint64_t p = (uint64_t)off + (uint32_t)k0;
+			uint64_t raw; __builtin_memcpy(&raw, txt + (p >> 2), 8);
+			const uint64_t v = __builtin_bswap64(raw); const uint32_t s = (uint32_t)p & 3u;
+			const int32_t n = length - k0 < 24 ? length - k0 : 24;
+			for (int32_t k = 0; k < n; k++) out[k0 + k] = (uint8_t)((v >> (62 - 2 * (s + (uint32_t)k))) & 3u);
 		}
-	else
-		for (uint32_t k = 0; k < (uint32_t)length; k++) {
-			out[k] = (o == ~0ULL) ? 0 : (txt[o] >> (6 - 2 * odd)) & 3;
-			if (odd == 0) { odd = 3; o--; } else odd--;
+	} else {	// bases off, off-1, ...; positions before the text read as 0 (the reference's byte index wraps to ~0 there)
+		for (int32_t k0 = 0; k0 < length; k0 += 24) {
+			const int64_t hi = off - k0; const int32_t n = length - k0 < 24 ? length - k0 : 24;
+			const int64_t lo = hi - (n - 1) > 0 ? hi - (n - 1) : 0;
+			if (hi < 0) { for (int32_t k = 0; k < n; k++) out[k0 + k] = 0; continue; }
+			const uint64_t b0 = (uint64_t)lo >> 2;
+			uint64_t raw; __builtin_memcpy(&raw, txt + b0, 8);
+			const uint64_t v = __builtin_bswap64(raw);
+			for (int32_t k = 0; k < n; k++) {
+				const int64_t pos = hi - k;
+				out[k0 + k] = pos < 0 ? 0 : (uint8_t)((v >> (62 - 2 * (uint32_t)(pos - (int64_t)(b0 << 2)))) & 3u);
+			}
 		}
+	}
 }
 // forward window of any length, lanes split the bases; caller must wave_sync() before reading
 DV void get_ref_wave(const uint8_t *txt, int lane, uint8_t *out, int64_t off, int32_t length)
