@@ -1272,22 +1272,35 @@ DN void wtab_build(lds_u32 *tab, int lane, const uint8_t *q_str, uint32_t q_bg, 
 	const uint32_t slots = wtab_size(n_q);
 	for (uint32_t i = lane; i < slots; i += DSB_WAVE) tab[i] = DSB_WTAB_EMPTY;
 	wave_sync();
-	for (uint32_t r = lane; r < n_q; r += DSB_WAVE) {
-		const uint8_t *q = q_str + q_bg + r;
-		uint64_t v = ld_u64(q); uint32_t k = 0;
+	// four positions per lane per round: the loads of a round are issued before its first insert (the read bytes come
+	// from L2/HBM for the big windows of the right/left extensions)
+	for (uint32_t r0 = lane; r0 < n_q; r0 += 4 * DSB_WAVE) {
+		uint64_t v[4]; uint32_t t8[4];
 #pragma unroll
-		for (int b = 0; b < 8; b++) k = (k << 2) | (uint32_t)((v >> (8 * b)) & 0xffu);
-		k = (k << 2) | q[8];
-		uint32_t e = (k << 12) | r, sl = wtab_slot(k, slots);
-		for (;;) {
+		for (int u = 0; u < 4; u++) {
+			const uint32_t r = r0 + u * DSB_WAVE;
+			const uint8_t *q = q_str + q_bg + (r < n_q ? r : r0);
+			v[u] = ld_u64(q); t8[u] = q[8];
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const uint32_t r = r0 + u * DSB_WAVE;
+			if (r >= n_q) break;
+			uint32_t k = 0;
+#pragma unroll
+			for (int b = 0; b < 8; b++) k = (k << 2) | (uint32_t)((v[u] >> (8 * b)) & 0xffu);
+			k = (k << 2) | t8[u];
+			uint32_t e = (k << 12) | r, sl = wtab_slot(k, slots);
+			for (;;) {
 #ifdef DSB_HOST_EMU
-			uint32_t old = tab[sl]; if (old == DSB_WTAB_EMPTY) tab[sl] = e;
+				uint32_t old = tab[sl]; if (old == DSB_WTAB_EMPTY) tab[sl] = e;
 #else
-			uint32_t old = DSB_WTAB_EMPTY;
-			__hip_atomic_compare_exchange_strong(tab + sl, &old, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				uint32_t old = DSB_WTAB_EMPTY;
+				__hip_atomic_compare_exchange_strong(tab + sl, &old, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-			if (old == DSB_WTAB_EMPTY) break;
-			sl = sl + 1 == slots ? 0 : sl + 1;
+				if (old == DSB_WTAB_EMPTY) break;
+				sl = sl + 1 == slots ? 0 : sl + 1;
+			}
 		}
 	}
 	wave_sync();
