@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """CPU-only differential: the device code compiled for the host (tests/emu) against the oracle on the reads
 [lo, hi) of a FASTQ, history = running max of read lengths as in a single-threaded run.  TEST TOOL.
-    python tools/emu_diff.py <reads.fq> [lo hi]"""
+    python tests/tools/emu_diff.py <reads.fq> [lo hi]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
 import emu_lib, oracle_lib
 import desamba_amd as D

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Full-size drop-in check on a GPU box: the CLI of this repo against the reference's UB-pinned build
 # (oracle/_ref/deSAMBA_ubfree -t <cores>) on four synthetic workloads, byte for byte, with wall times.
-#   tools/full_parity.sh [outdir]
-cd "$(dirname "$0")/.."
+#   tests/tools/full_parity.sh [outdir]
+cd "$(dirname "$0")/../.."
 OUT=${1:-gpurun_out}; mkdir -p "$OUT"
 python -c "import __graft_entry__ as g; g.demo_dir()" > "$OUT/demo.log" 2>&1
 R=oracle/_ref/deSAMBA_ubfree; G=desamba_amd/bin/deSAMBA; I=data/demo/index; T=$(nproc)
