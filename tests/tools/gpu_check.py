@@ -1,6 +1,6 @@
 """GPU parity check: classify a FASTQ on the GPU and compare every hit with the CPU oracle."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import desamba_amd as D
 import oracle_lib as O
