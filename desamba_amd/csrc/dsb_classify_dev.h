@@ -250,6 +250,21 @@ DV uint64_t d_hash64_2(uint64_t key)
 	return key;
 }
 
+// Index data lives in global memory: typed loads (global_load instead of FLAT, which also occupies the LDS queue).
+#ifdef DSB_HOST_EMU
+#define DSB_G64(p, i) (((const uint64_t *)(p))[i])
+#define DSB_G32(p, i) (((const uint32_t *)(p))[i])
+static inline uint64_t dsb_g64u(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+static inline uint32_t dsb_g32u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+#else
+#define DSB_G64(p, i) (((const __attribute__((address_space(1))) uint64_t *)(p))[i])
+#define DSB_G32(p, i) (((const __attribute__((address_space(1))) uint32_t *)(p))[i])
+typedef uint64_t dsb_u64u __attribute__((aligned(1)));
+typedef uint32_t dsb_u32u __attribute__((aligned(1)));
+DV uint64_t dsb_g64u(const uint8_t *p) { return *(const __attribute__((address_space(1))) dsb_u64u *)p; }      // unaligned
+DV uint32_t dsb_g32u(const uint8_t *p) { return *(const __attribute__((address_space(1))) dsb_u32u *)p; }
+#endif
+
 // ---- rank query, one 64-B line (reference: occ, src/bwt.c:43-65) ---------------------------
 DV uint64_t fm_occ(const DsbDevIndex *x, uint64_t r, uint32_t &c)
 {
@@ -296,7 +311,7 @@ DV void get_ref_small(const uint8_t *txt, uint8_t *out, int64_t off, int32_t len
 	if (fwd) {
 		for (int32_t k0 = 0; k0 < length; k0 += 24) {
 			const uint64_t p = (uint64_t)off + (uint32_t)k0;
-			uint64_t raw; __builtin_memcpy(&raw, txt + (p >> 2), 8);
+			const uint64_t raw = dsb_g64u(txt + (p >> 2));
 			const uint64_t v = __builtin_bswap64(raw); const uint32_t s = (uint32_t)p & 3u;
 			const int32_t n = length - k0 < 24 ? length - k0 : 24;
 			for (int32_t k = 0; k < n; k++) out[k0 + k] = (uint8_t)((v >> (62 - 2 * (s + (uint32_t)k))) & 3u);
@@ -307,7 +322,7 @@ DV void get_ref_small(const uint8_t *txt, uint8_t *out, int64_t off, int32_t len
 			const int64_t lo = hi - (n - 1) > 0 ? hi - (n - 1) : 0;
 			if (hi < 0) { for (int32_t k = 0; k < n; k++) out[k0 + k] = 0; continue; }
 			const uint64_t b0 = (uint64_t)lo >> 2;
-			uint64_t raw; __builtin_memcpy(&raw, txt + b0, 8);
+			const uint64_t raw = dsb_g64u(txt + b0);
 			const uint64_t v = __builtin_bswap64(raw);
 			for (int32_t k = 0; k < n; k++) {
 				const int64_t pos = hi - k;
@@ -324,7 +339,7 @@ DV void get_ref_wave(const uint8_t *txt, int lane, uint8_t *out, int64_t off, in
 	if (length < 0) length = 0;
 	for (int32_t k = 8 * lane; k < length; k += 8 * DSB_WAVE) {
 		uint64_t p = (uint64_t)off + (uint32_t)k;
-		uint32_t raw; __builtin_memcpy(&raw, txt + (p >> 2), 4);
+		const uint32_t raw = dsb_g32u(txt + (p >> 2));
 		uint32_t v = __builtin_bswap32(raw), s = (uint32_t)p & 3u;
 		uint64_t o = 0;
 #pragma unroll
@@ -337,12 +352,12 @@ DV void get_ref_wave(const uint8_t *txt, int lane, uint8_t *out, int64_t off, in
 // get_uni (src/cly.c:471-496)
 DV int64_t get_uni(const DsbDevIndex *x, uint64_t bwt_pos, int search_l, uint64_t *global_offset, uint32_t *uni_offset_)
 {
-	uint2 sa = x->sa[bwt_pos >> 3];
-	int64_t u = sa.x;
-	uint32_t uni_offset = sa.y + search_l + 1;
+	const uint64_t sa_ = DSB_G64(x->sa, bwt_pos >> 3);                  // uint2 {x, y}
+	int64_t u = (uint32_t)sa_;
+	uint32_t uni_offset = (uint32_t)(sa_ >> 32) + search_l + 1;
 	if (search_l > 0)
-		for (;;) { uint32_t len = x->uni[u].y; if (!(uni_offset >= len)) break; uni_offset -= (len + 1); u++; }
-	uint64_t rp = x->refpos[x->uni[u].x];
+		for (;;) { uint32_t len = DSB_G32(x->uni, 2 * u + 1); if (!(uni_offset >= len)) break; uni_offset -= (len + 1); u++; }
+	uint64_t rp = DSB_G64(x->refpos, DSB_G32(x->uni, 2 * u));
 	*global_offset = (rp & 0xFFFFFFFFFFULL) + uni_offset;
 	*uni_offset_ = uni_offset;
 	return u;
@@ -434,7 +449,7 @@ DV void bwt_single_search(const DsbDevIndex *x, uint64_t sp, const uint8_t *stri
 DV int bwt_MEM_search(const DsbDevIndex *x, const uint8_t *string, uint64_t pre_v, int max_rst, int l_min_mth, int l_max_mth, SpSet &sp_set, DsbMem *mem)
 {
 	int n_rst = 0;
-	uint64_t sp = x->hash_index[pre_v], ep = x->hash_index[pre_v + 1], new_sp, new_ep;
+	uint64_t sp = DSB_G64(x->hash_index, pre_v), ep = DSB_G64(x->hash_index, pre_v + 1), new_sp, new_ep;
 	string -= 13; int match_len = 13; uint32_t ch;
 	while (1) {
 		ch = *string; string--;
@@ -561,7 +576,7 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 			else l_pre = s_l;
 		}
 		if (uni >= 0) {
-			if (x->uni[uni].y < 35) break;
+			if (DSB_G32(x->uni, 2 * uni + 1) < 35) break;
 			l_pre = MINV(l_pre, u_off);
 			get_ref_small(t_b, t_pre, t_off - 1, l_pre, false);
 		}
@@ -572,10 +587,10 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 		if (uni < 0) {
 			while (b_p & 7) { uint32_t ch = 0xff; uint64_t o = fm_occ(x, b_p, ch); b_p = o + x->rank[ch]; s_l++; }
 			uni = get_uni(x, b_p, s_l, &t_off, &u_off);
-			if (x->uni[uni].y < 35) { s = 0; break; }
+			if (DSB_G32(x->uni, 2 * uni + 1) < 35) { s = 0; break; }
 		}
 		int32_t q_off_r = q_off + l_m + 1;
-		uint32_t l_max_suf = MINV(x->uni[uni].y - u_off - l_m, read_L - q_off_r);
+		uint32_t l_max_suf = MINV(DSB_G32(x->uni, 2 * uni + 1) - u_off - l_m, read_L - q_off_r);
 		if (l_max_suf != 0) {
 			l_suf = MINV(l_max_suf, 12);
 			const uint8_t *q_suf = q_b + q_off_r;
@@ -602,11 +617,11 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 
 	if (s > 0) {
 		AMap a_m = {(uint16_t)l_m, (int16_t)s, (uint8_t)l_pre, (uint8_t)d_pre, (uint8_t)l_suf, (uint8_t)d_suf};
-		uint32_t rp_s = x->uni[uni].x, rp_e = x->uni[uni + 1].x;
+		uint32_t rp_s = DSB_G32(x->uni, 2 * uni), rp_e = DSB_G32(x->uni, 2 * uni + 2);
 		bool ref_search_l = (l_pre < 12 || d_pre == 0), ref_search_r = (l_suf < 12 || d_suf == 0);
 		if ((int64_t)rp_e - (int64_t)rp_s > 50) { if (!((int64_t)rp_e - (int64_t)rp_s < 1000)) return 50; }
 		for (uint32_t r = rp_s; r < rp_e; r++) {
-			uint64_t rp = x->refpos[r];
+			uint64_t rp = DSB_G64(x->refpos, r);
 			uint64_t rp_go = rp & 0xFFFFFFFFFFULL; uint32_t rp_ref = (uint32_t)(rp >> 40) & 0x7FFFFF;
 			uint32_t ed_l, ed_r, len_l, len_r, l_m_ext_l = 0, l_m_ext_r;
 			if (ref_search_l || ref_search_r) {
