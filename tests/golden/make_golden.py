@@ -29,6 +29,9 @@ def main():
         run([sim, idx, fq, str(n), str(L), str(e), str(seed), prof])
         run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx, fq, "-o", os.path.join(OUT, name + ".ubfree.sam")])
         run([os.path.join(REF, "deSAMBA"), "classify", "-t", "1", idx, fq, "-o", os.path.join(OUT, name + ".stock.sam")])
+    # non-default output format and options (src/cly_mt.c:448-562)
+    run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", "-f", "SAM_FULL", idx, os.path.join(OUT, "ngs150.fq"), "-o", os.path.join(OUT, "ngs150.full.ubfree.sam")])
+    run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", "-l", "100", "-s", "30", "-r", "2", idx, os.path.join(OUT, "pb.fq"), "-o", os.path.join(OUT, "pb.l100s30r2.ubfree.sam")])
     # the two heaviest reads of the 2000-read ONT set (tools/readsim seed 1, reads 1476 and 9): a tandem-repeat
     # region where one reference 9-mer matches dozens of read positions -> thousands of sparse-DP nodes
     heavy = os.path.join(OUT, "heavy.fq")

@@ -138,6 +138,18 @@ def test_cli_drop_in(gpu, demo, golden_md5, tmp_path):
     assert hashlib.md5(open(out, "rb").read()).hexdigest() == golden_md5
 
 
+@pytest.mark.parametrize("args,fq,exp", [(["-f", "SAM_FULL"], "ngs150.fq", "ngs150.full.ubfree.sam"),
+                                         (["-l", "100", "-s", "30", "-r", "2"], "pb.fq", "pb.l100s30r2.ubfree.sam")])
+def test_cli_options(gpu, tmp_path, args, fq, exp):
+    """SAM_FULL (SEQ and QUAL columns) and non-default -l/-s/-r, against the reference's output for the same command line"""
+    import subprocess
+    from conftest import ROOT as R
+    out = tmp_path / "out.sam"
+    subprocess.check_call([os.path.join(R, "desamba_amd", "bin", "deSAMBA"), "classify"] + args +
+                          [os.path.join(R, "data", "demo", "index"), os.path.join(GOLDEN, "synth", fq), "-o", str(out)], stderr=subprocess.DEVNULL)
+    assert out.read_bytes() == open(os.path.join(GOLDEN, "synth", exp), "rb").read()
+
+
 def test_cli_many_batches_files_and_gzip(gpu, tmp_path, monkeypatch):
     """the CLI pipeline with buffers of 256 KB (dozens of batches alternating between the two device contexts, records
     carried over buffer ends), several input files (history restarts per file) and gzip input"""
