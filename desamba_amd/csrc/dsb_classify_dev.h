@@ -657,11 +657,11 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 // src/cly.c:1071-1234).  The probe kernel has answered get_exist_kmer for every window.
 // The scan runs on one lane; a word read back through readfirstlane is a scalar, and so is everything computed
 // from it: the scan's arithmetic and branches then go to the scalar unit instead of one-lane vector instructions.
-DV uint64_t sbits(const uint64_t *bits, uint32_t w) { uint64_t v = bits[w]; return DSB_RFL64(v); }
-DV int ebit(const uint64_t *bits, uint32_t i) { return (int)((sbits(bits, i >> 6) >> (i & 63)) & 1ULL); }
+template <class BP> DV uint64_t sbits(BP bits, uint32_t w) { uint64_t v = bits[w]; return DSB_RFL64(v); }
+template <class BP> DV int ebit(BP bits, uint32_t i) { return (int)((sbits(bits, i >> 6) >> (i & 63)) & 1ULL); }
 
 // number of consecutive set bits at positions start, start+1, ... (< n), at most maxc
-DV uint32_t run_ones_up(const uint64_t *bits, uint32_t n, uint32_t start, uint32_t maxc)
+template <class BP> DV uint32_t run_ones_up(BP bits, uint32_t n, uint32_t start, uint32_t maxc)
 {
 	uint32_t c = 0;
 	while (c < maxc && start < n) {
@@ -677,7 +677,7 @@ DV uint32_t run_ones_up(const uint64_t *bits, uint32_t n, uint32_t start, uint32
 	return c;
 }
 // consecutive set bits at positions start, start-1, ... (>= 0), at most maxc
-DV uint32_t run_ones_down(const uint64_t *bits, int start, uint32_t maxc)
+template <class BP> DV uint32_t run_ones_down(BP bits, int start, uint32_t maxc)
 {
 	uint32_t c = 0;
 	while (c < maxc && start >= 0) {
@@ -693,11 +693,19 @@ DV uint32_t run_ones_down(const uint64_t *bits, int start, uint32_t maxc)
 }
 #define DSB_M3 0x9249249249249249ULL      /* bits 0,3,6,...,63 */
 
-DN void seed_vector_scan(const uint64_t *bits_, uint32_t n_, DsbSeed *sv_, uint32_t direction_, uint32_t *ns_out, uint32_t *total_out)
+// BP: where the hit-bit words are read from -- a generic pointer (global memory), or LDS (the usual case: staged by
+// seed_vector; ds_read instead of FLAT loads on the scan's critical path)
+#ifdef DSB_HOST_EMU
+typedef const uint64_t *lds_bits_p;
+#else
+typedef const __attribute__((address_space(3))) uint64_t *lds_bits_p;
+#endif
+template <class BP>
+DN void seed_vector_scan(BP bits_, uint32_t n_, DsbSeed *sv_, uint32_t direction_, uint32_t *ns_out, uint32_t *total_out)
 {
 	// arguments of a non-inlined function arrive in vector registers and count as divergent: make them scalars
 	// (one lane runs this) so that the scan below compiles to scalar instructions and branches
-	const uint64_t *bits = (const uint64_t *)DSB_RFL64((uint64_t)bits_); DsbSeed *sv = (DsbSeed *)DSB_RFL64((uint64_t)sv_);
+	const BP bits = (BP)(uintptr_t)DSB_RFL64((uint64_t)(uintptr_t)bits_); DsbSeed *sv = (DsbSeed *)DSB_RFL64((uint64_t)sv_);
 	const uint32_t n = DSB_RFL(n_), direction = DSB_RFL(direction_);
 	// Same scan as search_exist_kmer_M2 (probe every 3rd window, extend back <= 2, forward to len 61,
 	// resume 3 past the seed), but 64 windows per load: the next probe hit is a ctz over the word
@@ -755,15 +763,15 @@ DV void seed_vector(WCtx &w, uint8_t *bin, const uint64_t *bits, uint32_t n, Dsb
 	uint32_t ns = 0, total = 0;
 	// the scan is a chain of dependent loads of the hit-bit words: stage them in LDS (the window table is idle
 	// here) when the strand fits
-	const uint64_t *src = bits; const uint32_t n_words = (n + 63) >> 6;
+	const uint32_t n_words = (n + 63) >> 6;
 	if (w.wtab && n_words + 1 <= DSB_WTAB_SLOTS / 2) {
 		uint64_t *l = reinterpret_cast<uint64_t *>(w.wtab);
 		for (uint32_t i = w.lane; i < n_words; i += DSB_WAVE) l[i] = bits[i];
 		if (w.lane == 0) l[n_words] = 0;
 		wave_sync();
-		src = l;
-	}
-	DSB_SERIAL(w) seed_vector_scan(src, n, sv, direction, &ns, &total);
+		DSB_SERIAL(w) seed_vector_scan<lds_bits_p>((lds_bits_p)l, n, sv, direction, &ns, &total);
+	} else
+		DSB_SERIAL(w) seed_vector_scan<const uint64_t *>(bits, n, sv, direction, &ns, &total);
 	ns = dsb_shfl(ns, 0); total = dsb_shfl(total, 0);
 	wave_sync();
 	out->seed_v = sv; out->l_seed_v = ns; out->bin_read = bin; out->bits = bits; out->direction = direction; out->total_score = total;
