@@ -191,10 +191,17 @@ typedef uint32_t lds_u32;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 #endif
 
+// the index descriptor lives in LDS (k_classify copies its kernel argument there): typed so that x->field is a ds_read
+#ifdef DSB_HOST_EMU
+typedef const DsbDevIndex *DsbXP;
+#else
+typedef const __attribute__((address_space(3))) DsbDevIndex *DsbXP;
+#endif
+
 struct SDir { DsbSeed *seed_v; uint32_t l_seed_v; uint8_t *bin_read; const uint64_t *bits; uint32_t direction, total_score; };
 
 struct WCtx {
-	const DsbDevIndex *x;
+	DsbXP x;
 	int lane;
 	uint8_t *bin; uint32_t L;
 	DsbSeed *seeds;
@@ -266,7 +273,7 @@ DV uint32_t dsb_g32u(const uint8_t *p) { return *(const __attribute__((address_s
 #endif
 
 // ---- rank query, one 64-B line (reference: occ, src/bwt.c:43-65) ---------------------------
-DV uint64_t fm_occ(const DsbDevIndex *x, uint64_t r, uint32_t &c)
+DV uint64_t fm_occ(DsbXP x, uint64_t r, uint32_t &c)
 {
 	// the index lives in global memory: say so (a generic pointer makes these FLAT loads, which also occupy the LDS queue)
 #ifdef DSB_HOST_EMU
@@ -350,7 +357,7 @@ DV void get_ref_wave(const uint8_t *txt, int lane, uint8_t *out, int64_t off, in
 }
 
 // get_uni (src/cly.c:471-496)
-DV int64_t get_uni(const DsbDevIndex *x, uint64_t bwt_pos, int search_l, uint64_t *global_offset, uint32_t *uni_offset_)
+DV int64_t get_uni(DsbXP x, uint64_t bwt_pos, int search_l, uint64_t *global_offset, uint32_t *uni_offset_)
 {
 	const uint64_t sa_ = DSB_G64(x->sa, bwt_pos >> 3);                  // uint2 {x, y}
 	int64_t u = (uint32_t)sa_;
@@ -430,7 +437,7 @@ DV int sp_set_insert(uint64_t node, SpSet &s)
 	}
 }
 
-DV void bwt_single_search(const DsbDevIndex *x, uint64_t sp, const uint8_t *string, int max_match_len, SpSet &sp_set, DsbMem &m)
+DV void bwt_single_search(DsbXP x, uint64_t sp, const uint8_t *string, int max_match_len, SpSet &sp_set, DsbMem &m)
 {
 	uint64_t new_sp, sa_sp = D_U64MAX; int match_len = 0, sa_sp_l = 0;
 	while (1) {
@@ -446,7 +453,7 @@ DV void bwt_single_search(const DsbDevIndex *x, uint64_t sp, const uint8_t *stri
 	m.sp = sp; m.match_len = match_len; m.sa_sp = sa_sp; m.sa_sp_l = sa_sp_l;
 }
 
-DV int bwt_MEM_search(const DsbDevIndex *x, const uint8_t *string, uint64_t pre_v, int max_rst, int l_min_mth, int l_max_mth, SpSet &sp_set, DsbMem *mem)
+DV int bwt_MEM_search(DsbXP x, const uint8_t *string, uint64_t pre_v, int max_rst, int l_min_mth, int l_max_mth, SpSet &sp_set, DsbMem *mem)
 {
 	int n_rst = 0;
 	uint64_t sp = DSB_G64(x->hash_index, pre_v), ep = DSB_G64(x->hash_index, pre_v + 1), new_sp, new_ep;
@@ -503,7 +510,7 @@ DV void lvbuf_init(LvBuf &v, uint8_t pad) {
 // get_new_ed (src/cly.c:629-694).  The right-side query is copied out of the read (with its
 // preceding byte) so that lv_extd works on local strings only; the reference's in-place
 // sentinel write is restored before it returns, so this is equivalent.
-DV void get_new_ed(const DsbDevIndex *x, uint32_t *e_d, uint32_t *len_, uint32_t *l_mem_ext,
+DV void get_new_ed(DsbXP x, uint32_t *e_d, uint32_t *len_, uint32_t *l_mem_ext,
                    int32_t q_off, uint64_t t_off, uint32_t l_read, const uint8_t *q_b, bool is_FWD)
 {
 	LvBuf qb, tb; lvbuf_init(qb, LVPAD_Q); lvbuf_init(tb, LVPAD_T);
@@ -548,7 +555,7 @@ DV DsbAnchor *push_anchor(WCtx &w)
 // map_seed (src/cly.c:706-939)
 DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, uint16_t seed_ID, uint8_t direction)
 {
-	const DsbDevIndex *x = w.x;
+	DsbXP x = w.x;
 	uint64_t b_p = m_r.sp; int32_t q_off = m_r.read_offset; uint32_t l_m = m_r.match_len;
 	const uint8_t *t_b = x->refbin;
 	int64_t uni = -1; uint32_t u_off = 0; uint64_t t_off = 0;
@@ -782,7 +789,7 @@ DV void seed_vector(WCtx &w, uint8_t *bin, const uint64_t *bits, uint32_t n, Dsb
 // Returns 1 when the reference would also skip the following seed (max_score > 512, src/cly.c:1530-1531).
 DV int fast_island(WCtx &w, SDir *s_d, uint32_t read_len, uint32_t seed_idx)
 {
-	const DsbDevIndex *x = w.x;
+	DsbXP x = w.x;
 	int l_ek = x->ek_len, min_index = 21 - l_ek;
 	uint8_t *bin_read = s_d->bin_read;
 	SpSet sp_set = {w.spset, 0, DSB_SPSET_CAP, &w.sp_gen};
@@ -938,7 +945,7 @@ DV void sort_mems(DsbMem *m, int n)
 // slow_classify (src/cly.c:1550-1611)
 DN void slow_classify(WCtx &w, SDir *sd, uint32_t read_len)
 {
-	const DsbDevIndex *x = w.x;
+	DsbXP x = w.x;
 	int l_ek = x->ek_len; uint8_t *bin_read = sd->bin_read; DsbSeed *sv_f = sd->seed_v;
 	SpSet sp_set = {w.spset, 0, DSB_SPSET_CAP, &w.sp_gen};
 	DsbMem *mem_rst = w.mem_slow; int mem_rst_num;
@@ -1776,7 +1783,7 @@ DV void fill_window(const WCtx &w, uint8_t *win, int n)
 // sdp_middle_M2 (src/cly.c:2444-2530)
 DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int key_len)
 {
-	const DsbDevIndex *x = w.x;
+	DsbXP x = w.x;
 	int score = 10000;
 	// the context lives in memory: work on copies (see sdp_match_t)
 	const DsbAnchor *A = w.anc; DsbSms *const S = w.sms; uint32_t *const wtab = w.wtab; uint8_t *const win = w.win_mid;
@@ -1875,7 +1882,7 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 // sdp_right_M2 (src/cly.c:2532-2677)
 DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain *c_st, int chain_ID, uint32_t l_read, DsbScHash *sc_hash, int score_ori)
 {
-	const DsbDevIndex *x = w.x;
+	DsbXP x = w.x;
 	score_ori += 10000;
 	int total_max_score = score_ori, max_sms_id = 0;
 	DsbChain *c_h = c_st + chain_ID, *combined;
@@ -1953,7 +1960,7 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 // sdp_left_M2 (src/cly.c:2679-2819)
 DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain *c_st, int chain_ID, uint32_t l_read, DsbScHash *sc_hash, int score_ori)
 {
-	const DsbDevIndex *x = w.x;
+	DsbXP x = w.x;
 	score_ori += 10000;
 	int total_max_score = score_ori, max_sms_id = 0;
 	DsbChain *c_h = c_st + chain_ID, *combined;
@@ -2058,7 +2065,7 @@ DN void get_score_M2(WCtx &w, SDir *sd, uint32_t l_read, DsbScHash *sc_hash)
 // delete_small_score_rst (src/cly.c:2883-2993)
 DN void delete_small_score_rst(WCtx &w, SDir *sd, uint32_t l_read)
 {
-	const DsbDevIndex *x = w.x;
+	DsbXP x = w.x;
 	if (w.n_hit == 0) return;
 	DSB_SERIAL(w) {
 		if (w.n_hit > 200) {

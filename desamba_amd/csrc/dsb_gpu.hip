@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	__syncthreads();                                                                                                    \
 	NS::WCtx w;                                                                                                         \
 	w.ring = lds_ring; w.red = lds_red;                                                                                 \
-	w.x = &sx; w.lane = lane; w.dbg = dbg ? dbg + 4 * slot_id : nullptr;                                             \
+	w.x = (NS::DsbXP)&sx; w.lane = lane; w.dbg = dbg ? dbg + 4 * slot_id : nullptr;                                             \
 	for (int i = 0; i < 14; i++) w.tacc[i] = 0;                                                                         \
 	w.seeds = (DsbSeed *)(slot + ar.off_seeds);                                                                         \
 	w.anc = (DsbAnchor *)(slot + ar.off_anc); w.anc_tmp = (DsbAnchor *)(slot + ar.off_anc_tmp);                         \
@@ -789,7 +789,7 @@ __global__ void __launch_bounds__(64) k_seed_dump(DsbDevIndex x, DsbReadDesc d, 
 	__shared__ DsbDevIndex sx;
 	if (threadIdx.x == 0) sx = x;
 	__syncthreads();
-	dsb_g64::WCtx w; w.x = &sx; w.lane = threadIdx.x; w.L = d.len; w.status = 0; w.dbg = nullptr; w.anc_cap = 0; w.wtab = nullptr;
+	dsb_g64::WCtx w; w.x = (dsb_g64::DsbXP)&sx; w.lane = threadIdx.x; w.L = d.len; w.status = 0; w.dbg = nullptr; w.anc_cap = 0; w.wtab = nullptr;
 	dsb_g64::SDir sd;
 	uint32_t n = d.len - x.ek_len + 1;
 	if (strand) dsb_g64::seed_vector(w, bin + d.bin_off + DSB_QPAD_L, bits + d.bit_off, n, out, D_FORWARD, &sd);
