@@ -1293,11 +1293,22 @@ DV uint64_t ld_u64(const uint8_t *p)
 	__builtin_memcpy(&v, p, 8);
 	return v;
 }
+// the byte windows of the sparse matching are either in global memory (generic pointers) or staged in LDS; the code
+// below is instantiated for both so that the staged case compiles to ds_read
+typedef const uint8_t *gp8;
+#ifdef DSB_HOST_EMU
+typedef const uint8_t *lp8;
+#else
+typedef const __attribute__((address_space(3))) uint8_t *lp8;
+typedef uint64_t dsb_lds_u64u __attribute__((aligned(1)));
+DV uint64_t ld_u64(lp8 p) { return *(const __attribute__((address_space(3))) dsb_lds_u64u *)p; }
+#endif
 DV uint32_t wtab_slot(uint32_t kmer, uint32_t slots) { return (uint32_t)(((uint64_t)(kmer * 2654435761u) * slots) >> 32); }
 // slots used for a window of n_q positions: load factor <= 0.5 for small windows, the whole table for big ones
 DV uint32_t wtab_size(uint32_t n_q) { uint32_t s = 2 * n_q; return s < 64u ? 64u : (s > DSB_WTAB_SLOTS ? DSB_WTAB_SLOTS : s); }
 
-DN void wtab_build(lds_u32 *tab, int lane, const uint8_t *q_str, uint32_t q_bg, uint32_t n_q)
+template <class P8>
+DN void wtab_build(lds_u32 *tab, int lane, P8 q_str, uint32_t q_bg, uint32_t n_q)
 {
 	const uint32_t slots = wtab_size(n_q);
 	for (uint32_t i = lane; i < slots; i += DSB_WAVE) tab[i] = DSB_WTAB_EMPTY;
@@ -1309,7 +1320,7 @@ DN void wtab_build(lds_u32 *tab, int lane, const uint8_t *q_str, uint32_t q_bg, 
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
 			const uint32_t r = r0 + u * DSB_WAVE;
-			const uint8_t *q = q_str + q_bg + (r < n_q ? r : r0);
+			P8 q = q_str + q_bg + (r < n_q ? r : r0);
 			v[u] = ld_u64(q); t8[u] = q[8];
 		}
 #pragma unroll
@@ -1339,7 +1350,8 @@ DN void wtab_build(lds_u32 *tab, int lane, const uint8_t *q_str, uint32_t q_bg, 
 // MEM_search (src/cly.c:1810-1818): length of the exact match, at most max, walking forward from (q,t)
 // or backward.  Eight bases per step; every buffer it is used on has >= 8 readable bytes past the
 // compared range on either side (pads), and bytes beyond `max` are ignored.
-DV int MEM_search(const uint8_t *q, const uint8_t *t, bool forward, int max)
+template <class P8>
+DV int MEM_search(P8 q, P8 t, bool forward, int max)
 {
 	int len = 0;
 	if (forward) {
@@ -1379,19 +1391,21 @@ DV uint64_t bin2kmer9(const uint8_t *s) { uint64_t v = 0;
 #define DSB_SDP_KEEP 3
 #define DSB_DP_UNROLL 4
 #define DSB_RING 16      /* recent DP nodes kept in LDS: the in-batch predecessors of the batched DP */
-struct SdpArgs { uint32_t q_bg, q_ed; const uint8_t *q_str, *t_str; uint32_t t_len, t_st; const lds_u32 *tab; uint32_t n_q; uint32_t *bm; uint4 *lnodes; };
+// q_str is addressed as q_base + (pos - q_lo): the staged copy starts at read position q_lo (no out-of-object pointers)
+template <class P8> struct SdpArgsT { uint32_t q_bg, q_ed; P8 q_base, t_str; int32_t q_lo; uint32_t t_len, t_st; const lds_u32 *tab; uint32_t n_q; uint32_t *bm; uint4 *lnodes; };
+#define AQ(a, pos) ((a).q_base + ((int32_t)(pos) - (a).q_lo))
 
 // one window position q_pos holding the 9-mer of reference position i: the two exact-match extensions and,
 // if the match qualifies, the node (src/cly.c:2390-2436)
-template <bool FWD, bool WRITE>
-DV void sdp_emit(const SdpArgs &a, int i, const uint8_t *c_t, uint32_t q_pos, DsbSms *out, uint32_t out_cap, uint32_t &cnt)
+template <bool FWD, bool WRITE, class P8>
+DV void sdp_emit(const SdpArgsT<P8> &a, int i, P8 c_t, uint32_t q_pos, DsbSms *out, uint32_t out_cap, uint32_t &cnt)
 {
 	if (FWD) {
-		int back_len = MEM_search(a.q_str + q_pos - 1, c_t - 1, false, 4);
+		int back_len = MEM_search<P8>(AQ(a, q_pos - 1), c_t - 1, false, 4);
 		if (back_len < 4 || i == 4) {
 			uint32_t max_search = a.q_ed - q_pos - 1;
 			max_search = MINV(max_search, a.t_len - i - 1) + 50;
-			int fwd = MEM_search(a.q_str + q_pos + 9, c_t + 9, true, max_search);
+			int fwd = MEM_search<P8>(AQ(a, q_pos + 9), c_t + 9, true, max_search);
 			int total = back_len + fwd + 1;
 			if (total >= 4) {
 				if (WRITE && cnt < out_cap) { DsbSms *p = out + cnt; p->len = total; p->q_pos = q_pos - back_len; p->t_pos = i - back_len + a.t_st; }
@@ -1399,11 +1413,11 @@ DV void sdp_emit(const SdpArgs &a, int i, const uint8_t *c_t, uint32_t q_pos, Ds
 			}
 		}
 	} else {
-		int fwd = MEM_search(a.q_str + q_pos + 9, c_t + 9, true, 4);
+		int fwd = MEM_search<P8>(AQ(a, q_pos + 9), c_t + 9, true, 4);
 		if (fwd < 4 || i == 4) {
 			uint32_t max_search = q_pos;
 			max_search = MINV((long)max_search, (long)(c_t - a.t_str)) + 50;
-			int back_len = MEM_search(a.q_str + q_pos - 1, c_t - 1, false, max_search);
+			int back_len = MEM_search<P8>(AQ(a, q_pos - 1), c_t - 1, false, max_search);
 			int total = back_len + fwd + 1;
 			if (total >= 4) {
 				if (WRITE && cnt < out_cap) { DsbSms *p = out + cnt; p->len = total; p->q_pos = q_pos - back_len; p->t_pos = (uint32_t)((long)(c_t - a.t_str) - back_len + a.t_st); }
@@ -1412,11 +1426,11 @@ DV void sdp_emit(const SdpArgs &a, int i, const uint8_t *c_t, uint32_t q_pos, Ds
 		}
 	}
 }
-template <bool FWD, bool WRITE>
-DV uint32_t sdp_visit(uint32_t &lsteps, int &st, const SdpArgs &a, int i, DsbSms *out, uint32_t out_cap)
+template <bool FWD, bool WRITE, class P8>
+DV uint32_t sdp_visit(uint32_t &lsteps, int &st, const SdpArgsT<P8> &a, int i, DsbSms *out, uint32_t out_cap)
 {
 	uint32_t cnt = 0;
-	const uint8_t *c_t; uint64_t kmer = 0;
+	P8 c_t; uint64_t kmer = 0;
 	if (FWD) {
 		c_t = a.t_str + i;
 		uint64_t v = ld_u64(c_t);
@@ -1460,16 +1474,16 @@ DV uint32_t sdp_visit(uint32_t &lsteps, int &st, const SdpArgs &a, int i, DsbSms
 		}
 		for (uint32_t w_ = 0; w_ < nbw; w_++)
 			for (uint32_t cur = bm[w_ * DSB_WAVE]; cur; cur &= cur - 1)
-				sdp_emit<FWD, WRITE>(a, i, c_t, a.q_bg + 32 * w_ + (uint32_t)__builtin_ctz(cur), out, out_cap, cnt);
+				sdp_emit<FWD, WRITE, P8>(a, i, c_t, a.q_bg + 32 * w_ + (uint32_t)__builtin_ctz(cur), out, out_cap, cnt);
 		return cnt;
 	}
 	for (int u = 1; u < nc; u++) { uint32_t v = cand[u]; int z = u - 1; while (z >= 0 && cand[z] > v) { cand[z + 1] = cand[z]; z--; } cand[z + 1] = v; }
-	for (int ci = 0; ci < nc; ci++) sdp_emit<FWD, WRITE>(a, i, c_t, cand[ci], out, out_cap, cnt);
+	for (int ci = 0; ci < nc; ci++) sdp_emit<FWD, WRITE, P8>(a, i, c_t, cand[ci], out, out_cap, cnt);
 	return cnt;
 }
 
-template <bool FWD>
-DN uint32_t sdp_match_t(WCtx &w, const SdpArgs a, uint32_t n_sms)
+template <bool FWD, class P8>
+DN uint32_t sdp_match_t(WCtx &w, const SdpArgsT<P8> a, uint32_t n_sms)
 {
 	uint32_t t_kmer_num = a.t_len - 9 + 1;
 	if (t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return n_sms; // the reference's loop does not run either (t_len >= 13 at every call site)
@@ -1480,7 +1494,7 @@ DN uint32_t sdp_match_t(WCtx &w, const SdpArgs a, uint32_t n_sms)
 	for (uint32_t g = 0; g < n_pos; g += DSB_WAVE) {
 		uint32_t pI = g + lane; bool valid = pI < n_pos; int i = 4 + 4 * (int)pI;
 		DsbSms keep[DSB_SDP_KEEP];
-		uint32_t cnt = valid ? sdp_visit<FWD, true>(lsteps, st, a, i, keep, DSB_SDP_KEEP) : 0;
+		uint32_t cnt = valid ? sdp_visit<FWD, true, P8>(lsteps, st, a, i, keep, DSB_SDP_KEEP) : 0;
 		uint32_t total, off = grp_excl_scan_u(red, lane, cnt, &total);
 		if (total == 0) continue;
 		if (n_sms + total > DSB_SMS_CAP) { st |= DSB_ST_SMS_OVF; break; }
@@ -1491,7 +1505,7 @@ DN uint32_t sdp_match_t(WCtx &w, const SdpArgs a, uint32_t n_sms)
 				// the first 64 nodes of the list are mirrored in LDS for the in-register DP of sdp_middle_M2
 				if (a.lnodes && n_sms + off + k < 64u) { uint4 r; r.x = keep[k].t_pos; r.y = keep[k].q_pos; r.z = keep[k].len; r.w = 0; a.lnodes[n_sms + off + k] = r; }
 			}
-		} else sdp_visit<FWD, true>(lsteps, st, a, i, dst, 0xffffffffu);
+		} else sdp_visit<FWD, true, P8>(lsteps, st, a, i, dst, 0xffffffffu);
 		if (a.lnodes && dsb_ballot64(cnt > DSB_SDP_KEEP)) mirror_bad = 0x80000000u;
 		n_sms += total;
 		wave_sync();
@@ -1509,16 +1523,29 @@ DV uint32_t sdp_nq(uint32_t L, uint32_t q_bg, uint32_t q_ed)
 }
 
 // appends the nodes to w.sms[n_sms...] and returns the new count (w.n_sms is not touched)
-DN uint32_t sdp_match_n(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len,
-                        uint32_t t_st, bool isForward, uint4 *lnodes)
+template <class P8>
+DV uint32_t sdp_match_p(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, P8 q_base, int32_t q_lo, P8 t_str, uint32_t t_len, uint32_t t_st, bool isForward, uint4 *lnodes)
 {
-	SdpArgs a; a.lnodes = lnodes; a.q_bg = q_bg; a.q_ed = q_ed; a.q_str = q_str; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st; a.tab = (const lds_u32 *)w.wtab; a.bm = reinterpret_cast<uint32_t *>(w.sortkey) + w.lane;
+	SdpArgsT<P8> a; a.lnodes = lnodes; a.q_bg = q_bg; a.q_ed = q_ed; a.q_base = q_base; a.q_lo = q_lo; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st;
+	a.tab = (const lds_u32 *)w.wtab; a.bm = reinterpret_cast<uint32_t *>(w.sortkey) + w.lane;
 	a.n_q = sdp_nq(w.L, q_bg, q_ed);
 	if (a.n_q > DSB_WTAB_MAXQ) { w.status |= DSB_ST_SMS_OVF; return n_sms; }     // cannot happen: windows are <= 2001 wide
 	uint32_t t_kmer_num = t_len - 9 + 1;
 	if (a.n_q == 0 || t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return n_sms;
-	wtab_build((lds_u32 *)w.wtab, w.lane, q_str, q_bg, a.n_q);
-	return isForward ? sdp_match_t<true>(w, a, n_sms) : sdp_match_t<false>(w, a, n_sms);
+	wtab_build<P8>((lds_u32 *)w.wtab, w.lane, q_base + ((int32_t)q_bg - q_lo), 0u, a.n_q);
+	return isForward ? sdp_match_t<true, P8>(w, a, n_sms) : sdp_match_t<false, P8>(w, a, n_sms);
+}
+// windows in global memory (q_str = the read strand) ...
+DN uint32_t sdp_match_n(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len,
+                        uint32_t t_st, bool isForward, uint4 *lnodes)
+{
+	return sdp_match_p<gp8>(w, n_sms, q_bg, q_ed, q_str, 0, t_str, t_len, t_st, isForward, lnodes);
+}
+// ... or staged in LDS by sdp_middle_M2: lq holds the read from position q_lo on, lt the reference window
+DN uint32_t sdp_match_lds(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *lq, int32_t q_lo, const uint8_t *lt, uint32_t t_len,
+                          uint32_t t_st, uint4 *lnodes)
+{
+	return sdp_match_p<lp8>(w, n_sms, q_bg, q_ed, (lp8)lq, q_lo, (lp8)lt, t_len, t_st, true, lnodes);
 }
 DV void sdp_match(WCtx &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len, int key_len,
                   int tbl, uint32_t t_st, bool isForward)
@@ -1809,7 +1836,7 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 			if (total_ref_len >= 2000) { w.status |= DSB_ST_TIMEOUT; w.n_sms = 0; return 0; }   // the reference aborts here (xassert, src/cly.c:2473)
 			uint64_t ref_offset = pre_refoffset + t_offset + pre_mch;
 			const uint32_t q_bg = pa.index_in_read + pre_mch - 8, q_ed = ca.index_in_read - 1;
-			const uint8_t *qs = q_str;
+			const uint8_t *qs = q_str; const uint8_t *lq_st = nullptr;
 			// Small gap (the usual case): the reference window and the stretch of the read the match can touch live
 			// in LDS behind the window's hash table, so the k-mer builds and exact-match extensions of sdp_match
 			// are LDS reads instead of global round trips.  Forward matching reads q in [q_bg - 8, q_ed + 66].
@@ -1820,12 +1847,13 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 				uint8_t *lq = reinterpret_cast<uint8_t *>(wtab + slots), *lt = lq + q_bytes + 8;
 				lnodes = reinterpret_cast<uint4 *>(lt + t_bytes + (((4 * slots + q_bytes + t_bytes) & 8u) ? 0 : 8));   // 16-byte aligned: the table starts 16-aligned
 				for (uint32_t k = 8 * lane; k < q_bytes; k += 8 * DSB_WAVE) *reinterpret_cast<uint64_t *>(lq + k) = ld_u64(q_str + q_lo + (int32_t)k);
-				ref = lt; qs = lq - q_lo;
+				ref = lt; qs = nullptr; lq_st = lq;
 			}
 			get_ref_wave(x->refbin, lane, ref, ref_offset, total_ref_len);
 			for (int k = total_ref_len + lane; k < total_ref_len + 64; k += DSB_WAVE) ref[k] = DSB_TPAD_VAL;   // reads reach <= 58 past the window
 			wave_sync();
-			n_sms = sdp_match_n(w, n_sms, q_bg, q_ed, qs, ref, total_ref_len, pre_refoffset + pre_mch, true, lnodes);
+			n_sms = lq_st ? sdp_match_lds(w, n_sms, q_bg, q_ed, lq_st, q_lo, ref, total_ref_len, pre_refoffset + pre_mch, lnodes)
+			              : sdp_match_n(w, n_sms, q_bg, q_ed, qs, ref, total_ref_len, pre_refoffset + pre_mch, true, lnodes);
 			mirror = lnodes != nullptr && !(n_sms >> 31); n_sms &= 0x7fffffffu;
 		}
 		n_sms++;                                                     // the last node
