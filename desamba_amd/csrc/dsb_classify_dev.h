@@ -489,10 +489,14 @@ DV int bwt_MEM_search(DsbXP x, const uint8_t *string, uint64_t pre_v, int max_rs
 // 13-base prefix value of the k-mer window ending at string_index (= kmer[kmer_index] & PRE_IDX_MASK,
 // src/cly.c:1504; the windows used are always inside an island, so the k-mer is never filtered)
 DV uint64_t prefix13(const uint8_t *bin, int string_index)
-{
+{	// v = bases [si-12, si], first base in the top bits: two unaligned 8-byte loads of the byte strand (global memory)
+	// instead of 13 byte loads; every byte is a base 0..3 here
+	const uint64_t a = dsb_g64u(bin + string_index - 12), b = dsb_g64u(bin + string_index - 4);
 	uint64_t v = 0;
 #pragma unroll
-	for (int i = 12; i >= 0; i--) v = (v << 2) | bin[string_index - i];
+	for (int i = 0; i < 8; i++) v = (v << 2) | ((a >> (8 * i)) & 0xffULL);
+#pragma unroll
+	for (int i = 0; i < 5; i++) v = (v << 2) | ((b >> (8 * i)) & 0xffULL);
 	return v;
 }
 
@@ -1554,10 +1558,19 @@ DV void sdp_match(WCtx &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, c
 	w.n_sms = sdp_match_n(w, w.n_sms, q_bg, q_ed, q_str, t_str, t_len, t_st, isForward, nullptr) & 0x7fffffffu;
 }
 
+// the ring lives in LDS: typed accesses (ds_read_b128 / ds_write_b128)
+#ifdef DSB_HOST_EMU
+DV uint4 ring_ld(const uint4 *ring, uint32_t i) { return ring[i]; }
+DV void ring_st(uint4 *ring, uint32_t i, uint4 v) { ring[i] = v; }
+#else
+typedef uint32_t dsb_u32x4 __attribute__((ext_vector_type(4)));
+DV uint4 ring_ld(const uint4 *ring, uint32_t i) { dsb_u32x4 v = ((const __attribute__((address_space(3))) dsb_u32x4 *)ring)[i]; uint4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+DV void ring_st(uint4 *ring, uint32_t i, uint4 r) { dsb_u32x4 v; v.x = r.x; v.y = r.y; v.z = r.z; v.w = r.w; ((__attribute__((address_space(3))) dsb_u32x4 *)ring)[i] = v; }
+#endif
 DV void ring_put(WCtx &w, uint32_t idx, uint32_t t_pos, uint32_t q_pos, uint32_t len, uint32_t score)
 {
 	uint4 r; r.x = t_pos; r.y = q_pos; r.z = len; r.w = score;
-	w.ring[idx & (DSB_RING - 1)] = r;
+	ring_st(w.ring, idx & (DSB_RING - 1), r);
 }
 // the nodes sdp_match appended are consumed one by one: fetch them 64 at a time (one per lane) and hand
 // node idx to every lane with shuffles
@@ -1597,7 +1610,7 @@ DV int sdp_best_pred(WCtx &w, const DsbSms &cs, int32_t cur)
 		for (int u = 0; u < DSB_DP_UNROLL; u++) {
 			int32_t pi = hi - u * DSB_WAVE - w.lane;
 			if (pi < 0) { pv[u].t_pos = pv[u].q_pos = pv[u].len = pv[u].score = 0; }
-			else if (MODE != 0 && pi > cur - DSB_RING) { uint4 r = w.ring[pi & (DSB_RING - 1)]; pv[u].t_pos = r.x; pv[u].q_pos = r.y; pv[u].len = r.z; pv[u].score = r.w; }
+			else if (MODE != 0 && pi > cur - DSB_RING) { uint4 r = ring_ld(w.ring, pi & (DSB_RING - 1)); pv[u].t_pos = r.x; pv[u].q_pos = r.y; pv[u].len = r.z; pv[u].score = r.w; }
 			else pv[u] = w.sms[pi];
 		}
 		bool stop = false;
@@ -1715,7 +1728,7 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 	_Pragma("unroll") for (int u = 0; u < DSB_DP_UNROLL; u++) {                                                 \
 		int32_t pi = (hi_) - u * DSB_WAVE - w.lane;                                                              \
 		if (pi < 0) { dst[u].t_pos = 0; dst[u].q_pos = (MODE == 2) ? 0u : 0xfffffff0u; dst[u].len = 0; dst[u].score = 0; } \
-		else if (pi > n0 - DSB_RING) { uint4 r = w.ring[pi & (DSB_RING - 1)]; dst[u].t_pos = r.x; dst[u].q_pos = r.y; dst[u].len = r.z; dst[u].score = r.w; } \
+		else if (pi > n0 - DSB_RING) { uint4 r = ring_ld(w.ring, pi & (DSB_RING - 1)); dst[u].t_pos = r.x; dst[u].q_pos = r.y; dst[u].len = r.z; dst[u].score = r.w; } \
 		else dst[u] = w.sms[pi];                                                                                 \
 	}
 	if (n0 > 0) { DSB_FETCH_PREDS(nx, n0 - 1) }
@@ -1791,7 +1804,7 @@ DV int sdp_best_pred_b(WCtx &w, DpBatch &b, const DsbSms &cs, int32_t cur)
 	int best = (int)cs.len; bool cut = false;
 	uint32_t lim_q, lim_t; sdp_limits<MODE>(cs, lim_q, lim_t);
 	for (int32_t pi = cur - 1; pi >= (int32_t)b.n0; pi--) {      // in-batch predecessors, newest first
-		uint4 r = w.ring[pi & (DSB_RING - 1)]; DsbSms ps; ps.t_pos = r.x; ps.q_pos = r.y; ps.len = r.z; ps.score = r.w;
+		uint4 r = ring_ld(w.ring, pi & (DSB_RING - 1)); DsbSms ps; ps.t_pos = r.x; ps.q_pos = r.y; ps.len = r.z; ps.score = r.w;
 		bool skip, brk; int ns;
 		sdp_judge<MODE>(cs, ps, lim_q, lim_t, skip, brk, ns);
 		if (!skip && brk) { cut = true; break; }
