@@ -31,7 +31,7 @@ class DsbHit(C.Structure):
 
 
 class DsbReadResult(C.Structure):
-    _fields_ = [("first", C.c_uint32), ("n", C.c_uint32), ("status", C.c_int32), ("fast", C.c_uint32), ("device_us", C.c_uint32)]
+    _fields_ = [("first", C.c_uint32), ("n", C.c_uint32), ("status", C.c_int32), ("fast", C.c_uint32), ("device_us", C.c_uint32), ("n_anc", C.c_uint32)]
 
 
 class DsbResult(C.Structure):
@@ -51,7 +51,7 @@ class DsbTiming(C.Structure):
 EXPORTS = ["dsb_index_open", "dsb_index_close", "dsb_index_n_ref", "dsb_index_ref_name", "dsb_index_ref_len", "dsb_index_ek_len",
            "dsb_index_occ_host", "dsb_ctx_create", "dsb_ctx_destroy", "dsb_ctx_reset_history", "dsb_classify_batch",
            "dsb_batch_upload", "dsb_batch_upload_fastq", "dsb_batch_upload_text", "dsb_ctx_set_history", "dsb_host_alloc", "dsb_host_free", "dsb_batch_run", "dsb_batch_fetch", "dsb_batch_timing", "dsb_batch_seeds", "dsb_batch_exist_bits",
-           "dsb_format_sam", "dsb_strerror", "dsb_version"]
+           "dsb_format_sam", "dsb_format_des", "dsb_strerror", "dsb_version"]
 
 _lib = None
 

@@ -409,9 +409,10 @@ static void *format_main(void *arg)
 		dsb_read rd; rd.name = b->text + b->name_off[i]; rd.seq = b->text + b->seq_off[i]; rd.len = b->seq_len[i];
 		rd.qual = b->has_qual[i] ? b->text + b->qual_off[i] : "";
 		if (rr->status) { fprintf(stderr, "[classify] read %s: device arena overflow (status %d)\n", rd.name, rr->status); exit(1); }
-		size_t need = 4096 + 800 * (size_t)rr->n + (a->full ? 2 * (size_t)rd.len : 0) + strlen(rd.name);
+		size_t need = 4096 + 800 * (size_t)rr->n + (a->full == 1 ? 2 * (size_t)rd.len : 0) + strlen(rd.name);
 		if (j->len + need > j->cap) { j->cap = (j->len + need) * 2; j->buf = realloc(j->buf, j->cap); if (!j->buf) die("[classify] out of memory"); }
-		long w = dsb_format_sam(a->idx, &rd, b->hits + rr->first, rr->n, a->o.max_sec_N, a->full, j->buf + j->len, j->cap - j->len);
+		long w = a->full >= 2 ? dsb_format_des(a->idx, &rd, rr, b->hits + rr->first, a->o.max_sec_N, a->full == 3, j->buf + j->len, j->cap - j->len)
+		                      : dsb_format_sam(a->idx, &rd, b->hits + rr->first, rr->n, a->o.max_sec_N, a->full, j->buf + j->len, j->cap - j->len);
 		if (w < 0) die("[dsb_format_sam] buffer too small");
 		j->len += (size_t)w;
 	}
@@ -453,7 +454,8 @@ static void usage(void)
 	fprintf(stderr, "    -o, FILE        output results into file [stdout]\n    -s, INT         MIN score[64]\n");
 	fprintf(stderr, "    -g, INT         GPU device id [0]\n");
 	fprintf(stderr, "    -f, STR         output format, one of:\n                    - SAM: SAM-like results without SEQ and QUAL and header, default\n");
-	fprintf(stderr, "                    - SAM_FULL: SAM-like results with SEQ and QUAL\n\n");
+	fprintf(stderr, "                    - SAM_FULL: SAM-like results with SEQ and QUAL\n");
+	fprintf(stderr, "                    - DES: smaller format\n                    - DES_FULL: all results are showed, ignore '-r' opinion\n\n");
 }
 
 static double now(void) { struct timeval tv; gettimeofday(&tv, NULL); return tv.tv_sec + tv.tv_usec * 1e-6; }
@@ -473,7 +475,8 @@ static int classify_main(int argc, char **argv)
 		else if (c == 'g') dev = atoi(optarg);
 		else if (c == 'f') {
 			if (!strcmp(optarg, "SAM")) a.full = 0; else if (!strcmp(optarg, "SAM_FULL")) a.full = 1;
-			else { fprintf(stderr, "output format %s is not available in the GPU build (SAM, SAM_FULL)\n", optarg); return 1; }
+			else if (!strcmp(optarg, "DES")) a.full = 2; else if (!strcmp(optarg, "DES_FULL")) a.full = 3;
+			/* anything else keeps the default, as in the reference (src/cly_mt.c:497-502) */
 		}
 	}
 	if (optind + 2 > argc) { usage(); return 0; }

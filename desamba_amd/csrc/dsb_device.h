@@ -58,7 +58,7 @@ struct DsbMem { int match_len; int sa_sp_l; uint64_t sp, sa_sp; int read_offset;
 struct DsbScHash { uint16_t next; uint16_t seed_ID; };                   // bit 15 of seed_ID = s_or_e
 
 struct DsbHitOut { uint32_t ref_ID, t_st, t_ed, q_st, q_ed, sum_score, indel; uint8_t direction, primary, pri_index, pad; };
-struct DsbReadOut { uint32_t first, n; int32_t status; uint32_t fast; };
+struct DsbReadOut { uint32_t first, n; int32_t status; uint32_t fast; uint32_t n_anc, pad; };   // n_anc: cly_r.anchor_v.n at the end (DES header)
 
 // ---- arena sizes (per wave slot) ---------------------------------------------------------------
 #define DSB_QPAD_L 64

@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 		}                                                                                                               \
 		if (w.dbg && lane == 0) { w.dbg[0] = 200; if (r < 65536u) for (int i = 0; i < 14; i++) dbg[16 * 65536 + 14 * r + i] = (uint32_t)((w.tacc[i] - tacc0[i]) / 100); } \
 		if (lane == 0) { DsbReadOut ro; ro.first = first; ro.n = n_out; ro.status = w.status | (w.status ? (w.stage << 8) : 0); \
-			ro.fast = fast | ((uint32_t)((wall_clock64() - t_start) / 100) << 1); rout[r] = ro; }                       \
+			ro.fast = fast | ((uint32_t)((wall_clock64() - t_start) / 100) << 1); ro.n_anc = w.n_anc; ro.pad = 0; rout[r] = ro; }                       \
 	}                                                                                                                   \
 }
 
@@ -746,7 +746,7 @@ extern "C" int dsb_batch_fetch(dsb_ctx *c, dsb_result *out)
 	for (size_t i = 0; i < n; i++) {
 		const DsbReadOut &r = c->h_rout[i];
 		dsb_read_result &o = c->res_reads[i];
-		o.first = (uint32_t)c->res_hits.size(); o.n = r.n; o.fast = r.fast & 1u; o.device_us = r.fast >> 1;
+		o.first = (uint32_t)c->res_hits.size(); o.n = r.n; o.fast = r.fast & 1u; o.device_us = r.fast >> 1; o.n_anc = r.n_anc;
 		o.status = r.status ? (DSB_ECAP * 256 - r.status) : 0;
 		if (r.status) worst = DSB_ECAP;
 		for (uint32_t k = 0; k < r.n; k++) {

@@ -224,3 +224,26 @@ extern "C" const char *dsb_strerror(int code)
 	return "unknown error";
 }
 extern "C" const char *dsb_version(void) { return "desamba_amd 0.1 (gfx950)"; }
+
+// output_one_result_des / output_one_result_full (src/cly_mt.c:158-243; print_hit :60-104).  Anchors are never listed:
+// MAP_opt.show_anchor is false and no option sets it (src/cly_mt.c:486).
+extern "C" long dsb_format_des(const dsb_index *x, const dsb_read *rd_, const dsb_read_result *rr, const dsb_hit *h, int max_sec, int full, char *buf, size_t cap)
+{
+	static const char *primary_string[3] = {"PRI", "SEC", "SUP"};
+	size_t o = 0; int w;
+#define EMIT(...) do { w = snprintf(buf + o, cap > o ? cap - o : 0, __VA_ARGS__); if (w < 0 || (size_t)w >= (cap > o ? cap - o : 0)) return -1; o += (size_t)w; } while (0)
+	EMIT("%s\t%s\t%s\t%ld\tn_rst:[%ld]\tn_anc:[%ld]\t\n", rd_->name, rr->n ? "CLASSIFY" : "UNCLASSIFY", rr->fast ? "FAST" : "SLOW", (long)rd_->len, (long)rr->n, (long)rr->n_anc);
+	int rst_cnt = 0;
+	for (int loop = 0; loop <= 1; loop++)
+		for (uint32_t i = 0; i < rr->n; i++) {
+			const dsb_hit *c = h + i;
+			bool show = loop == 0 ? c->pri_index == 0 : (c->pri_index > 0 && (full || c->pri_index <= max_sec));
+			if (!show) continue;
+			unsigned ps = (unsigned)(c->primary - 1); if (ps > 2) ps = 2;
+			EMIT("%3d %s %s %20s ts:%-10d te:%-10d qs:%-10d qe:%-10d %-5d\t%d\t\n", rst_cnt++, primary_string[ps], c->direction ? "F" : "R",
+			     dsb_index_ref_name(x, c->ref_ID), (int)c->t_st, (int)c->t_ed, (int)c->q_st, (int)c->q_ed, (int)c->sum_score, (int)c->indel);
+		}
+	EMIT("\n");
+#undef EMIT
+	return (long)o;
+}

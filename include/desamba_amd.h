@@ -58,6 +58,7 @@ typedef struct {
 	int32_t status;       /* 0, or DSB_ECAP with the overflowing arena in the low bits */
 	uint32_t fast;        /* cly_r.fast_classify */
 	uint32_t device_us;   /* time the read occupied its wavefront (100 MHz wall clock), diagnostics */
+	uint32_t n_anc;       /* cly_r.anchor_v.n when classify_seq returns (printed by the DES writers) */
 } dsb_read_result;
 
 typedef struct {
@@ -125,6 +126,11 @@ int  dsb_batch_exist_bits(dsb_ctx *ctx, size_t read, int strand, uint8_t *out, s
 /* output_one_result_sam (src/cly_mt.c:245-344): format the records of one read into buf;
  * returns the number of bytes written (excluding the NUL), or -1 if cap is too small */
 long dsb_format_sam(const dsb_index *idx, const dsb_read *read, const dsb_hit *hits, uint32_t n_hits,
+                    int max_sec_N, int full, char *buf, size_t cap);
+
+/* output_one_result_des / output_one_result_full (src/cly_mt.c:158-243): the DES (full = 0: secondaries up to max_sec_N)
+ * or DES_FULL (full = 1: all) record of one read; same return convention as dsb_format_sam */
+long dsb_format_des(const dsb_index *idx, const dsb_read *read, const dsb_read_result *rr, const dsb_hit *hits,
                     int max_sec_N, int full, char *buf, size_t cap);
 
 const char *dsb_strerror(int code);

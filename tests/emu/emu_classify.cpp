@@ -143,3 +143,6 @@ int main(int argc, char **argv)
 	return 0;
 }
 #endif
+
+// cly_r.anchor_v.n when classify_seq returned (printed by the DES writers)
+extern "C" uint32_t emu_n_anc(void *p) { return ((EmuCtx *)p)->w.n_anc; }

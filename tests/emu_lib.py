@@ -24,6 +24,7 @@ class Emu:
         L.dsb_index_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         L.emu_new.argtypes = [C.c_void_p, C.c_int, C.c_int]; L.emu_new.restype = C.c_void_p
         L.emu_classify.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int, C.POINTER(EmuHit), C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_n_anc.argtypes = [C.c_void_p]; L.emu_n_anc.restype = C.c_uint32
         L.emu_seeds.argtypes = [C.c_void_p, C.c_int, C.POINTER(EmuSeed), C.c_int, C.POINTER(C.c_uint32)]
         self.L = L
         self.idx = C.c_void_p()
@@ -42,6 +43,9 @@ class Emu:
             raise RuntimeError("device-code status %#x" % (-n))
         hits = [self.buf[i].key() for i in range(min(n, 512))]
         return (hits, bF, bR) if want_bits else hits
+
+    def n_anc(self):
+        return int(self.L.emu_n_anc(self.e))
 
     def seeds(self, strand):
         buf = (EmuSeed * 65536)(); ts = C.c_uint32()

@@ -32,6 +32,8 @@ def main():
     # non-default output format and options (src/cly_mt.c:448-562)
     run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", "-f", "SAM_FULL", idx, os.path.join(OUT, "ngs150.fq"), "-o", os.path.join(OUT, "ngs150.full.ubfree.sam")])
     run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", "-l", "100", "-s", "30", "-r", "2", idx, os.path.join(OUT, "pb.fq"), "-o", os.path.join(OUT, "pb.l100s30r2.ubfree.sam")])
+    for fmt, extra, name, outn in (("DES", [], "pb", "pb.des.ubfree.txt"), ("DES_FULL", ["-r", "1"], "ngs150", "ngs150.desfull.ubfree.txt"), ("DES", ["-r", "1"], "ont5k_e25", "ont5k_e25.des_r1.ubfree.txt")):
+        run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", "-f", fmt] + extra + [idx, os.path.join(OUT, name + ".fq"), "-o", os.path.join(OUT, outn)])
     # the two heaviest reads of the 2000-read ONT set (tools/readsim seed 1, reads 1476 and 9): a tandem-repeat
     # region where one reference 9-mer matches dozens of read positions -> thousands of sparse-DP nodes
     heavy = os.path.join(OUT, "heavy.fq")

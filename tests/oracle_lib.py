@@ -40,6 +40,7 @@ def lib():
         L.ora_last_seeds.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(OraSeed)), C.POINTER(C.c_uint32)]
         L.ora_exist_bits.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint8)]
         L.ora_last_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.ora_last_anchors.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.ora_occ.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint8)]; L.ora_occ.restype = C.c_uint64
         L.ora_classify_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         L.ora_classify_file.restype = C.c_long
@@ -72,6 +73,10 @@ class Oracle:
         out = (C.c_uint8 * (len(seq) + 1))()
         lib().ora_exist_bits(C.byref(self.idx), seq, len(seq), strand, out)
         return out
+
+    def n_anc(self):
+        """anchor_v.n of the last read (what the DES header prints)"""
+        return int(lib().ora_last_anchors(self.ctx, None, 0))
 
     def counters(self):
         out = (C.c_uint64 * 8)()

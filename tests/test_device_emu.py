@@ -28,6 +28,7 @@ def _cmp(emu, oracle, recs, check_stages=False):
         else:
             got = emu.classify(seq, hist)
         assert got == exp, name
+        assert emu.n_anc() == oracle.n_anc(), name
         hist = max(hist, len(seq))
 
 

@@ -139,9 +139,13 @@ def test_cli_drop_in(gpu, demo, golden_md5, tmp_path):
 
 
 @pytest.mark.parametrize("args,fq,exp", [(["-f", "SAM_FULL"], "ngs150.fq", "ngs150.full.ubfree.sam"),
-                                         (["-l", "100", "-s", "30", "-r", "2"], "pb.fq", "pb.l100s30r2.ubfree.sam")])
+                                         (["-l", "100", "-s", "30", "-r", "2"], "pb.fq", "pb.l100s30r2.ubfree.sam"),
+                                         (["-f", "DES"], "pb.fq", "pb.des.ubfree.txt"),
+                                         (["-f", "DES_FULL", "-r", "1"], "ngs150.fq", "ngs150.desfull.ubfree.txt"),
+                                         (["-f", "DES", "-r", "1"], "ont5k_e25.fq", "ont5k_e25.des_r1.ubfree.txt")])
 def test_cli_options(gpu, tmp_path, args, fq, exp):
-    """SAM_FULL (SEQ and QUAL columns) and non-default -l/-s/-r, against the reference's output for the same command line"""
+    """SAM_FULL (SEQ and QUAL columns), DES / DES_FULL (n_rst, n_anc, FAST/SLOW) and non-default -l/-s/-r, against the
+    reference's output for the same command line"""
     import subprocess
     from conftest import ROOT as R
     out = tmp_path / "out.sam"
