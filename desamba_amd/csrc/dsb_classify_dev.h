@@ -302,11 +302,13 @@ DV uint64_t fm_occ(DsbXP x, uint64_t r, uint32_t &c)
 		uint64_t e0 = ~sp[0] & ((c & 1u) ? p0[0] : ~p0[0]) & ((c & 2u) ? p1[0] : ~p1[0]) & m0;
 		uint64_t e1 = ~sp[1] & ((c & 1u) ? p0[1] : ~p0[1]) & ((c & 2u) ? p1[1] : ~p1[1]) & m1;
 		uint32_t base = c == 0 ? a0.x : c == 1 ? a0.y : c == 2 ? a0.z : a0.w;
-		return (uint64_t)base + __popcll(e0) + __popcll(e1);
+		const uint64_t *sb = x->fm_sb;                               // null unless the BWT has >= 2^32 symbols
+		return (uint64_t)base + (sb ? DSB_G64(sb, (r >> 22) * 5 + c) : 0) + __popcll(e0) + __popcll(e1);
 	}
 	// c == 4: '#' rows before r
 	uint64_t blk0 = (r >> 7) << 7;
-	uint64_t base = blk0 - ((uint64_t)a0.x + a0.y + a0.z + a0.w) - (x->dollar_row < blk0 ? 1u : 0u);
+	const uint64_t *sb4 = x->fm_sb;
+	uint64_t base = blk0 - ((uint64_t)a0.x + a0.y + a0.z + a0.w + (sb4 ? DSB_G64(sb4, (r >> 22) * 5 + 4) : 0)) - (x->dollar_row < blk0 ? 1u : 0u);
 	return base + __popcll(sp[0] & ~p0[0] & m0) + __popcll(sp[1] & ~p0[1] & m1);
 }
 

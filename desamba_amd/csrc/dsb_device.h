@@ -32,6 +32,7 @@ struct DsbRefInfo { uint64_t seq_l, seq_offset; };
 struct DsbDevIndex {
 	const uint8_t *ek0, *ek1; uint64_t ek_mask; int ek_len, single_base_max;
 	const DsbFmBlock *fm; uint64_t bwt_len; uint64_t rank[6]; uint64_t dollar_pos; uint64_t dollar_row;
+	const uint64_t *fm_sb;     // BWT of >= 2^32 symbols: 5 u64 per superblock (2^22 symbols), block counts are relative to them; else null
 	const uint64_t *hash_index;
 	const uint2 *sa; const uint2 *uni; const uint64_t *refpos; const uint8_t *refbin; const DsbRefInfo *refinfo;
 	const int *qmem;           // [2000]

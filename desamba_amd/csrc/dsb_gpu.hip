@@ -424,6 +424,7 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 		}
 	}
 	if ((rc = dev_upload(c, h->fm, h->n_fm, &dx.fm))) return rc;
+	if (h->fm_sb && (rc = dev_upload(c, h->fm_sb, h->n_fm_sb * 5, &dx.fm_sb))) return rc;
 	dx.bwt_len = h->bwt_len; memcpy(dx.rank, h->rank, sizeof dx.rank); dx.dollar_pos = h->dollar_pos; dx.dollar_row = h->dollar_row;
 	if ((rc = dev_upload(c, h->hash_index, ((size_t)1 << 26) + 1, &dx.hash_index))) return rc;
 	if ((rc = dev_upload(c, (const uint2 *)h->sa, h->sa_size, &dx.sa))) return rc;

@@ -11,6 +11,7 @@ struct DsbHostRefInfoDisk { char name[128]; uint64_t seq_l, seq_offset; };   // 
 struct DsbHostIndex {
 	uint64_t ek_size, ek_mask; int ek_len, single_base_max; uint8_t *ek0, *ek1;
 	DsbFmBlock *fm; uint64_t n_fm, bwt_len, rank[6], dollar_pos, dollar_row;
+	uint64_t *fm_sb; uint64_t n_fm_sb;     // 64-bit rank: per superblock of 2^15 blocks {A, C, G, T, sum} before it; null = block counts are absolute
 	uint64_t *hash_index;
 	DsbHostSa *sa; uint64_t sa_size;
 	DsbHostUni *uni; uint64_t n_uni;

@@ -49,15 +49,26 @@ extern "C" int dsb_index_open(const char *dir, dsb_index **out)
 	h.fm = (DsbFmBlock *)calloc(h.n_fm, sizeof(DsbFmBlock));
 	if (!h.fm) { free(raw); FAIL(DSB_ENOMEM); }
 	h.dollar_row = ~0ULL;
+	// 32-bit block counters hold a BWT of < 2^32 symbols per base.  Beyond that (the reference's 35 Gbp index) -- or with
+	// DSB_FORCE_RANK64=1, for tests -- every 2^15 blocks (2^22 symbols) get a superblock entry {A, C, G, T, sum} of 64-bit
+	// counts and the block counters are relative to it.
+	bool rank64 = getenv("DSB_FORCE_RANK64") != NULL;
+	if (n_blk256) { uint64_t last[5]; memcpy(last, raw + (n_blk256 - 1) * 168, 40); for (int c = 0; c < 4; c++) if (last[c] + 256 > 0xffffffffULL) rank64 = true; }
+	h.fm_sb = NULL; h.n_fm_sb = 0;
+	if (rank64) {
+		h.n_fm_sb = (h.n_fm >> 15) + 1;
+		h.fm_sb = (uint64_t *)calloc(h.n_fm_sb * 5, 8);
+		if (!h.fm_sb) { free(raw); FAIL(DSB_ENOMEM); }
+	}
 	for (uint64_t b = 0; b < n_blk256; b++) {
 		const uint8_t *blk = raw + b * 168;
 		uint64_t cnt[5]; memcpy(cnt, blk, 40);
 		for (int hblk = 0; hblk < 2; hblk++) {
-			DsbFmBlock &o = h.fm[b * 2 + hblk];
-			for (int c = 0; c < 4; c++) {
-				if (cnt[c] > 0xffffffffULL) { fprintf(stderr, "[desamba_amd] index too large for the 32-bit rank layout\n"); free(raw); FAIL(DSB_EINVAL); }
-				o.cnt[c] = (uint32_t)cnt[c];
-			}
+			const uint64_t bi = b * 2 + hblk;
+			DsbFmBlock &o = h.fm[bi];
+			uint64_t *sb = rank64 ? h.fm_sb + (bi >> 15) * 5 : NULL;
+			if (sb && (bi & 32767u) == 0) { for (int c = 0; c < 4; c++) sb[c] = cnt[c]; sb[4] = cnt[0] + cnt[1] + cnt[2] + cnt[3]; }
+			for (int c = 0; c < 4; c++) o.cnt[c] = (uint32_t)(cnt[c] - (sb ? sb[c] : 0));
 			for (int i = 0; i < 128; i++) {
 				int s = hblk * 128 + i;
 				uint8_t sym = (blk[40 + (s >> 1)] >> ((s & 1) * 4)) & 0xf;
@@ -150,7 +161,7 @@ extern "C" void dsb_index_close(dsb_index *x)
 {
 	if (!x) return;
 	DsbHostIndex &h = x->h;
-	free(h.ek0); free(h.ek1); free(h.fm); free(h.hash_index); free(h.sa); free(h.uni); free(h.refpos); free(h.refbin); free(h.refdisk); free(h.refinfo);
+	free(h.ek0); free(h.ek1); free(h.fm); free(h.fm_sb); free(h.hash_index); free(h.sa); free(h.uni); free(h.refpos); free(h.refbin); free(h.refdisk); free(h.refinfo);
 	free(x);
 }
 extern "C" uint64_t dsb_index_n_ref(const dsb_index *x) { return x ? x->h.n_ref : 0; }
@@ -176,10 +187,10 @@ extern "C" uint64_t dsb_index_occ_host(const dsb_index *x, uint64_t r, uint8_t *
 	if (c < 4u) {
 		uint64_t e0 = ~b.sp[0] & ((c & 1u) ? b.p0[0] : ~b.p0[0]) & ((c & 2u) ? b.p1[0] : ~b.p1[0]) & m0;
 		uint64_t e1 = ~b.sp[1] & ((c & 1u) ? b.p0[1] : ~b.p0[1]) & ((c & 2u) ? b.p1[1] : ~b.p1[1]) & m1;
-		return (uint64_t)b.cnt[c] + __builtin_popcountll(e0) + __builtin_popcountll(e1);
+		return (uint64_t)b.cnt[c] + (h.fm_sb ? h.fm_sb[(r >> 22) * 5 + c] : 0) + __builtin_popcountll(e0) + __builtin_popcountll(e1);
 	}
 	uint64_t blk0 = (r >> 7) << 7;
-	uint64_t base = blk0 - ((uint64_t)b.cnt[0] + b.cnt[1] + b.cnt[2] + b.cnt[3]) - (h.dollar_row < blk0 ? 1u : 0u);
+	uint64_t base = blk0 - ((uint64_t)b.cnt[0] + b.cnt[1] + b.cnt[2] + b.cnt[3] + (h.fm_sb ? h.fm_sb[(r >> 22) * 5 + 4] : 0)) - (h.dollar_row < blk0 ? 1u : 0u);
 	return base + __builtin_popcountll(b.sp[0] & ~b.p0[0] & m0) + __builtin_popcountll(b.sp[1] & ~b.p0[1] & m1);
 }
 

@@ -26,15 +26,20 @@ def test_exports_match_header(built):
     assert sorted(D.EXPORTS) == syms
 
 
-def test_index_loader_and_rank_layout(demo, oracle):
-    """device rank layout (64-B blocks) == reference occ() (src/bwt.c:43-65) on random rows, every symbol"""
+@pytest.mark.parametrize("rank64", [False, True])
+def test_index_loader_and_rank_layout(demo, oracle, monkeypatch, rank64):
+    """device rank layout (64-B blocks) == reference occ() (src/bwt.c:43-65) on random rows, every symbol; also with the
+    64-bit superblock layout of indexes beyond 2^32 BWT symbols forced on (the demo BWT spans three superblocks)"""
     import desamba_amd as D
+    if rank64:
+        monkeypatch.setenv("DSB_FORCE_RANK64", "1")
     idx = D.Index(demo["index"])
     assert idx.n_ref == 463 and idx.ek_len == 16
     assert idx.ref_name(0).startswith("tid|")
     rng = random.Random(5)
     bwt_len = 11798750
-    rows = [rng.randrange(bwt_len) for _ in range(20000)] + [0, 1, 127, 128, 129, 255, 256, bwt_len - 1]
+    rows = [rng.randrange(bwt_len) for _ in range(20000)] + [0, 1, 127, 128, 129, 255, 256, bwt_len - 1] + \
+        [k * (1 << 22) + d for k in (1, 2) for d in (-129, -128, -1, 0, 1, 127, 128)]
     for r in rows:
         for c in (0, 1, 2, 3, 4, 0xff):
             assert idx.occ_host(r, c) == oracle.occ(r, c)

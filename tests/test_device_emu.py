@@ -58,3 +58,13 @@ def test_random_long_reads(emu, oracle, demo, tmp_path):
     fq = tmp_path / "ont50k.fq"
     subprocess.check_call([os.path.join(ROOT, "tools", "readsim"), demo["index"], str(fq), "600", "50000", "0.15", "1", "ont"])
     _cmp(emu, oracle, D.read_fastq(str(fq)))
+
+
+def test_rank64_layout_in_device_code(oracle, demo, monkeypatch):
+    """the device code with the 64-bit superblock rank layout forced on: same hits as the oracle"""
+    import emu_lib
+    import desamba_amd as D
+    monkeypatch.setenv("DSB_FORCE_RANK64", "1")
+    e = emu_lib.Emu(demo["index"])
+    for name in ("ont20k", "wrapq", "appc"):
+        _cmp(e, oracle, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))

@@ -59,6 +59,19 @@ def test_heavy_first_launch(gpu, name, monkeypatch):
     assert sam == open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read()
 
 
+def test_rank64_layout_on_device(demo, monkeypatch):
+    """the 64-bit superblock rank layout (indexes beyond 2^32 BWT symbols), forced on for the demo index"""
+    import desamba_amd as D
+    monkeypatch.setenv("DSB_FORCE_RANK64", "1")
+    idx = D.Index(demo["index"]); ctx = D.Ctx(idx, 0)
+    try:
+        for name in ("ont20k", "pb", "ngs150"):
+            hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))
+            assert sam == open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read(), name
+    finally:
+        ctx.close(); idx.close()
+
+
 def test_stage_parity_seed_lookup(gpu, demo, oracle):
     """exist-kmer bits of every window and the seed lists (a-3) of both strands"""
     D, idx, ctx = gpu
