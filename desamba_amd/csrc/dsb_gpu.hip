@@ -413,8 +413,11 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	if ((rc = dev_upload(c, h->ek1, h->ek_size, &dx.ek1))) return rc;
 	dx.ek_mask = h->ek_mask; dx.ek_len = h->ek_len; dx.single_base_max = h->single_base_max;
 	{
-		// DSB_EK_SUMMARY=0 turns the summary off, 3..6 choose its granularity
-		const char *lv = getenv("DSB_EK_SUMMARY"); int shift = lv ? atoi(lv) : 6;
+		// DSB_EK_SUMMARY=0 turns the summary off, 3..8 choose its granularity.  Default: one bit per 64 table bits while that
+		// keeps the summary L2-sized (tables up to 256 MiB -> <= 4 MiB), one per 256 up to 1 GiB tables, none beyond (the
+		// multi-GiB tables of the big indexes are also much fuller: a summary bit would rarely be clear)
+		const char *lv = getenv("DSB_EK_SUMMARY");
+		int shift = lv ? atoi(lv) : (h->ek_size <= (256ull << 20) ? 6 : h->ek_size <= (1024ull << 20) ? 8 : 0);
 		if (shift >= 3 && shift <= 8 && (h->ek_size >> (shift - 3)) >= 4096) {
 			uint64_t n_out = h->ek_size >> shift;              // table bits / 2^shift / 8
 			HIPCHK(hipMalloc((void **)&c->d_summ, n_out + 256)); c->dev_allocs.push_back(c->d_summ);
