@@ -45,7 +45,7 @@ class DsbSeed(C.Structure):
 class DsbTiming(C.Structure):
     _fields_ = [("encode_ms", C.c_float), ("seed_probe_ms", C.c_float), ("classify_ms", C.c_float), ("total_ms", C.c_float),
                 ("windows", C.c_uint64), ("probes_t1", C.c_uint64), ("bases", C.c_uint64),
-                ("order_ms", C.c_float), ("tail_ms", C.c_float), ("n_early", C.c_uint32), ("pad", C.c_uint32)]
+                ("order_ms", C.c_float), ("tail_ms", C.c_float), ("n_early", C.c_uint32), ("n_retry", C.c_uint32)]
 
 
 EXPORTS = ["dsb_index_open", "dsb_index_close", "dsb_index_n_ref", "dsb_index_ref_name", "dsb_index_ref_len", "dsb_index_ek_len",

@@ -1377,7 +1377,8 @@ DV int MEM_search(P8 q, P8 t, bool forward, int max)
 }
 DV DsbSms *push_sms(WCtx &w)
 {
-	if (w.n_sms >= DSB_SMS_CAP) { w.status |= DSB_ST_SMS_OVF; return w.sms + DSB_SMS_CAP - 1; }
+	const uint32_t cap = w.x->sms_cap;
+	if (w.n_sms >= cap) { w.status |= DSB_ST_SMS_OVF; return w.sms + cap - 1; }
 	return w.sms + w.n_sms++;
 }
 DV uint64_t bin2kmer9(const uint8_t *s) { uint64_t v = 0;
@@ -1495,7 +1496,7 @@ DN uint32_t sdp_match_t(WCtx &w, const SdpArgsT<P8> a, uint32_t n_sms)
 	if (t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return n_sms; // the reference's loop does not run either (t_len >= 13 at every call site)
 	uint32_t n_pos = (t_kmer_num - 4 + 3) / 4;                      // i = 4, 8, ... < t_kmer_num
 	// the context lives in memory (it is shared by reference with non-inlined callers): work on copies
-	const int lane = w.lane; uint32_t *const red = w.red; DsbSms *const sms = w.sms;
+	const int lane = w.lane; uint32_t *const red = w.red; DsbSms *const sms = w.sms; const uint32_t sms_cap = w.x->sms_cap;
 	uint32_t lsteps = w.lsteps, mirror_bad = 0; int st = 0;
 	for (uint32_t g = 0; g < n_pos; g += DSB_WAVE) {
 		uint32_t pI = g + lane; bool valid = pI < n_pos; int i = 4 + 4 * (int)pI;
@@ -1503,7 +1504,7 @@ DN uint32_t sdp_match_t(WCtx &w, const SdpArgsT<P8> a, uint32_t n_sms)
 		uint32_t cnt = valid ? sdp_visit<FWD, true, P8>(lsteps, st, a, i, keep, DSB_SDP_KEEP) : 0;
 		uint32_t total, off = grp_excl_scan_u(red, lane, cnt, &total);
 		if (total == 0) continue;
-		if (n_sms + total > DSB_SMS_CAP) { st |= DSB_ST_SMS_OVF; break; }
+		if (n_sms + total > sms_cap) { st |= DSB_ST_SMS_OVF; break; }
 		DsbSms *dst = sms + n_sms + off;
 		if (cnt <= DSB_SDP_KEEP) {
 			for (uint32_t k = 0; k < cnt; k++) {
@@ -1872,7 +1873,7 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 			mirror = lnodes != nullptr && !(n_sms >> 31); n_sms &= 0x7fffffffu;
 		}
 		n_sms++;                                                     // the last node
-		if (n_sms > DSB_SMS_CAP) { w.status |= DSB_ST_SMS_OVF; n_sms = DSB_SMS_CAP; }
+		if (n_sms > w.x->sms_cap) { w.status |= DSB_ST_SMS_OVF; n_sms = w.x->sms_cap; }
 		{
 #ifndef DSB_HOST_EMU
 			if (n_sms <= (uint32_t)DSB_WAVE && DSB_GROUP == 64) {

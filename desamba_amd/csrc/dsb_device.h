@@ -38,6 +38,7 @@ struct DsbDevIndex {
 	const int *qmem;           // [2000]
 	const int *qlv;            // [20][20]
 	int filter_min_length, filter_min_score, filter_min_score_LV3;
+	uint32_t sms_cap;          // entries of the per-wave match-node arena (sized from the longest read of the batch)
 };
 
 // ---- per-read records produced on the device -------------------------------------------------
@@ -69,6 +70,9 @@ struct DsbReadOut { uint32_t first, n; int32_t status; uint32_t fast; uint32_t n
 #define DSB_ANC_CAP 8192
 #define DSB_HIT_CAP 4096
 #define DSB_SMS_CAP 16384
+// The extension loops keep every match node of one uninterrupted extension (src/cly.c:2532-2819, a kvec there), so the
+// arena grows with the longest read of the batch.
+static inline uint32_t dsb_sms_cap_for(uint32_t max_len) { uint32_t c = 2 * max_len; return c < DSB_SMS_CAP ? DSB_SMS_CAP : c; }
 #define DSB_MEMSLOW_CAP (8 * 800 + 1 + 16)
 #define DSB_SPSET_CAP 500
 #define DSB_REFWIN 2176

@@ -266,6 +266,7 @@ struct DsbSlotArena {
 	size_t off_seeds, off_anc, off_anc_tmp, off_hit, off_hit_tmp, off_sms, off_kh, off_sc, off_mem, off_spset, off_scorev,
 	       off_sortkey, off_sortidx, off_win, off_lane_anc, off_lane_sp, off_top, off_round;   /* off_kh: unused since the 9-mer tables moved to LDS */
 	uint32_t max_len;                             // longest read the arena was sized for
+	uint32_t sms_cap;                             // entries of the match-node arena (off_sms)
 };
 
 // One kernel body, two instantiations.  Work items come from an atomic counter; with `list` == nullptr
@@ -353,6 +354,15 @@ DSB_DEFINE_CLASSIFY(k_classify, dsb_g64, 64)
 // the same kernel under a second name for the early launch of the heaviest reads, so that profiles list the two apart
 DSB_DEFINE_CLASSIFY(k_classify_early, dsb_g64, 64)
 
+// reads whose match-node arena overflowed (and nothing else went wrong) are listed for a second run
+__global__ void k_collect_retry(const DsbReadOut *rout, uint32_t n, uint32_t *list, unsigned int *count)
+{
+	uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	int st = rout[i].status & 0xff;
+	if ((st & DSB_ST_SMS_OVF) && !(st & (DSB_ST_TIMEOUT | DSB_ST_OUT_OVF))) list[atomicAdd(count, 1u)] = i;
+}
+
 // ================================== host side ====================================================
 struct dsb_ctx {
 	dsb_index *idx; int device; hipStream_t stream;
@@ -364,6 +374,7 @@ struct dsb_ctx {
 	DsbReadOut *d_rout; DsbHitOut *d_hout; size_t cap_rout, cap_hout;
 	unsigned int *d_counters;                      // [0] work, [1] hits; +8: u64 p1 counter
 	DsbSlotArena arena; size_t arena_bytes; int n_slots;
+	DsbSlotArena arena_big; int n_slots_big;      // second run of reads whose match-node arena overflowed
 	uint32_t *d_score, *d_order; size_t cap_score, cap_order;
 	unsigned n_early;                              // reads of the last run that went through the early launch
 	uint8_t *d_summ; int summ_shift;               // cache-resident summary of exist table 0 (k_ek_summary); null = off
@@ -456,7 +467,7 @@ extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 	hipSetDevice(c->device);
 	for (void *p : c->dev_allocs) hipFree(p);
 	hipFree(c->d_rd); hipFree(c->d_wd); hipFree(c->d_ascii); hipFree(c->d_bin); hipFree(c->d_pk); hipFree(c->d_bits);
-	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->d_score); hipFree(c->d_order);
+	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->arena_big.base); hipFree(c->d_score); hipFree(c->d_order);
 	for (int i = 0; i < 4; i++) hipEventDestroy(c->ev[i]);
 	hipEventDestroy(c->ev_order); hipEventDestroy(c->ev_cls); hipEventDestroy(c->ev_heavy); hipEventDestroy(c->ev_hprobe); hipStreamDestroy(c->stream2);
 	hipStreamDestroy(c->stream);
@@ -480,18 +491,23 @@ static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // slots [n_slots, n_slots + DSB_HEAVY_SLOTS) belong to the early launch of the heaviest reads (dsb_batch_run)
 #define DSB_HEAVY_SLOTS 512
-static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int n_slots, int group)
+// the arena of the second run (dsb_batch_run): few slots, DSB_RETRY_GROW times the match nodes
+#define DSB_RETRY_SLOTS 64
+#define DSB_RETRY_GROW 32
+#define DSB_RETRY_MAX_NODES (8u << 20)
+static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int n_slots, int group, uint32_t sms_cap, int extra_slots, bool exact_cap = false)
 {
-	if (a.base && a.max_len >= max_len && *cur_slots >= n_slots) return 0;
+	if (a.base && a.max_len >= max_len && *cur_slots >= n_slots && (exact_cap ? a.sms_cap == sms_cap : a.sms_cap >= sms_cap)) return 0;
+	if (a.max_len > max_len) max_len = a.max_len;
 	if (a.base) { hipFree(a.base); a.base = nullptr; }
 	size_t o = 0;
-	a.max_len = max_len;
+	a.max_len = max_len; a.sms_cap = sms_cap;
 	a.off_seeds = o;   o += al256(((size_t)(max_len >> 1) + 64) * sizeof(DsbSeed));
 	a.off_anc = o;     o += al256((size_t)DSB_ANC_CAP * sizeof(DsbAnchor));
 	a.off_anc_tmp = o; o += al256((size_t)DSB_ANC_CAP * sizeof(DsbAnchor));
 	a.off_hit = o;     o += al256((size_t)DSB_HIT_CAP * sizeof(DsbChain));
 	a.off_hit_tmp = o; o += al256((size_t)DSB_HIT_CAP * sizeof(DsbChain));
-	a.off_sms = o;     o += al256((size_t)DSB_SMS_CAP * sizeof(DsbSms));
+	a.off_sms = o;     o += al256((size_t)sms_cap * sizeof(DsbSms));
 	a.off_kh = o;
 	a.off_sc = o;      o += al256((size_t)(256 + 2 * 400 + 64) * sizeof(DsbScHash));
 	a.off_mem = o;     o += al256((size_t)DSB_MEMSLOW_CAP * sizeof(DsbMem));
@@ -506,7 +522,7 @@ static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int n_s
 	a.off_round = o;    o += al256(((size_t)(max_len >> 1) + 64) * 4);
 	a.stride = al256(o);
 	*cur_slots = n_slots;
-	if (hipMalloc((void **)&a.base, a.stride * ((size_t)n_slots + DSB_HEAVY_SLOTS)) != hipSuccess) { a.base = nullptr; return DSB_ENOMEM; }
+	if (hipMalloc((void **)&a.base, a.stride * ((size_t)n_slots + extra_slots)) != hipSuccess) { a.base = nullptr; return DSB_ENOMEM; }
 	return 0;
 }
 
@@ -544,7 +560,12 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 	// reads in flight: one wavefront each; default = what is resident at once (12 waves per CU: LDS), bounded by the batch
 	int want = c->opts.n_slots > 0 ? c->opts.n_slots : 256 * 12;
 	if ((size_t)want > n) want = (int)(n ? n : 1);
-	if ((rc = size_arena(c->arena, &c->n_slots, max_len, want > c->n_slots ? want : c->n_slots, 64))) return rc;
+	uint32_t cap1 = dsb_sms_cap_for(max_len);
+	const bool cap_forced = getenv("DSB_SMS_CAP") != NULL;                      // diagnostics: a small arena forces second runs
+	if (cap_forced) { cap1 = (uint32_t)atol(getenv("DSB_SMS_CAP")); if (cap1 < 64) cap1 = 64; }
+	uint64_t cap2 = (uint64_t)cap1 * DSB_RETRY_GROW; if (cap2 > DSB_RETRY_MAX_NODES) cap2 = cap1 > DSB_RETRY_MAX_NODES ? cap1 : DSB_RETRY_MAX_NODES;
+	if ((rc = size_arena(c->arena, &c->n_slots, max_len, want > c->n_slots ? want : c->n_slots, 64, cap1, DSB_HEAVY_SLOTS, cap_forced))) return rc;
+	if ((rc = size_arena(c->arena_big, &c->n_slots_big, max_len, DSB_RETRY_SLOTS, 64, (uint32_t)cap2, 0))) return rc;
 	if ((rc = grow(&c->d_score, &c->cap_score, n + 1))) return rc;
 	if ((rc = grow(&c->d_order, &c->cap_order, n + 1))) return rc;
 	if (n) {
@@ -655,13 +676,14 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		if (n_heavy > n / 2) n_heavy = (unsigned)(n / 2);
 	}
 	c->n_early = n_heavy;
+	DsbDevIndex dx1 = c->dx; dx1.sms_cap = c->arena.sms_cap;
 	if (n_heavy) {
 		// their probes first, alone on the device (about a millisecond), then their classify launch on the second stream
 		hipLaunchKernelGGL(k_seed_probe_reads, dim3(n_heavy * DSB_HPROBE_SPLIT), dim3(256), 0, c->stream, c->dx, c->d_rd, (const uint32_t *)c->d_order, c->d_pk, c->d_bits, c->d_summ, c->summ_shift);
 		HIPCHK(hipEventRecord(c->ev_hprobe, c->stream));
 		HIPCHK(hipEventRecord(c->ev_order, c->stream));             // order_ms covers scoring, ordering and these probes
 		HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_hprobe, 0));
-		hipLaunchKernelGGL(k_classify_early, dim3(n_heavy), dim3(64), 0, c->stream2, c->dx, c->d_rd, (uint32_t)n_heavy, (const unsigned int *)nullptr, (const uint32_t *)c->d_order,
+		hipLaunchKernelGGL(k_classify_early, dim3(n_heavy), dim3(64), 0, c->stream2, dx1, c->d_rd, (uint32_t)n_heavy, (const unsigned int *)nullptr, (const uint32_t *)c->d_order,
 		                   c->d_bin, c->d_bits, c->arena, c->d_counters + 4, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout,
 		                   (uint32_t *)nullptr, 0u, (uint32_t)c->n_slots);
 		HIPCHK(hipEventRecord(c->ev_heavy, c->stream2));
@@ -679,7 +701,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		uint32_t *dbgp = dbg ? c->dbg_dev : nullptr;
 		if (dbg) memset(c->dbg_host, 0, 32 * 65536 * sizeof(uint32_t));
 		// counters: [0] work, [1] hits, [2..3] u64 table-1 probes
-		hipLaunchKernelGGL(k_classify, dim3(slots), dim3(64), 0, c->stream, c->dx, c->d_rd, (uint32_t)n, (const unsigned int *)nullptr, (const uint32_t *)c->d_order,
+		hipLaunchKernelGGL(k_classify, dim3(slots), dim3(64), 0, c->stream, dx1, c->d_rd, (uint32_t)n, (const unsigned int *)nullptr, (const uint32_t *)c->d_order,
 		                   c->d_bin, c->d_bits, c->arena, c->d_counters, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout,
 		                   dbgp, (uint32_t)n_heavy, 0u);
 		HIPCHK(hipEventRecord(c->ev_cls, c->stream));
@@ -695,6 +717,17 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 				}
 			}
 		}
+	}
+	{
+		// Second run: the match-node arena of a slot holds 2 nodes per base of the longest read (dsb_sms_cap_for); the
+		// reference's vector is unbounded (tandem repeats under a long extension).  Reads that overflowed it are listed
+		// on the device and run again in DSB_RETRY_SLOTS slots whose arena is DSB_RETRY_GROW times larger; with an
+		// empty list the launch drains at once.  counters: [6] listed reads, [7] work counter of the second run.
+		DsbDevIndex dx2 = c->dx; dx2.sms_cap = c->arena_big.sms_cap;
+		hipLaunchKernelGGL(k_collect_retry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const DsbReadOut *)c->d_rout, (uint32_t)n, c->d_score, c->d_counters + 6);
+		hipLaunchKernelGGL(k_classify, dim3(DSB_RETRY_SLOTS), dim3(64), 0, c->stream, dx2, c->d_rd, 0u, (const unsigned int *)(c->d_counters + 6), (const uint32_t *)c->d_score,
+		                   c->d_bin, c->d_bits, c->arena_big, c->d_counters + 7, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout,
+		                   (uint32_t *)nullptr, 0u, 0u);
 	}
 	HIPCHK(hipEventRecord(c->ev[3], c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
@@ -723,7 +756,8 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	hipEventElapsedTime(&c->timing.tail_ms, c->ev_cls, c->ev[3]);           // waiting for the early launch, if it is still running
 	c->timing.n_early = c->n_early;
 	hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[3]);
-	HIPCHK(hipMemcpyAsync(&c->p1, c->d_counters + 2, 8, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipMemcpyAsync(&c->p1, c->d_counters + 2, 8, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(&c->timing.n_retry, c->d_counters + 6, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
 
 	c->timing.windows = c->total_windows; c->timing.probes_t1 = c->p1; c->timing.bases = c->total_bases;
 	return DSB_OK;

@@ -77,9 +77,9 @@ typedef struct {
 	uint64_t probes_t1;    /* probes that continued to table 1 (= P1) */
 	uint64_t bases;
 	float order_ms;        /* scoring + ordering of the reads (longest first) + the probes of the early launch */
-	float tail_ms;         /* time the batch waited for the early launch (heaviest reads, second stream) after the main one */
+	float tail_ms;         /* after the main launch: waiting for the early launch (heaviest reads, second stream) + the second run */
 	uint32_t n_early;      /* reads that went through the early launch */
-	uint32_t pad;
+	uint32_t n_retry;      /* reads run a second time with the large match-node arena (theirs overflowed) */
 } dsb_timing;
 
 /* load_idx (src/idx.c:1103-1160, src/bwt.c:68-104): read <dir>/deSAMBA.* into host memory */

@@ -12,7 +12,7 @@
 using namespace dsb_g64;
 
 struct EmuCtx {
-	DsbDevIndex dx; std::vector<uint8_t> arena; uint32_t max_len; WCtx w;
+	DsbDevIndex dx; std::vector<uint8_t> arena; uint32_t max_len; WCtx w; size_t sms_off;
 	std::vector<uint8_t> bin; std::vector<uint64_t> pk, bits;
 	std::vector<DsbSeed> seedsF, seedsR;
 };
@@ -38,12 +38,13 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 {
 	if (L <= e->max_len) return;
 	e->max_len = L + L / 4 + 1024;
+	e->dx.sms_cap = getenv("DSB_EMU_SMS_CAP") ? (uint32_t)atol(getenv("DSB_EMU_SMS_CAP")) : dsb_sms_cap_for(e->max_len);
 	size_t o = 0, off[20]; int k = 0;
 	auto add = [&](size_t n) { off[k++] = o; o += al(n); };
 	add(((size_t)(e->max_len >> 1) + 64) * sizeof(DsbSeed));            // 0 seeds
 	add((size_t)DSB_ANC_CAP * sizeof(DsbAnchor)); add((size_t)DSB_ANC_CAP * sizeof(DsbAnchor));  // 1,2
 	add((size_t)DSB_HIT_CAP * sizeof(DsbChain)); add((size_t)DSB_HIT_CAP * sizeof(DsbChain));    // 3,4
-	add((size_t)DSB_SMS_CAP * sizeof(DsbSms));                           // 5
+	add((size_t)e->dx.sms_cap * sizeof(DsbSms)); e->sms_off = off[5];      // 5
 	add(256);                                                            // 6 (unused)
 	add((size_t)(256 + 2 * 400 + 64) * sizeof(DsbScHash));               // 7
 	add((size_t)DSB_MEMSLOW_CAP * sizeof(DsbMem));                       // 8
@@ -144,5 +145,13 @@ int main(int argc, char **argv)
 }
 #endif
 
+// high-water mark of the match-node arena since the arena was (re)built (its fill pattern is 0xCD)
+extern "C" uint32_t emu_sms_peak(void *p)
+{
+	EmuCtx *e = (EmuCtx *)p; const uint32_t *a = (const uint32_t *)(e->arena.data() + e->sms_off);
+	size_t n = (size_t)e->dx.sms_cap * 4;
+	while (n && a[n - 1] == 0xCDCDCDCDu) n--;
+	return (uint32_t)((n + 3) / 4);
+}
 // cly_r.anchor_v.n when classify_seq returned (printed by the DES writers)
 extern "C" uint32_t emu_n_anc(void *p) { return ((EmuCtx *)p)->w.n_anc; }

@@ -25,6 +25,7 @@ class Emu:
         L.emu_new.argtypes = [C.c_void_p, C.c_int, C.c_int]; L.emu_new.restype = C.c_void_p
         L.emu_classify.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int, C.POINTER(EmuHit), C.c_int, C.c_void_p, C.c_void_p]
         L.emu_n_anc.argtypes = [C.c_void_p]; L.emu_n_anc.restype = C.c_uint32
+        L.emu_sms_peak.argtypes = [C.c_void_p]; L.emu_sms_peak.restype = C.c_uint32
         L.emu_seeds.argtypes = [C.c_void_p, C.c_int, C.POINTER(EmuSeed), C.c_int, C.POINTER(C.c_uint32)]
         self.L = L
         self.idx = C.c_void_p()

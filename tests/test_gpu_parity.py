@@ -59,6 +59,21 @@ def test_heavy_first_launch(gpu, name, monkeypatch):
     assert sam == open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read()
 
 
+@pytest.mark.parametrize("name", ["heavy", "ont20k", "pb"])
+def test_second_run_with_large_node_arena(gpu, name, monkeypatch):
+    """reads that overflow the match-node arena of their slot (a kvec in the reference, src/cly.c:2532-2819) are
+    run again in the large-arena slots; a tiny first-level arena forces that path"""
+    D, idx, ctx = gpu
+    monkeypatch.setenv("DSB_SMS_CAP", "96")
+    hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))
+    assert ctx.timing().n_retry > 0
+    assert sam == open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read()
+    monkeypatch.delenv("DSB_SMS_CAP")
+    hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))
+    assert ctx.timing().n_retry == 0
+    assert sam == open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read()
+
+
 def test_rank64_layout_on_device(demo, monkeypatch):
     """the 64-bit superblock rank layout (indexes beyond 2^32 BWT symbols), forced on for the demo index"""
     import desamba_amd as D
