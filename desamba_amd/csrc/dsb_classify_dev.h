@@ -1751,10 +1751,35 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 			wrapped[u] = dsb_ballot64((int)(A[u] | B[u] | C[u]) < 0) != 0;
 		}
 		if (hi - DSB_DP_UNROLL * DSB_WAVE >= 0) { DSB_FETCH_PREDS(nx, hi - DSB_DP_UNROLL * DSB_WAVE) }
+		// Chunks without wrapped coordinates (all but a few) are first judged straight through, with no test for the
+		// distance cut between the groups; only a node that meets its cut in this pass is judged again in order.
+		const bool plain = wnm == 0 && !(wrapped[0] | wrapped[1] | wrapped[2] | wrapped[3]);
+		uint32_t redo = ~stopm & ((1u << DSB_DPB) - 1u);
+		if (plain) {
+#pragma unroll
+			for (int j = 0; j < DSB_DPB; j++) {
+				if ((stopm >> j) & 1u) continue;
+				int tb = -2147483647 - 1; bool anyb = false;
+#pragma unroll
+				for (int u = 0; u < DSB_DP_UNROLL; u++) {
+					const int oq = (MODE == 2) ? (int)(nq[j] - A[u]) : (int)(A[u] - nq[j]);
+					const int ot = (MODE == 2) ? (int)(nt[j] - B[u]) : (int)(B[u] - nt[j]);
+					const int indel = (int)(D[u] - dl[j]); const int ai = ABSV(indel);
+					int ovl = MAXV(oq, ot); ovl = MAXV(ovl, 0);
+					const bool skip = ovl > 6;
+					const bool brk = !skip & ((MODE == 2) ? (lt[j] + 600 < C[u]) : (C[u] < lt[j]));
+					const int ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3)) - ovl;
+					anyb |= brk;
+					if (!skip & !brk & (ai <= 200) & (ns > tb)) tb = ns;
+				}
+				if (dsb_ballot64(anyb) == 0) { if (tb > best[j]) best[j] = tb; redo &= ~(1u << j); }
+			}
+		}
+		preds += DSB_DP_UNROLL * DSB_WAVE * (uint32_t)__builtin_popcount(~stopm & ((1u << DSB_DPB) - 1u));
+		if (redo)
 #pragma unroll
 		for (int j = 0; j < DSB_DPB; j++) {
-			if ((stopm >> j) & 1u) continue;
-			preds += DSB_DP_UNROLL * DSB_WAVE;
+			if (!((redo >> j) & 1u)) continue;
 #pragma unroll
 			for (int u = 0; u < DSB_DP_UNROLL; u++) {
 				if ((stopm >> j) & 1u) break;

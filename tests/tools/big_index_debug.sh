@@ -10,6 +10,6 @@ if [ ! -f $I/deSAMBA.ref_p ]; then
 	rm -f $D/kmer.srt; echo "index built"
 fi
 tools/readsim $I /dev/shm/y.fq $N 50000 0.15 1 ont > /dev/null 2>&1
-DSB_INDEX=$I python3 tools/prof_generic.py /dev/shm/y.fq 2 2>&1 | tail -2
+DSB_INDEX=$I python3 tools/prof_generic.py /dev/shm/y.fq 2 2>&1 | tail -1
 DSB_INDEX=$I DSB_DEBUG=1 timeout -k 10 300 python3 tools/prof_generic.py /dev/shm/y.fq 1 2>&1 | grep -v "still running\|   slot" | tail -8
 rm -f /dev/shm/y.fq

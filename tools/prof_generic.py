@@ -13,6 +13,3 @@ tm = ctx.timing()
 res = ctx.fetch(strict=False)
 bad = sum(1 for i in range(n) if res.reads[i].status); mapped = sum(1 for i in range(n) if res.reads[i].n)
 print("ms encode %.2f probe %.2f classify %.2f total %.2f | %.0f reads/s %.3f Gbp/s | mapped %d status!=0 %d second-run %d" % (tm.encode_ms, tm.seed_probe_ms, tm.classify_ms, tm.total_ms, n / (tm.total_ms / 1e3), tm.bases / (tm.total_ms / 1e3) / 1e9, mapped, bad, tm.n_retry))
-slow = sorted(((res.reads[i].fast >> 1, i) for i in range(n)), reverse=True)[:8]          # wave time per read, microseconds
-print("slowest reads (ms, index, hits): " + ", ".join("%.1f #%d h%d" % (t / 1e3, i, res.reads[i].n) for t, i in slow)
-      + " | sum of wave time %.1f s" % (sum(res.reads[i].fast >> 1 for i in range(n)) / 1e6))
