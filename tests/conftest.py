@@ -32,6 +32,17 @@ def demo(built):
 
 
 @pytest.fixture(scope="session")
+def strain(built):
+    """data/strain: a second, synthetic index (strains + tandem repeats, tools/make_strain_index.sh) and 96 ONT reads
+    simulated from it; the expected SAM (reference, UB-pinned build) is tests/golden/strain/reads.ubfree.sam."""
+    d = os.path.join(ROOT, "data", "strain")
+    subprocess.check_call([os.path.join(ROOT, "tools", "make_strain_index.sh"), d], stdout=subprocess.DEVNULL)
+    fq = os.path.join(d, "reads.fq")
+    assert md5_file(fq) == open(os.path.join(GOLDEN, "strain", "reads.fq.md5")).read().strip(), "strain read set differs from the one the golden SAM was made from"
+    return {"index": os.path.join(d, "index"), "fastq": fq, "sam": os.path.join(GOLDEN, "strain", "reads.ubfree.sam")}
+
+
+@pytest.fixture(scope="session")
 def oracle(demo):
     import oracle_lib
     return oracle_lib.Oracle(demo["index"])

@@ -18,7 +18,17 @@ def run(cmd):
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 
 
+def strain():
+    """tests/golden/strain: the second index (tools/make_strain_index.sh) and the reference's SAM for its 96 reads"""
+    d = os.path.join(ROOT, "data", "strain"); out = os.path.join(ROOT, "tests", "golden", "strain")
+    os.makedirs(out, exist_ok=True)
+    subprocess.check_call([os.path.join(ROOT, "tools", "make_strain_index.sh"), d])
+    run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", os.path.join(d, "index"), os.path.join(d, "reads.fq"), "-o", os.path.join(out, "reads.ubfree.sam")])
+    open(os.path.join(out, "reads.fq.md5"), "w").write(hashlib.md5(open(os.path.join(d, "reads.fq"), "rb").read()).hexdigest() + "\n")
+
+
 def main():
+    strain()
     subprocess.check_call([os.path.join(ROOT, "tools", "make_demo_index.sh"), DEMO])
     idx = os.path.join(DEMO, "index")
     sim = os.path.join(ROOT, "tools", "readsim")

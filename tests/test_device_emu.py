@@ -68,3 +68,16 @@ def test_rank64_layout_in_device_code(oracle, demo, monkeypatch):
     e = emu_lib.Emu(demo["index"])
     for name in ("ont20k", "wrapq", "appc"):
         _cmp(e, oracle, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))
+
+
+def test_second_index(strain, monkeypatch):
+    """device code on the strain index: the heaviest reads of the set (right extensions across tandem repeats, up to
+    67 k match nodes: beyond a slot's first-level arena, so the 1-lane harness gets the large one) and 16 others"""
+    import emu_lib, oracle_lib, desamba_amd as D
+    monkeypatch.setenv("DSB_EMU_SMS_CAP", "4000000")
+    emu = emu_lib.Emu(strain["index"]); ora = oracle_lib.Oracle(strain["index"])
+    recs = D.read_fastq(strain["fastq"])
+    for i in [75, 23, 90] + list(range(16)):
+        name, seq, q = recs[i]
+        assert emu.classify(seq, 15000) == ora.classify(seq, 15000), name
+        assert emu.n_anc() == ora.n_anc(), name

@@ -245,3 +245,16 @@ def test_upload_fastq_equals_upload(gpu, demo):
     ctx.run(); b = ctx.sam(ctx.fetch())
     assert a == b
     assert ctx.upload_fastq(demo["fastq"], 1200, 1000) == 37
+
+
+def test_second_index_golden(strain):
+    """a second index (synthetic strains + tandem repeats, 4 Mbp): byte-identical SAM against the reference's, with
+    reads whose match-node list outgrows their slot's arena going through the second run by themselves"""
+    import desamba_amd as D
+    idx = D.Index(strain["index"]); ctx = D.Ctx(idx, 0)
+    try:
+        hits, sam = classify_all(D, ctx, D.read_fastq(strain["fastq"]))
+        assert ctx.timing().n_retry > 0
+        assert sam == open(strain["sam"], "rb").read()
+    finally:
+        ctx.close(); idx.close()

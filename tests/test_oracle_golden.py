@@ -67,3 +67,13 @@ def test_against_live_reference(demo, oracle, tmp_path):
                           stderr=subprocess.DEVNULL)
     oracle.classify_file(str(fq), str(ora_out), threads=2)
     assert sam_lines(str(ora_out)) == sam_lines(str(ref_out))
+
+
+def test_second_index_golden(strain, tmp_path):
+    """the oracle on a second index (synthetic strains + tandem repeats: several near-equal targets per read, match-node
+    lists of tens of thousands of nodes) against the reference's SAM for the same reads"""
+    import oracle_lib
+    ora = oracle_lib.Oracle(strain["index"])
+    out = str(tmp_path / "strain.sam")
+    ora.classify_file(strain["fastq"], out)
+    assert open(out, "rb").read() == open(strain["sam"], "rb").read()

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Deterministic synthetic reference collection for index-size experiments:
-`synth_ref.py <out.fa> <Mbp> [seed]` writes about <Mbp> million bases of FASTA: random base genomes of
+`synth_ref.py <out.fa> <Mbp> [seed [tandem_hi unit_hi]]` writes about <Mbp> million bases of FASTA: random base genomes of
 60-400 kbp, each followed by 0-3 strains that differ from it by 0.5-4 % substitutions and a few short
 indels (so the de Bruijn graph branches the way a RefSeq collection does), a pool of 1-4 kbp mobile elements
-copied into random genomes, and short tandem repeats.  Headers follow the reference's
+copied into random genomes, and short tandem repeats (0..tandem_hi-1 per genome, default 3, unit length
+2..unit_hi-1, default 60).  Headers follow the reference's
 `>tid|<n>|ref|<name>` convention.  The index itself is built by the reference binary."""
 import sys
 import numpy as np
@@ -12,6 +13,8 @@ import numpy as np
 def main():
     out, mbp = sys.argv[1], float(sys.argv[2])
     rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+    tandem_hi = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+    unit_hi = int(sys.argv[5]) if len(sys.argv) > 5 else 60
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     mobile = [rng.integers(0, 4, rng.integers(1000, 4000), dtype=np.uint8) for _ in range(64)]
     total, target, gid = 0, int(mbp * 1e6), 0
@@ -34,8 +37,8 @@ def main():
                 m = mobile[int(rng.integers(0, len(mobile)))]
                 p = int(rng.integers(0, n - len(m)))
                 g[p:p + len(m)] = m
-            for _ in range(int(rng.integers(0, 3))):             # tandem repeats
-                unit = rng.integers(0, 4, int(rng.integers(2, 60)), dtype=np.uint8)
+            for _ in range(int(rng.integers(0, tandem_hi))):     # tandem repeats
+                unit = rng.integers(0, 4, int(rng.integers(2, unit_hi)), dtype=np.uint8)
                 ln = int(rng.integers(200, 3000))
                 p = int(rng.integers(0, n - ln))
                 g[p:p + ln] = np.resize(unit, ln)
