@@ -353,6 +353,8 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 DSB_DEFINE_CLASSIFY(k_classify, dsb_g64, 64)
 // the same kernel under a second name for the early launch of the heaviest reads, so that profiles list the two apart
 DSB_DEFINE_CLASSIFY(k_classify_early, dsb_g64, 64)
+// ... and a third one for the second run of reads whose match-node arena overflowed (usually an empty launch)
+DSB_DEFINE_CLASSIFY(k_classify_second, dsb_g64, 64)
 
 // reads whose match-node arena overflowed (and nothing else went wrong) are listed for a second run
 __global__ void k_collect_retry(const DsbReadOut *rout, uint32_t n, uint32_t *list, unsigned int *count)
@@ -725,7 +727,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		// empty list the launch drains at once.  counters: [6] listed reads, [7] work counter of the second run.
 		DsbDevIndex dx2 = c->dx; dx2.sms_cap = c->arena_big.sms_cap;
 		hipLaunchKernelGGL(k_collect_retry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const DsbReadOut *)c->d_rout, (uint32_t)n, c->d_score, c->d_counters + 6);
-		hipLaunchKernelGGL(k_classify, dim3(DSB_RETRY_SLOTS), dim3(64), 0, c->stream, dx2, c->d_rd, 0u, (const unsigned int *)(c->d_counters + 6), (const uint32_t *)c->d_score,
+		hipLaunchKernelGGL(k_classify_second, dim3(DSB_RETRY_SLOTS), dim3(64), 0, c->stream, dx2, c->d_rd, 0u, (const unsigned int *)(c->d_counters + 6), (const uint32_t *)c->d_score,
 		                   c->d_bin, c->d_bits, c->arena_big, c->d_counters + 7, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout,
 		                   (uint32_t *)nullptr, 0u, 0u);
 	}
