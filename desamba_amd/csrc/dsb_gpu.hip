@@ -356,13 +356,14 @@ DSB_DEFINE_CLASSIFY(k_classify_early, dsb_g64, 64)
 // ... and a third one for the second run of reads whose match-node arena overflowed (usually an empty launch)
 DSB_DEFINE_CLASSIFY(k_classify_second, dsb_g64, 64)
 
-// reads whose match-node arena overflowed (and nothing else went wrong) are listed for a second run
+// reads whose match-node arena overflowed are listed for a second run
 __global__ void k_collect_retry(const DsbReadOut *rout, uint32_t n, uint32_t *list, unsigned int *count)
 {
 	uint32_t i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= n) return;
 	int st = rout[i].status & 0xff;
-	if ((st & DSB_ST_SMS_OVF) && !(st & (DSB_ST_TIMEOUT | DSB_ST_OUT_OVF))) list[atomicAdd(count, 1u)] = i;
+	// (a step-budget timeout after the overflow is a consequence of the truncated list: the second run starts from scratch)
+	if ((st & DSB_ST_SMS_OVF) && !(st & DSB_ST_OUT_OVF)) list[atomicAdd(count, 1u)] = i;
 }
 
 // ================================== host side ====================================================
@@ -437,6 +438,14 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 			hipLaunchKernelGGL(k_ek_summary, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream, dx.ek0, n_out, shift, c->d_summ);
 			HIPCHK(hipStreamSynchronize(c->stream));
 			c->summ_shift = shift;
+			if (!lv) {
+				// a summary bit helps only where it is clear: tables filled beyond ~4 % (here: > 90 % of the summary
+				// bits set) answer no window from the summary, so it is dropped again
+				std::vector<uint64_t> hs((n_out + 7) / 8, 0);
+				HIPCHK(hipMemcpy(hs.data(), c->d_summ, n_out, hipMemcpyDeviceToHost));
+				uint64_t ones = 0; for (uint64_t v : hs) ones += (uint64_t)__builtin_popcountll(v);
+				if ((double)ones > 0.9 * 8.0 * (double)n_out) { c->d_summ = nullptr; c->summ_shift = 0; }
+			}
 		}
 	}
 	if ((rc = dev_upload(c, h->fm, h->n_fm, &dx.fm))) return rc;
