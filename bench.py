@@ -190,6 +190,7 @@ def main():
             "kernel_ms_per_step": {"k_encode": encode_ms / steps, "order+early_probe": order_ms / steps, "k_seed_probe": probe_ms / steps,
                                    "k_classify": classify_ms / steps, "wait_for_k_classify_early": tail_ms / steps},
             "reads_in_early_launch": tm.n_early,
+            "reads_in_second_run": tm.n_retry,      # match-node arena outgrown (none on this workload); their time is part of the wait term
             "roofline": roof_cls if dom_is_cls else roof_seed,
             "roofline_seed_lookup": roof_seed,
             "reads_mapped_frac": n_mapped / max(n_up, 1), "reads_with_device_status": n_bad,
