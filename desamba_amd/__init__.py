@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdesamba_amd.so")
+LIB_PATH = os.environ.get("DSB_LIB_PATH", os.path.join(_HERE, "libdesamba_amd.so"))   # override: A/B builds in experiments
 
 DSB_OK, DSB_EIO, DSB_ENODEV, DSB_ENOMEM, DSB_EINVAL, DSB_ECAP = 0, -1, -2, -3, -4, -5
 
