@@ -14,7 +14,8 @@ DSB_OK, DSB_EIO, DSB_ENODEV, DSB_ENOMEM, DSB_EINVAL, DSB_ECAP = 0, -1, -2, -3, -
 
 
 class DsbOpts(C.Structure):
-    _fields_ = [("L_min_matching", C.c_int), ("min_score", C.c_int), ("max_sec_N", C.c_int), ("n_slots", C.c_int)]
+    _fields_ = [("L_min_matching", C.c_int), ("min_score", C.c_int), ("max_sec_N", C.c_int), ("n_slots", C.c_int),
+                ("max_read_len", C.c_uint32), ("max_batch_reads", C.c_uint32), ("input_slots", C.c_int), ("reserved", C.c_int)]
 
 
 class DsbRead(C.Structure):
@@ -45,13 +46,22 @@ class DsbSeed(C.Structure):
 class DsbTiming(C.Structure):
     _fields_ = [("encode_ms", C.c_float), ("seed_probe_ms", C.c_float), ("classify_ms", C.c_float), ("total_ms", C.c_float),
                 ("windows", C.c_uint64), ("probes_t1", C.c_uint64), ("bases", C.c_uint64),
-                ("order_ms", C.c_float), ("tail_ms", C.c_float), ("n_early", C.c_uint32), ("n_retry", C.c_uint32)]
+                ("order_ms", C.c_float), ("tail_ms", C.c_float), ("n_early", C.c_uint32), ("n_retry", C.c_uint32),
+                ("n_regrow", C.c_uint32), ("pad", C.c_uint32),
+                ("n_occ", C.c_uint64), ("n_mem", C.c_uint64), ("n_sa", C.c_uint64), ("ref_bases", C.c_uint64),
+                ("main_occ", C.c_uint64), ("main_mem", C.c_uint64), ("main_sa", C.c_uint64), ("main_ref_bases", C.c_uint64)]
+
+
+class DsbChunk(C.Structure):
+    _fields_ = [("start", C.c_uint64), ("end", C.c_uint64), ("hist_max_before", C.c_uint32), ("rank", C.c_int32)]
 
 
 EXPORTS = ["dsb_index_open", "dsb_index_close", "dsb_index_n_ref", "dsb_index_ref_name", "dsb_index_ref_len", "dsb_index_ek_len",
            "dsb_index_occ_host", "dsb_ctx_create", "dsb_ctx_destroy", "dsb_ctx_reset_history", "dsb_classify_batch",
            "dsb_batch_upload", "dsb_batch_upload_fastq", "dsb_batch_upload_text", "dsb_ctx_set_history", "dsb_host_alloc", "dsb_host_free", "dsb_batch_run", "dsb_batch_fetch", "dsb_batch_timing", "dsb_batch_seeds", "dsb_batch_exist_bits",
-           "dsb_format_sam", "dsb_format_des", "dsb_strerror", "dsb_version"]
+           "dsb_format_sam", "dsb_format_des", "dsb_strerror", "dsb_version",
+           "dsb_device_count", "dsb_ctx_select_slot", "dsb_ctx_create_multi", "dsb_multi_destroy", "dsb_multi_n", "dsb_multi_ctx",
+           "dsb_multi_reset_history", "dsb_multi_classify_batch", "dsb_shard_plan"]
 
 _lib = None
 
@@ -84,6 +94,22 @@ def lib():
     L.dsb_batch_exist_bits.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint32)]
     L.dsb_format_sam.argtypes = [C.c_void_p, C.POINTER(DsbRead), C.POINTER(DsbHit), C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
     L.dsb_format_sam.restype = C.c_long
+    L.dsb_format_des.argtypes = [C.c_void_p, C.POINTER(DsbRead), C.POINTER(DsbReadResult), C.POINTER(DsbHit), C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    L.dsb_format_des.restype = C.c_long
+    L.dsb_batch_upload_text.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_size_t]
+    L.dsb_ctx_set_history.argtypes = [C.c_void_p, C.c_uint32]; L.dsb_ctx_set_history.restype = None
+    L.dsb_host_alloc.argtypes = [C.c_size_t]; L.dsb_host_alloc.restype = C.c_void_p
+    L.dsb_host_free.argtypes = [C.c_void_p]; L.dsb_host_free.restype = None
+    L.dsb_device_count.argtypes = []; L.dsb_device_count.restype = C.c_int
+    L.dsb_ctx_select_slot.argtypes = [C.c_void_p, C.c_int]
+    L.dsb_ctx_create_multi.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.POINTER(DsbOpts), C.POINTER(C.c_void_p)]
+    L.dsb_multi_destroy.argtypes = [C.c_void_p]; L.dsb_multi_destroy.restype = None
+    L.dsb_multi_n.argtypes = [C.c_void_p]
+    L.dsb_multi_ctx.argtypes = [C.c_void_p, C.c_int]; L.dsb_multi_ctx.restype = C.c_void_p
+    L.dsb_multi_reset_history.argtypes = [C.c_void_p]; L.dsb_multi_reset_history.restype = None
+    L.dsb_multi_classify_batch.argtypes = [C.c_void_p, C.POINTER(DsbRead), C.c_size_t, C.POINTER(DsbResult)]
+    L.dsb_shard_plan.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.c_uint64, C.c_uint32, C.POINTER(DsbChunk), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.dsb_index_close.restype = None; L.dsb_ctx_destroy.restype = None; L.dsb_ctx_reset_history.restype = None
     L.dsb_strerror.argtypes = [C.c_int]; L.dsb_strerror.restype = C.c_char_p
     L.dsb_version.restype = C.c_char_p
     _lib = L
@@ -145,9 +171,9 @@ def make_reads(records):
 class Ctx:
     """classify_main's set-up (src/cly_mt.c:518-550) on one GPU."""
 
-    def __init__(self, index, device=0, L_min_matching=170, min_score=64, max_sec_N=5, n_slots=0):
+    def __init__(self, index, device=0, L_min_matching=170, min_score=64, max_sec_N=5, n_slots=0, max_read_len=0, max_batch_reads=0, input_slots=1):
         self.index = index
-        self.opts = DsbOpts(L_min_matching, min_score, max_sec_N, n_slots)
+        self.opts = DsbOpts(L_min_matching, min_score, max_sec_N, n_slots, max_read_len, max_batch_reads, input_slots, 0)
         self.h = C.c_void_p()
         rc = lib().dsb_ctx_create(index.h, device, C.byref(self.opts), C.byref(self.h))
         if rc != 0:
@@ -160,6 +186,21 @@ class Ctx:
 
     def reset_history(self):
         lib().dsb_ctx_reset_history(self.h)
+
+    def set_history(self, max_len_before):
+        lib().dsb_ctx_set_history(self.h, max_len_before)
+
+    def select_slot(self, slot):
+        rc = lib().dsb_ctx_select_slot(self.h, slot)
+        if rc != 0:
+            raise DsbError(rc, "dsb_ctx_select_slot(%d)" % slot)
+
+    def upload_text(self, text_ptr, text_len, seq_off, seq_len, n):
+        """sequences inside one host blob (pinned if it came from dsb_host_alloc): one H2D copy, no per-read gather"""
+        self.reads = None
+        rc = lib().dsb_batch_upload_text(self.h, text_ptr, text_len, seq_off, seq_len, n)
+        if rc != 0:
+            raise DsbError(rc, "dsb_batch_upload_text")
 
     def upload(self, reads):
         self.reads = reads
@@ -213,51 +254,139 @@ class Ctx:
             raise DsbError(rc, "dsb_batch_exist_bits")
         return bytes(buf[:n.value])
 
-    def sam(self, res, full=False):
+    def sam(self, res, full=False, reads=None):
         """Format a whole batch exactly as output_one_result_sam does (src/cly_mt.c:245-344)."""
-        out = []
-        buf = C.create_string_buffer(1 << 20)
-        for i in range(len(self.reads)):
-            rr = res.reads[i]
-            hits = C.cast(C.byref(res.hits.contents, rr.first * C.sizeof(DsbHit)), C.POINTER(DsbHit)) if rr.n else None
-            cap = len(buf)
-            need = 4096 + 700 * rr.n + (2 * self.reads[i].len if full else 0)
-            if need > cap:
-                buf = C.create_string_buffer(need)
-            n = lib().dsb_format_sam(self.index.h, C.byref(self.reads[i]), hits, rr.n, self.opts.max_sec_N, 1 if full else 0, buf, len(buf))
-            if n < 0:
-                raise DsbError(DSB_EINVAL, "dsb_format_sam")
-            out.append(buf.raw[:n])
-        return b"".join(out)
+        return format_sam(self.index, reads if reads is not None else self.reads, res, self.opts.max_sec_N, full)
+
+
+def format_sam(index, reads, res, max_sec_N=5, full=False):
+    out = []
+    buf = C.create_string_buffer(1 << 20)
+    for i in range(len(reads)):
+        rr = res.reads[i]
+        hits = C.cast(C.byref(res.hits.contents, rr.first * C.sizeof(DsbHit)), C.POINTER(DsbHit)) if rr.n else None
+        cap = len(buf)
+        need = 4096 + 700 * rr.n + (2 * reads[i].len if full else 0)
+        if need > cap:
+            buf = C.create_string_buffer(need)
+        n = lib().dsb_format_sam(index.h, C.byref(reads[i]), hits, rr.n, max_sec_N, 1 if full else 0, buf, len(buf))
+        if n < 0:
+            raise DsbError(DSB_EINVAL, "dsb_format_sam")
+        out.append(buf.raw[:n])
+    return b"".join(out)
+
+
+class Multi:
+    """dsb_ctx_create_multi: one context per listed device; classify() shards a batch over them (no collective)."""
+
+    def __init__(self, index, devices, L_min_matching=170, min_score=64, max_sec_N=5, n_slots=0):
+        self.index = index
+        self.opts = DsbOpts(L_min_matching, min_score, max_sec_N, n_slots, 0, 0, 1, 0)
+        ids = (C.c_int * len(devices))(*devices)
+        self.h = C.c_void_p()
+        rc = lib().dsb_ctx_create_multi(index.h, ids, len(devices), C.byref(self.opts), C.byref(self.h))
+        if rc != 0:
+            raise DsbError(rc, "dsb_ctx_create_multi(%r)" % (devices,))
+
+    def close(self):
+        if self.h:
+            lib().dsb_multi_destroy(self.h); self.h = C.c_void_p()
+
+    def reset_history(self):
+        lib().dsb_multi_reset_history(self.h)
+
+    def classify(self, reads, strict=True):
+        res = DsbResult()
+        rc = lib().dsb_multi_classify_batch(self.h, reads, len(reads), C.byref(res))
+        if rc != 0 and (strict or rc != DSB_ECAP):
+            raise DsbError(rc, "dsb_multi_classify_batch")
+        return res
+
+
+def shard_plan(lengths, world, chunk_bases=0, chunk_reads=0):
+    """dsb_shard_plan -> list of (start, end, hist_max_before, rank)"""
+    n = len(lengths)
+    arr = (C.c_uint32 * max(n, 1))(*lengths)
+    cnt = C.c_size_t()
+    lib().dsb_shard_plan(arr, n, world, chunk_bases, chunk_reads, None, 0, C.byref(cnt))
+    out = (DsbChunk * max(cnt.value, 1))()
+    rc = lib().dsb_shard_plan(arr, n, world, chunk_bases, chunk_reads, out, cnt.value, C.byref(cnt))
+    if rc != 0:
+        raise DsbError(rc, "dsb_shard_plan")
+    return [(out[i].start, out[i].end, out[i].hist_max_before, out[i].rank) for i in range(cnt.value)]
 
 
 def read_fastq(path, limit=None):
-    """Plain-text FASTQ/FASTA reader with kseq's record rules (src/lib/utils.c:939-977)."""
-    recs = []
+    """Plain-text FASTQ/FASTA reader with the record rules of the reference's kseq_read (src/lib/utils.c:939-977; the
+    OLD kseq: '\\r' stays in sequence and quality, the first character of a sequence line is data even if it is '\\n',
+    quality is read in whole lines).  Returns (name, seq, qual) tuples; records with a quality string of the wrong
+    length are dropped as read_reads (src/cly_mt.c:42-56) drops them."""
     with open(path, "rb") as f:
         data = f.read()
-    lines = data.split(b"\n")
-    i = 0
-    while i < len(lines):
-        ln = lines[i]
-        if not ln or ln[0:1] not in (b"@", b">"):
-            i += 1; continue
-        fq = ln[0:1] == b"@"
-        name = ln[1:].split()[0] if len(ln) > 1 and ln[1:].split() else b""
-        i += 1
-        seq = []
-        while i < len(lines) and lines[i][0:1] not in (b">", b"+", b"@"):
-            seq.append(lines[i].rstrip(b"\r")); i += 1
-        seq = b"".join(seq)
-        qual = None
-        if fq and i < len(lines) and lines[i][0:1] == b"+":
-            i += 1
-            q = []
-            ql = 0
-            while i < len(lines) and ql < len(seq):
-                q.append(lines[i].rstrip(b"\r")); ql += len(q[-1]); i += 1
-            qual = b"".join(q)
-        recs.append((name, seq, qual))
-        if limit and len(recs) >= limit:
+    return parse_fastq(data, limit)
+
+
+def parse_fastq(data, limit=None):
+    recs = []
+    n = len(data)
+    p = 0
+    last = 0
+    space = b" \t\n\v\f\r"
+    while True:
+        if last == 0:
+            a, b = data.find(b">", p), data.find(b"@", p)
+            if a < 0 and b < 0:
+                break
+            p = min(x for x in (a, b) if x >= 0) + 1
+        q = p
+        while q < n and data[q] not in space:
+            q += 1
+        if q >= n and q == p:
             break
+        name = data[p:q]
+        if q < n and data[q:q + 1] != b"\n":
+            e = data.find(b"\n", q)
+            q = n if e < 0 else e
+        p = min(q + 1, n) if q < n else n
+        seq = []
+        c = -1
+        while True:
+            if p >= n:
+                c = -1
+                break
+            c = data[p]
+            if c in b">+@":
+                p += 1
+                break
+            e = data.find(b"\n", p + 1)
+            e = n if e < 0 else e
+            seq.append(data[p:e])
+            p = min(e + 1, n)
+        seq = b"".join(seq)
+        last = c if c in (ord(">"), ord("@")) else 0
+        qual = None
+        bad = False
+        if c == ord("+"):
+            e = data.find(b"\n", p)
+            if e < 0:
+                break
+            p = e + 1
+            ql = []
+            tot = 0
+            while True:
+                if p >= n:
+                    break
+                e = data.find(b"\n", p)
+                e = n if e < 0 else e
+                ql.append(data[p:e]); tot += e - p
+                p = min(e + 1, n)
+                if tot >= len(seq):
+                    break
+            qual = b"".join(ql)
+            last = 0
+            bad = len(qual) != len(seq)
+        if not bad:
+            recs.append((name, seq, qual))
+            if limit and len(recs) >= limit:
+                break
     return recs

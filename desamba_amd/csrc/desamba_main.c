@@ -1,15 +1,18 @@
 /* `deSAMBA classify` drop-in (host side in C, calling the HIP library through its C-ABI).
  * Mirrors classify_main / classify_usage (src/cly_mt.c:448-562): same options, same output,
  * same stderr progress lines; print-and-exit error convention lives only here.
- * Extra option: -g INT  GPU (device id) to run on [0].
+ * Extra option: -g LIST  GPUs to run on: "0", "0,1,2", "all"; a device may be listed twice [0].
  *
  * The reference's pipeline (kt_pipeline, src/cly_mt.c:393-410: read -> classify -> write, one batch
  * per step) is kept as three kinds of threads around two device contexts:
  *   reader   fills pinned buffers with raw (plain or gzip) FASTQ/FASTA text and finds the records in
  *            place (record rules of kseq_read, src/lib/utils.c:939-977): no per-read copies; the buffer
  *            goes to the device as it is (dsb_batch_upload_text)
- *   2 x GPU  one dsb_ctx each on the same device, so that the upload of one batch overlaps the kernels
- *            of the other; max_read_l (src/cly.c:2958) travels with the batch as a prefix maximum
+ *   GPU      per listed device two dsb_ctx (they share the index staged in that device's HBM), one host thread
+ *            each, so that the upload of one batch overlaps the kernels of another; batches are dealt to
+ *            whichever worker is free -- the kt_for of the reference (src/cly_mt.c:389, src/lib/kthread.c:61-86)
+ *            with GPUs for threads; max_read_l (src/cly.c:2958), the only cross-read state, travels in the
+ *            batch header as the prefix maximum of read length (dsb_ctx_set_history)
  *   writer   formats SAM in input order
  */
 #define _GNU_SOURCE
@@ -27,8 +30,10 @@
 #include <zlib.h>
 #include "desamba_amd.h"
 
-#define N_BATCH 4                     /* batch buffers in flight */
-#define N_GPU_CTX 2
+#define MAX_DEV 16
+#define CTX_PER_DEV 2                 /* contexts per device: the upload of one batch overlaps the kernels of the other */
+#define MAX_CTX (MAX_DEV * CTX_PER_DEV)
+#define N_BATCH (MAX_CTX + 2)          /* batch buffers (allocated on first use; n_ctx + 2 of them are put in circulation) */
 #define MAX_BATCH_READS (1u << 23)
 
 static double now(void);
@@ -39,7 +44,7 @@ typedef struct {
 	char *text; size_t cap, len;                      /* pinned; the records of this batch lie in text[0, len) */
 	size_t n, cap_n;
 	uint64_t *seq_off, *name_off, *qual_off; uint32_t *seq_len; unsigned char *has_qual;
-	uint32_t hist_before;                             /* longest read of this file before this batch */
+	uint32_t hist_before;                             /* longest read of the run before this batch */
 	long seqno;
 	dsb_read_result *rr; dsb_hit *hits; size_t cap_rr, cap_hits, n_hits;
 } batch_t;
@@ -73,91 +78,22 @@ static void batch_reserve(batch_t *b, size_t n)
 	b->cap_n = m;
 }
 
-/* ---------------------------------------------------------------- record parser (kseq_read rules) on a buffer */
-/* One record starting at *ppos.  `last` is kseq's look-ahead: the header character ('>' / '@') already consumed by the
- * previous record, or 0.  modify = 0 only measures (nothing is written, so an incomplete record can be re-read later with
- * more data); modify = 1 joins multi-line sequence / quality in place and drops '\r'.
- * returns 1 record found, 0 more data needed, -1 end of input, -2 truncated quality */
-typedef struct { size_t name_off, name_end, seq_off, seq_len, qual_off; int has_qual, plain; size_t next; int next_last; } rec_t;
-static int g_chunk_has_cr = 1;    /* reader thread only: does the current buffer hold any '\r' at all? (one memchr per buffer instead of one per line) */
-static size_t copy_line(char *t, size_t w, size_t p, size_t len, int modify, int *plain)
-{	/* append t[p, p+len) minus '\r' at t[w]; returns the number of characters appended */
-	if (!g_chunk_has_cr || !memchr(t + p, '\r', len)) { if (modify && w != p) memmove(t + w, t + p, len); return len; }
-	*plain = 0;
-	size_t k = 0;
-	for (size_t i = 0; i < len; i++) if (t[p + i] != '\r') { if (modify) t[w + k] = t[p + i]; k++; }
-	return k;
-}
-static int scan_record(char *t, size_t pos, size_t end, int eof, int last, int modify, rec_t *r)
-{
-	size_t p = pos; int c;
-	r->next = pos; r->next_last = last;
-	if (last == 0) {
-		while (p < end && t[p] != '>' && t[p] != '@') p++;
-		if (p >= end) { r->next = end; r->next_last = 0; return eof ? -1 : 0; }
-		p++;
-	}
-	r->plain = 1;
-	r->name_off = p;
-	while (p < end && !isspace((unsigned char)t[p])) p++;
-	if (p >= end) { if (!eof) return 0; if (p == r->name_off) return -1; }
-	r->name_end = p;
-	c = p < end ? (unsigned char)t[p] : -1;
-	if (c != -1 && c != '\n') { char *e = memchr(t + p, '\n', end - p); if (!e) { if (!eof) return 0; p = end; c = -1; } else p = (size_t)(e - t); }
-	if (c != -1) p++;                                                     /* past the newline of the header line */
-	r->seq_off = p; r->seq_len = 0; size_t w = p; int first = 1;
-	for (;;) {
-		if (p >= end) { if (!eof) return 0; c = -1; break; }
-		c = (unsigned char)t[p];
-		if (c == '>' || c == '+' || c == '@') { p++; break; }
-		if (c == '\n') { p++; continue; }
-		char *e = memchr(t + p, '\n', end - p);
-		if (!e && !eof) return 0;
-		size_t le = e ? (size_t)(e - t) : end, len = le - p;
-		if (first) { r->seq_off = p; w = p; first = 0; } else r->plain = 0;
-		size_t k = copy_line(t, w, p, len, modify, &r->plain);
-		w += k; r->seq_len += k;
-		p = e ? le + 1 : end;
-	}
-	r->has_qual = 0; r->qual_off = 0; r->next_last = 0;
-	if (c == '>' || c == '@') r->next_last = c;
-	if (c == '+') {
-		char *e = memchr(t + p, '\n', end - p);
-		if (!e) return eof ? -2 : 0;
-		p = (size_t)(e - t) + 1;
-		size_t ql = 0, qw = p; int qfirst = 1; r->qual_off = p;
-		while (ql < r->seq_len) {
-			if (p >= end) { if (!eof) return 0; break; }
-			if (t[p] == '\n' || t[p] == '\r') { p++; continue; }
-			e = memchr(t + p, '\n', end - p);
-			if (!e && !eof) return 0;
-			size_t le = e ? (size_t)(e - t) : end, len = le - p, want = r->seq_len - ql;
-			if (len > want) {	/* kseq stops in the middle of the line; '\r' inside does not count */
-				size_t i = 0, k = 0;
-				if (qfirst) { r->qual_off = p; qw = p; qfirst = 0; } else r->plain = 0;
-				for (; i < len && k < want; i++) if (t[p + i] != '\r') { if (modify) t[qw + k] = t[p + i]; k++; } else r->plain = 0;
-				qw += k; ql += k; p += i;
-				break;
-			}
-			if (qfirst) { r->qual_off = p; qw = p; qfirst = 0; } else r->plain = 0;
-			size_t k = copy_line(t, qw, p, len, modify, &r->plain);
-			qw += k; ql += k;
-			p = e ? le + 1 : end;
-		}
-		if (ql != r->seq_len) return -2;
-		r->has_qual = 1; r->next_last = 0;
-	}
-	r->next = p;
-	return 1;
-}
+/* ---------------------------------------------------------------- record parser: dsb_fastq_scan.h (the rules of the
+ * reference's kseq_read, src/lib/utils.c:939-977, incl. its treatment of '\r' and of empty lines) */
+#include "dsb_fastq_scan.h"
+typedef dsb_rec_t rec_t;
+#define scan_record dsb_scan_record
 
 /* ---------------------------------------------------------------- shared state */
 typedef struct {
 	int argc; char **argv; int first_file;
-	dsb_index *idx; dsb_ctx *ctx[N_GPU_CTX]; dsb_opts o; int full; FILE *out;
+	dsb_index *idx; dsb_multi *multi; dsb_ctx *ctx[MAX_CTX]; dsb_opts o; int full; FILE *out;
 	queue_t free_q, parsed_q, done_q;
 	size_t batch_cap; unsigned long total;
 	int pageable;                                     /* batch buffers from malloc instead of pinned memory (parser tests without a GPU) */
+	unsigned long n_badqual;                          /* records dropped because their quality string had the wrong length */
+	unsigned long n_status;                           /* reads whose device status stayed non-zero after the second run */
+	int n_ctx;
 } app_t;
 
 typedef struct { int fd; gzFile gz; } src_t;
@@ -272,7 +208,7 @@ static int parse_parallel(batch_t *b, size_t end, int eof, uint32_t *hist, size_
 {
 	static long pmin = -1; static seg_t seg[N_PARSE];
 	if (pmin < 0) { const char *e = getenv("DSB_CLI_PPARSE_MIN"); pmin = e ? atol(e) : (32L << 20); }
-	if (end < (size_t)pmin || g_chunk_has_cr) return 0;
+	if (end < (size_t)pmin) return 0;
 	size_t start[N_PARSE + 1]; int np = 1; start[0] = 0;
 	for (int k = 1; k < N_PARSE; k++) {
 		size_t from = end / N_PARSE * (size_t)k; if (from <= start[np - 1]) continue;
@@ -314,11 +250,14 @@ static void *reader_main(void *arg)
 {
 	app_t *a = arg; long seqno = 0;
 	char *carry = NULL; size_t carry_cap = 0;
+	/* max_read_l (src/cly.c:2958) lives in the per-thread buffers that classify_main allocates once, before the loop
+	 * over the input files (src/cly_mt.c:538-556), and is never reset: the prefix maximum runs over ALL files */
+	uint32_t hist = 0;
 	for (int fi = a->first_file; fi < a->argc; fi++) {
 		src_t src;
 		if (src_open(&src, a->argv[fi]) != 0) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", a->argv[fi]); exit(1); }
 		fprintf(stderr, "Processing file: [%s].\n", a->argv[fi]);
-		uint32_t hist = 0; int last = 0, eof = 0; size_t carry_len = 0;
+		int last = 0, eof = 0; size_t carry_len = 0;
 		while (!eof || carry_len) {
 			batch_t *b = q_pop(&a->free_q);
 			if (!b->text) { b->text = a->pageable ? malloc(a->batch_cap + 64) : dsb_host_alloc(a->batch_cap + 64); b->cap = a->batch_cap; if (!b->text) die("[classify] cannot allocate a pinned batch buffer"); }
@@ -330,13 +269,12 @@ static void *reader_main(void *arg)
 			size_t end = carry_len + got;
 			if (!eof && end < b->cap) eof = 1;
 			b->n = 0; b->hist_before = hist; b->seqno = seqno++;
-			g_chunk_has_cr = memchr(b->text, '\r', end) != NULL;
 			size_t pos = 0; rec_t r;
 			if (last == 0 && parse_parallel(b, end, eof, &hist, &pos)) goto parsed;
 			for (;;) {
 				int rc = scan_record(b->text, pos, end, eof, last, 0, &r);
 				if (rc == 1 && !r.plain) rc = scan_record(b->text, pos, end, eof, last, 1, &r);
-				if (rc == -2) { fprintf(stderr, "[read_reads] truncated quality string in '%s'\n", a->argv[fi]); exit(1); }
+				if (rc == -2) { a->n_badqual++; pos = r.next; last = r.next_last; continue; }   /* read_reads (src/cly_mt.c:42-56) drops such a record and goes on behind it */
 				if (rc != 1) { pos = rc == -1 ? end : r.next; break; }       /* -1: nothing but junk is left; 0: r.next skips junk, if any */
 				if (r.seq_len > 0xffffffffUL) die("[classify] a read longer than 4 Gbp");
 				batch_reserve(b, b->n + 1);
@@ -407,7 +345,7 @@ static void *format_main(void *arg)
 	for (size_t i = j->lo; i < j->hi; i++) {
 		const dsb_read_result *rr = &b->rr[i];
 		dsb_read rd; rd.name = b->text + b->name_off[i]; rd.seq = b->text + b->seq_off[i]; rd.len = b->seq_len[i];
-		rd.qual = b->has_qual[i] ? b->text + b->qual_off[i] : "";
+		rd.qual = b->has_qual[i] ? b->text + b->qual_off[i] : NULL;
 		if (rr->status) { fprintf(stderr, "[classify] read %s: device arena overflow (status %d)\n", rd.name, rr->status); exit(1); }
 		size_t need = 4096 + 800 * (size_t)rr->n + (a->full == 1 ? 2 * (size_t)rd.len : 0) + strlen(rd.name);
 		if (j->len + need > j->cap) { j->cap = (j->len + need) * 2; j->buf = realloc(j->buf, j->cap); if (!j->buf) die("[classify] out of memory"); }
@@ -452,7 +390,7 @@ static void usage(void)
 	fprintf(stderr, "    -l, INT         minimum matching length, ignored for NGS reads [170]\n");
 	fprintf(stderr, "    -r, INT         max Output number of secondary alignments[5]\n");
 	fprintf(stderr, "    -o, FILE        output results into file [stdout]\n    -s, INT         MIN score[64]\n");
-	fprintf(stderr, "    -g, INT         GPU device id [0]\n");
+	fprintf(stderr, "    -g, LIST        GPU device ids, e.g. 0 or 0,1,2,3 or all [0]\n");
 	fprintf(stderr, "    -f, STR         output format, one of:\n                    - SAM: SAM-like results without SEQ and QUAL and header, default\n");
 	fprintf(stderr, "                    - SAM_FULL: SAM-like results with SEQ and QUAL\n");
 	fprintf(stderr, "                    - DES: smaller format\n                    - DES_FULL: all results are showed, ignore '-r' opinion\n\n");
@@ -463,7 +401,8 @@ static double cputime(void) { struct rusage r; getrusage(RUSAGE_SELF, &r); retur
 
 static int classify_main(int argc, char **argv)
 {
-	static app_t a; int dev = 0, c;
+	static app_t a; int c;
+	int dev[MAX_DEV], n_dev = 1; dev[0] = 0;
 	a.o.L_min_matching = 170; a.o.min_score = 64; a.o.max_sec_N = 5; a.o.n_slots = 0; a.out = stdout;
 	while ((c = getopt(argc, argv, "ht:l:r:f:o:s:g:")) >= 0) {
 		if (c == 'h') { usage(); return 0; }
@@ -472,7 +411,19 @@ static int classify_main(int argc, char **argv)
 		else if (c == 'r') a.o.max_sec_N = atoi(optarg);
 		else if (c == 'o') { a.out = fopen(optarg, "w"); if (!a.out) { fprintf(stderr, "[xopen] fail to open file '%s'\n", optarg); exit(1); } }
 		else if (c == 's') a.o.min_score = atoi(optarg);
-		else if (c == 'g') dev = atoi(optarg);
+		else if (c == 'g') {
+			if (!strcmp(optarg, "all")) { n_dev = dsb_device_count(); if (n_dev < 1) die("[classify] no GPU"); if (n_dev > MAX_DEV) n_dev = MAX_DEV; for (int i = 0; i < n_dev; i++) dev[i] = i; }
+			else {
+				n_dev = 0;
+				for (const char *q = optarg; *q;) {
+					char *e; long v = strtol(q, &e, 10);
+					if (e == q || v < 0 || n_dev >= MAX_DEV) die("[classify] -g takes a comma-separated list of device ids, or `all`");
+					dev[n_dev++] = (int)v; q = *e == ',' ? e + 1 : e;
+					if (*e && *e != ',') die("[classify] -g takes a comma-separated list of device ids, or `all`");
+				}
+				if (n_dev == 0) die("[classify] -g: empty device list");
+			}
+		}
 		else if (c == 'f') {
 			if (!strcmp(optarg, "SAM")) a.full = 0; else if (!strcmp(optarg, "SAM_FULL")) a.full = 1;
 			else if (!strcmp(optarg, "DES")) a.full = 2; else if (!strcmp(optarg, "DES_FULL")) a.full = 3;
@@ -500,31 +451,35 @@ static int classify_main(int argc, char **argv)
 	fprintf(stderr, "loading index\t");
 	int rc = dsb_index_open(index_dir, &a.idx);
 	if (rc) { fprintf(stderr, "\n[load_idx] %s\n", dsb_strerror(rc)); exit(1); }
-	for (int k = 0; k < N_GPU_CTX; k++) {
-		rc = dsb_ctx_create(a.idx, dev, &a.o, &a.ctx[k]);
-		if (rc) { fprintf(stderr, "\n[dsb_ctx_create] %s\n", dsb_strerror(rc)); exit(1); }
-	}
+	/* CTX_PER_DEV contexts per listed device; the contexts of one device share its staged index */
+	int ids[MAX_CTX]; a.n_ctx = 0;
+	for (int k = 0; k < CTX_PER_DEV; k++) for (int d = 0; d < n_dev; d++) ids[a.n_ctx++] = dev[d];
+	rc = dsb_ctx_create_multi(a.idx, ids, a.n_ctx, &a.o, &a.multi);
+	if (rc) { fprintf(stderr, "\n[dsb_ctx_create] %s\n", dsb_strerror(rc)); exit(1); }
+	for (int k = 0; k < a.n_ctx; k++) a.ctx[k] = dsb_multi_ctx(a.multi, k);
 	double t0 = now(), cpu0 = cputime();
 	fprintf(stderr, "Start classify\n");
 	q_init(&a.free_q); q_init(&a.parsed_q); q_init(&a.done_q);
 	static batch_t batches[N_BATCH];
-	for (int i = 0; i < N_BATCH; i++) q_push(&a.free_q, &batches[i]);
-	pthread_t th_r, th_w, th_g[N_GPU_CTX]; gpu_arg_t ga[N_GPU_CTX];
+	for (int i = 0; i < a.n_ctx + 2; i++) q_push(&a.free_q, &batches[i]);
+	pthread_t th_r, th_w, th_g[MAX_CTX]; gpu_arg_t ga[MAX_CTX];
 	pthread_create(&th_r, NULL, reader_main, &a);
-	for (int k = 0; k < N_GPU_CTX; k++) { ga[k].a = &a; ga[k].k = k; pthread_create(&th_g[k], NULL, gpu_main, &ga[k]); }
+	for (int k = 0; k < a.n_ctx; k++) { ga[k].a = &a; ga[k].k = k; pthread_create(&th_g[k], NULL, gpu_main, &ga[k]); }
 	pthread_create(&th_w, NULL, writer_main, &a);
 	pthread_join(th_r, NULL);
-	for (int k = 0; k < N_GPU_CTX; k++) pthread_join(th_g[k], NULL);
+	for (int k = 0; k < a.n_ctx; k++) pthread_join(th_g[k], NULL);
 	q_close(&a.done_q);
 	pthread_join(th_w, NULL);
 	double sec = now() - t0;
 	fprintf(stderr, "%ld sequences processed in %.3fs (%.1f Kseq/m).\n", a.total, sec, a.total / 1.0e3 / (sec / 60));
 	fprintf(stderr, "Classify CPU: %.3f sec\n", cputime() - cpu0);
+	if (a.n_badqual) fprintf(stderr, "[read_reads] %lu record(s) with a quality string of the wrong length were skipped\n", a.n_badqual);
+	if (a.n_status) fprintf(stderr, "[classify] %lu read(s) exceeded a device capacity even in the second run; their records may be incomplete\n", a.n_status);
 	if (a.out != stdout) fclose(a.out); else fflush(stdout);
-	for (int i = 0; i < N_BATCH; i++) dsb_host_free(batches[i].text);
-	for (int k = 0; k < N_GPU_CTX; k++) dsb_ctx_destroy(a.ctx[k]);
+	for (int i = 0; i < N_BATCH; i++) { if (a.pageable) free(batches[i].text); else dsb_host_free(batches[i].text); }
+	dsb_multi_destroy(a.multi);
 	dsb_index_close(a.idx);
-	return 0;
+	return a.n_status ? 1 : 0;
 }
 
 #ifndef DSB_CLI_NO_MAIN

@@ -8,10 +8,9 @@
 //
 // Integer types and expression shapes follow the reference where its results depend on C's
 // signed/unsigned conversions (e.g. src/cly.c:2590-2592); citations are on each function.
-// This header may be included more than once: DSB_GROUP (threads that work on one read: 64 = one
-// wavefront, or a multiple of 64 = a whole workgroup) and DSB_NS (namespace of the instantiation) are set
-// by the includer.  k_classify uses <64>.  (A 512-thread instantiation for reads with a very heavy sparse DP
-// was tried in round 1: its barrier-based reductions cost more than the extra lanes gained; not built.)
+// One wavefront works on one read (DSB_GROUP == 64); DSB_NS names the namespace of the instantiation.
+// (A 512-thread instantiation for reads with a very heavy sparse DP was tried in round 1: its barrier-based
+// reductions cost more than the extra lanes gained; its code paths are gone.)
 #include "dsb_device.h"
 
 #ifndef DSB_GROUP
@@ -49,9 +48,8 @@
 #define D_FORWARD 1u
 #define D_REVERSE 0u
 #define D_U64MAX 0xffffffffffffffffULL
-#define DSB_STEP_LIMIT 20000000u
-#define SPENT(w) (++(w).steps > DSB_STEP_LIMIT)        /* group-uniform code only */
-#define LSPENT(w) (++(w).lsteps > DSB_STEP_LIMIT)      /* per-thread code (fast_island, sdp_visit) */
+#define SPENT(w) (++(w).steps > (w).step_limit)        /* group-uniform code only */
+#define LSPENT(w) (++(w).lsteps > (w).step_limit)      /* per-thread code (fast_island, sdp_visit) */
 #ifdef DSB_HOST_EMU
 #define DSB_CLOCK() 0ULL
 #else
@@ -140,48 +138,7 @@ template <class T> DV T dsb_shfl(T v, int l) { static_assert(sizeof(T) == 4, "32
 #define DSB_RFL(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
 #define DSB_RFL64(v) (((uint64_t)DSB_RFL((uint32_t)((uint64_t)(v) >> 32)) << 32) | (uint64_t)DSB_RFL((uint32_t)(v)))
 #else
-#define DSB_RFL(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
-#define DSB_RFL64(v) (((uint64_t)DSB_RFL((uint32_t)((uint64_t)(v) >> 32)) << 32) | (uint64_t)DSB_RFL((uint32_t)(v)))
-#define dsb_ballot64(p) ((unsigned long long)__syncthreads_or(p))
-DV void wave_sync() { __syncthreads(); }
-// red: DSB_GROUP/64 + 1 words of LDS
-DV int grp_first(uint32_t *red, int tid, bool p)
-{
-	uint64_t m = __ballot(p);
-	if ((tid & 63) == 0) red[tid >> 6] = m ? (uint32_t)((tid & ~63) + __builtin_ctzll(m)) : (uint32_t)DSB_GROUP;
-	__syncthreads();
-	uint32_t r = DSB_GROUP;
-#pragma unroll
-	for (int k = 0; k < DSB_GROUP / 64; k++) r = red[k] < r ? red[k] : r;
-	__syncthreads();
-	return (int)r;
-}
-DV int grp_max_i(uint32_t *red, int tid, int v)
-{
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) { int u = __shfl_xor(v, o); v = u > v ? u : v; }
-	if ((tid & 63) == 0) red[tid >> 6] = (uint32_t)v;
-	__syncthreads();
-	int r = (int)red[0];
-#pragma unroll
-	for (int k = 1; k < DSB_GROUP / 64; k++) r = (int)red[k] > r ? (int)red[k] : r;
-	__syncthreads();
-	return r;
-}
-DV uint32_t grp_excl_scan_u(uint32_t *red, int tid, uint32_t v, uint32_t *total)
-{
-	uint32_t inc = v; const int lane = tid & 63;
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) { uint32_t u = __shfl_up(inc, o); if (lane >= o) inc += u; }
-	if (lane == 63) red[tid >> 6] = inc;
-	__syncthreads();
-	uint32_t base = 0, tot = 0;
-#pragma unroll
-	for (int k = 0; k < DSB_GROUP / 64; k++) { if (k < (tid >> 6)) base += red[k]; tot += red[k]; }
-	__syncthreads();
-	*total = tot;
-	return base + inc - v;
-}
+#error "one wavefront per read: DSB_GROUP must be 64"
 #endif
 
 // words in LDS, addressed as LDS (ds_read / ds_cmpst / ds_add), not through generic pointers
@@ -189,6 +146,22 @@ DV uint32_t grp_excl_scan_u(uint32_t *red, int tid, uint32_t v, uint32_t *total)
 typedef uint32_t lds_u32;
 #else
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+#endif
+
+// Work counters of a launch (the terms of the algorithmic bytes): [0] occ() evaluations, [1] MEM searches
+// (one hash_index pair each), [2] SA-sample + unitig + ref-pos lookups (get_uni), [3] reference bases fetched (get_ref).
+// Four words in LDS per wavefront, flushed to global memory when the wavefront leaves the kernel.  A function counts in a
+// register and adds once when it returns; `uni` marks code that all lanes run redundantly (lane 0 counts for them).
+#ifdef DSB_HOST_EMU
+struct Cnt { uint32_t *c; uint32_t uni; };
+DV void cnt_add(const Cnt &k, int which, uint32_t v) { if (k.c) k.c[which] += v; }
+#else
+struct Cnt { lds_u32 *c; uint32_t uni; };
+DV void cnt_add(const Cnt &k, int which, uint32_t v)
+{
+	if (k.uni && __lane_id() != 0) return;
+	__hip_atomic_fetch_add(k.c + which, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 #endif
 
 // the index descriptor lives in LDS (k_classify copies its kernel argument there): typed so that x->field is a ds_read
@@ -206,6 +179,7 @@ struct WCtx {
 	uint8_t *bin; uint32_t L;
 	DsbSeed *seeds;
 	DsbAnchor *anc, *anc_tmp; uint32_t n_anc, anc_cap;
+	uint32_t anc_cap_main, hit_cap, step_limit;   // capacities of this launch's arena (anchors, chains) and its loop budget
 	DsbAnchor *lane_anc; uint64_t *lane_spset; uint32_t *top_idx;   // per-lane scratch of the island-parallel fast_classify
 	DsbChain *hit, *hit_tmp; uint32_t n_hit;
 	DsbSms *sms; uint32_t n_sms;
@@ -222,6 +196,7 @@ struct WCtx {
 	uint4 *ring;               // LDS: the most recent DSB_RING sparse-DP nodes of sdp_right/left ({t_pos,q_pos,len,score})
 	int status; int max_read_l;
 	int stage; int boosted; uint32_t sp_gen;   // generation of the visited-row sets (monotonic within a launch)
+	Cnt k;                     // work counters (LDS)
 	uint32_t steps, lsteps; volatile uint32_t *dbg; uint64_t tacc[14], tlast, tsub;   // optional host-visible progress words (DSB_DEBUG)
             // loop-iteration budget: every unbounded loop charges it and bails when exhausted
 	SDir sd[2];
@@ -359,8 +334,9 @@ DV void get_ref_wave(const uint8_t *txt, int lane, uint8_t *out, int64_t off, in
 }
 
 // get_uni (src/cly.c:471-496)
-DV int64_t get_uni(DsbXP x, uint64_t bwt_pos, int search_l, uint64_t *global_offset, uint32_t *uni_offset_)
+DV int64_t get_uni(DsbXP x, const Cnt &k, uint64_t bwt_pos, int search_l, uint64_t *global_offset, uint32_t *uni_offset_)
 {
+	cnt_add(k, 2, 1u);
 	const uint64_t sa_ = DSB_G64(x->sa, bwt_pos >> 3);                  // uint2 {x, y}
 	int64_t u = (uint32_t)sa_;
 	uint32_t uni_offset = (uint32_t)(sa_ >> 32) + search_l + 1;
@@ -439,48 +415,51 @@ DV int sp_set_insert(uint64_t node, SpSet &s)
 	}
 }
 
-DV void bwt_single_search(DsbXP x, uint64_t sp, const uint8_t *string, int max_match_len, SpSet &sp_set, DsbMem &m)
+DV void bwt_single_search(DsbXP x, const Cnt &k, uint64_t sp, const uint8_t *string, int max_match_len, SpSet &sp_set, DsbMem &m)
 {
-	uint64_t new_sp, sa_sp = D_U64MAX; int match_len = 0, sa_sp_l = 0;
+	uint64_t new_sp, sa_sp = D_U64MAX; int match_len = 0, sa_sp_l = 0; uint32_t n_occ = 0;
 	while (1) {
 		if (match_len >= max_match_len) break;
 		if ((sp & 7) == 0) { sa_sp = sp; sa_sp_l = 0; } else sa_sp_l--;
 		uint32_t ch = 0xff;
-		new_sp = fm_occ(x, sp, ch); new_sp += x->rank[ch];
+		new_sp = fm_occ(x, sp, ch); new_sp += x->rank[ch]; n_occ++;
 		if (ch != *string) break;
 		match_len++; string--;
-		if (sp_set_insert(new_sp, sp_set) == 0) { m.match_len = -1000; return; }
+		if (sp_set_insert(new_sp, sp_set) == 0) { m.match_len = -1000; cnt_add(k, 0, n_occ); return; }
 		sp = new_sp;
 	}
+	cnt_add(k, 0, n_occ);
 	m.sp = sp; m.match_len = match_len; m.sa_sp = sa_sp; m.sa_sp_l = sa_sp_l;
 }
 
-DV int bwt_MEM_search(DsbXP x, const uint8_t *string, uint64_t pre_v, int max_rst, int l_min_mth, int l_max_mth, SpSet &sp_set, DsbMem *mem)
+DV int bwt_MEM_search(DsbXP x, const Cnt &k, const uint8_t *string, uint64_t pre_v, int max_rst, int l_min_mth, int l_max_mth, SpSet &sp_set, DsbMem *mem)
 {
-	int n_rst = 0;
+	int n_rst = 0; uint32_t n_occ = 0;
+	cnt_add(k, 1, 1u);
 	uint64_t sp = DSB_G64(x->hash_index, pre_v), ep = DSB_G64(x->hash_index, pre_v + 1), new_sp, new_ep;
 	string -= 13; int match_len = 13; uint32_t ch;
 	while (1) {
 		ch = *string; string--;
 		new_sp = x->rank[ch] + fm_occ(x, sp, ch);
-		new_ep = x->rank[ch] + fm_occ(x, ep, ch);
+		new_ep = x->rank[ch] + fm_occ(x, ep, ch); n_occ += 2;
 		if (match_len >= l_min_mth - 1) {
 			if (new_sp + max_rst >= new_ep) break;
-			if (match_len >= l_max_mth) return 0;
+			if (match_len >= l_max_mth) { cnt_add(k, 0, n_occ); return 0; }
 		}
 		if (new_sp + 1 >= new_ep) break;
 		match_len++; sp = new_sp; ep = new_ep;
 	}
+	cnt_add(k, 0, n_occ);
 	if (new_sp >= new_ep) return 0;
 	if (new_sp + 1 == new_ep) {
 		if (sp_set_insert(new_sp, sp_set) == 0) return 0;
-		bwt_single_search(x, new_sp, string, MAXV(0, l_max_mth - match_len), sp_set, mem[n_rst]);
+		bwt_single_search(x, k, new_sp, string, MAXV(0, l_max_mth - match_len), sp_set, mem[n_rst]);
 		mem[n_rst].match_len += match_len + 1;
 		if (mem[n_rst].match_len >= l_min_mth) n_rst++;
 	} else {
 		for (uint64_t c_sp = new_sp; c_sp < new_ep; c_sp++) {
 			if (sp_set_insert(c_sp, sp_set) == 0) continue;
-			bwt_single_search(x, c_sp, string, MAXV(0, l_max_mth - match_len), sp_set, mem[n_rst]);
+			bwt_single_search(x, k, c_sp, string, MAXV(0, l_max_mth - match_len), sp_set, mem[n_rst]);
 			mem[n_rst].match_len += match_len + 1;
 			if (mem[n_rst].match_len >= l_min_mth) n_rst++;
 		}
@@ -516,7 +495,7 @@ DV void lvbuf_init(LvBuf &v, uint8_t pad) {
 // get_new_ed (src/cly.c:629-694).  The right-side query is copied out of the read (with its
 // preceding byte) so that lv_extd works on local strings only; the reference's in-place
 // sentinel write is restored before it returns, so this is equivalent.
-DV void get_new_ed(DsbXP x, uint32_t *e_d, uint32_t *len_, uint32_t *l_mem_ext,
+DV void get_new_ed(DsbXP x, const Cnt &k, uint32_t *e_d, uint32_t *len_, uint32_t *l_mem_ext,
                    int32_t q_off, uint64_t t_off, uint32_t l_read, const uint8_t *q_b, bool is_FWD)
 {
 	LvBuf qb, tb; lvbuf_init(qb, LVPAD_Q); lvbuf_init(tb, LVPAD_T);
@@ -533,6 +512,7 @@ DV void get_new_ed(DsbXP x, uint32_t *e_d, uint32_t *len_, uint32_t *l_mem_ext,
 		qp = q_b + q_off;
 		for (uint32_t k = 0; k < len; k++) q[k] = qp[k];
 	}
+	uint32_t n_rw = len;
 	get_ref_small(t_b, t, t_off, len, !is_FWD);
 	if (len > 0 && t[0] == q[0]) {
 		int mtc;
@@ -542,10 +522,11 @@ DV void get_new_ed(DsbXP x, uint32_t *e_d, uint32_t *len_, uint32_t *l_mem_ext,
 				*l_mem_ext += mtc; max_len -= mtc; len = MINV(12, max_len);
 				if (is_FWD) { q_off -= mtc; t_off -= mtc; for (uint32_t k = 0; k < len; k++) q[k] = q_b[q_off - k]; }
 				else { t_off += mtc; qp += mtc; for (uint32_t k = 0; k < len; k++) q[k] = qp[k]; }
-				get_ref_small(t_b, t, t_off, len, !is_FWD);
+				get_ref_small(t_b, t, t_off, len, !is_FWD); n_rw += len;
 			}
 		} while (mtc > 0);
 	}
+	cnt_add(k, 3, n_rw);
 	if (!is_FWD) q[-1] = qp[-1];          // the byte in front of a string inside the read is a real base
 	t[len] = '#'; q[len] = '$';
 	*e_d = lv_extd(t, len, q, len);
@@ -567,6 +548,7 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 	int64_t uni = -1; uint32_t u_off = 0; uint64_t t_off = 0;
 	uint32_t l_pre, l_suf = 0, d_pre, d_suf = 0; int32_t s = 0, max_s = 0;
 	const int *Q_MEM = x->qmem; const int *Q_LV = x->qlv;
+	const Cnt k = w.k; uint32_t n_occ = 0, n_rw = 0;
 	do {
 		LvBuf qpre, tpre, qsuf, tsuf;
 		lvbuf_init(qpre, LVPAD_Q); lvbuf_init(tpre, LVPAD_T); lvbuf_init(tsuf, LVPAD_T);
@@ -574,32 +556,32 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 		l_pre = MINV(q_off + 1, 12);
 		for (uint32_t k = 0; k < l_pre; k++) q_pre[k] = q_b[q_off - (int)k];
 		int s_l = 0;
-		if (m_r.sa_sp != D_U64MAX) uni = get_uni(x, m_r.sa_sp, m_r.sa_sp_l, &t_off, &u_off);
+		if (m_r.sa_sp != D_U64MAX) uni = get_uni(x, k, m_r.sa_sp, m_r.sa_sp_l, &t_off, &u_off);
 		else {
 			uint32_t ch; uint64_t new_sp;
 			while (1) {
 				if ((b_p & 7) == 0) break;
 				ch = 0xff;
-				new_sp = fm_occ(x, b_p, ch); new_sp += x->rank[ch];
+				new_sp = fm_occ(x, b_p, ch); new_sp += x->rank[ch]; n_occ++;
 				if (ch == 4) break;
 				t_pre[s_l++] = ch; b_p = new_sp;
 				if (s_l >= l_pre) break;
 			}
-			if ((b_p & 7) == 0) uni = get_uni(x, b_p, s_l, &t_off, &u_off);
+			if ((b_p & 7) == 0) uni = get_uni(x, k, b_p, s_l, &t_off, &u_off);
 			else l_pre = s_l;
 		}
 		if (uni >= 0) {
 			if (DSB_G32(x->uni, 2 * uni + 1) < 35) break;
 			l_pre = MINV(l_pre, u_off);
-			get_ref_small(t_b, t_pre, t_off - 1, l_pre, false);
+			get_ref_small(t_b, t_pre, t_off - 1, l_pre, false); n_rw += l_pre;
 		}
 		t_pre[l_pre] = '#'; q_pre[l_pre] = '$';
 		d_pre = lv_extd(t_pre, l_pre, q_pre, l_pre);
 		s = Q_MEM[l_m] + Q_LV[d_pre * 20 + l_pre];
 		if (s < 12 && l_pre == 12 && uni < 0) { s = 0; break; }
 		if (uni < 0) {
-			while (b_p & 7) { uint32_t ch = 0xff; uint64_t o = fm_occ(x, b_p, ch); b_p = o + x->rank[ch]; s_l++; }
-			uni = get_uni(x, b_p, s_l, &t_off, &u_off);
+			while (b_p & 7) { uint32_t ch = 0xff; uint64_t o = fm_occ(x, b_p, ch); b_p = o + x->rank[ch]; s_l++; n_occ++; }
+			uni = get_uni(x, k, b_p, s_l, &t_off, &u_off);
 			if (DSB_G32(x->uni, 2 * uni + 1) < 35) { s = 0; break; }
 		}
 		int32_t q_off_r = q_off + l_m + 1;
@@ -607,7 +589,7 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 		if (l_max_suf != 0) {
 			l_suf = MINV(l_max_suf, 12);
 			const uint8_t *q_suf = q_b + q_off_r;
-			get_ref_small(t_b, t_suf, t_off + l_m, l_suf, true);
+			get_ref_small(t_b, t_suf, t_off + l_m, l_suf, true); n_rw += l_suf;
 			if (t_suf[0] == q_suf[0]) {
 				int mtc;
 				do {
@@ -616,7 +598,7 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 						l_m += mtc;
 						s = Q_MEM[l_m] + Q_LV[d_pre * 20 + l_pre];
 						l_max_suf -= mtc; l_suf = MINV(l_max_suf, 12); q_suf += mtc;
-						get_ref_small(t_b, t_suf, t_off + l_m, l_suf, true);
+						get_ref_small(t_b, t_suf, t_off + l_m, l_suf, true); n_rw += l_suf;
 					}
 				} while (mtc > 0);
 			}
@@ -627,6 +609,7 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 		} else l_suf = d_suf = 0;
 		if (s <= 20 && l_suf == 12) { s = 0; break; }
 	} while (0);
+	cnt_add(k, 0, n_occ); cnt_add(k, 3, n_rw);
 
 	if (s > 0) {
 		AMap a_m = {(uint16_t)l_m, (int16_t)s, (uint8_t)l_pre, (uint8_t)d_pre, (uint8_t)l_suf, (uint8_t)d_suf};
@@ -639,13 +622,13 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 			uint32_t ed_l, ed_r, len_l, len_r, l_m_ext_l = 0, l_m_ext_r;
 			if (ref_search_l || ref_search_r) {
 				if (ref_search_l) {
-					get_new_ed(x, &ed_l, &len_l, &l_m_ext_l, q_off, rp_go + u_off - 1, read_L, q_b, true);
+					get_new_ed(x, k, &ed_l, &len_l, &l_m_ext_l, q_off, rp_go + u_off - 1, read_L, q_b, true);
 					a_m.left_len = len_l; a_m.left_ED = ed_l;
 				}
 				a_m.mtch_len = l_m + l_m_ext_l;
 				if (ref_search_r) {
 					l_m_ext_r = 0;
-					get_new_ed(x, &ed_r, &len_r, &l_m_ext_r, q_off + l_m + 1, rp_go + u_off + l_m, read_L, q_b, false);
+					get_new_ed(x, k, &ed_r, &len_r, &l_m_ext_r, q_off + l_m + 1, rp_go + u_off + l_m, read_L, q_b, false);
 					a_m.rigt_len = len_r; a_m.rigt_ED = ed_r; a_m.mtch_len += l_m_ext_r;
 				}
 				a_m.score = Q_MEM[a_m.mtch_len] + Q_LV[a_m.left_ED * 20 + a_m.left_len] + Q_LV[a_m.rigt_ED * 20 + a_m.rigt_len];
@@ -813,7 +796,7 @@ DV int fast_island(WCtx &w, SDir *s_d, uint32_t read_len, uint32_t seed_idx)
 			int kmer_index = sv.offset + j;
 			string_index = kmer_index + l_ek - 1;
 			uint64_t prefixValue = prefix13(bin_read, string_index);
-			n = bwt_MEM_search(x, bin_read + string_index, prefixValue, 2, 21 - 1, string_index, sp_set, m_r);
+			n = bwt_MEM_search(x, w.k, bin_read + string_index, prefixValue, 2, 21 - 1, string_index, sp_set, m_r);
 			if (n == 0) { j -= 2; continue; }
 			j -= 3;
 			break;
@@ -862,6 +845,7 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 	// island from a counter in LDS when it is done with one -- island walks differ widely in length, and fixed
 	// rounds of 64 would wait for the longest of each round.  Per island: which lane, where in its scratch, how
 	// many anchors, the skip flag, and whether the scratch overflowed (then the island is redone at commit).
+	w.k.uni = 0;                                                   // lanes walk different islands: every lane counts its own work
 	w.anc = w.lane_anc + (size_t)lane * DSB_LANE_ANC_CAP; w.n_anc = 0; w.anc_cap = DSB_LANE_ANC_CAP;
 	w.spset = w.lane_spset + (size_t)lane * DSB_SPHASH;
 	for (;;) {
@@ -879,7 +863,8 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 		if (ovf) { w.status &= ~DSB_ST_ANC_OVF; w.n_anc = start; }
 		info[t] = (uint32_t)lane | (start << 6) | ((w.n_anc - start) << 16) | ((uint32_t)flag << 26) | ((uint32_t)ovf << 27);
 	}
-	w.anc = main_anc; w.n_anc = main_n0; w.anc_cap = DSB_ANC_CAP; w.spset = main_sp;
+	w.k.uni = 1;
+	w.anc = main_anc; w.n_anc = main_n0; w.anc_cap = w.anc_cap_main; w.spset = main_sp;
 	// each lane bumped its own copy of the set generation: continue from the largest so that no lane's stale
 	// entries can look current, and the group-uniform code below sees one value
 	w.sp_gen = (uint32_t)grp_max_i(w.red, lane, (int)w.sp_gen);
@@ -907,7 +892,7 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 				for (int l = 1; l < 64; l++) if (((C >> l) & 1ULL) && !((S >> (l - 1)) & 1ULL)) S |= 1ULL << l;
 				const bool keep = valid && !((S >> lane) & 1ULL);
 				uint32_t total, off = grp_excl_scan_u(w.red, lane, keep ? my_n : 0u, &total);
-				if (main_n + total <= DSB_ANC_CAP) {
+				if (main_n + total <= w.anc_cap_main) {
 					const DsbAnchor *src = w.lane_anc + (size_t)(ri & 0x3fu) * DSB_LANE_ANC_CAP + ((ri >> 6) & 0x3ffu);
 					if (keep) for (uint32_t k = 0; k < my_n; k++) main_anc[main_n + off + k] = src[k];
 					w.n_anc = main_n + total;
@@ -925,7 +910,7 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 				if (sidx == skip_seed) continue;
 				if (ovf_l) f_l = fast_island(w, s_d, read_len, sidx);
 				else {
-					if (w.n_anc + n_l > DSB_ANC_CAP) { w.status |= DSB_ST_ANC_OVF; n_l = 0; }
+					if (w.n_anc + n_l > w.anc_cap_main) { w.status |= DSB_ST_ANC_OVF; n_l = 0; }
 					const DsbAnchor *src = w.lane_anc + (size_t)(ri_l & 0x3fu) * DSB_LANE_ANC_CAP + ((ri_l >> 6) & 0x3ffu);
 					for (uint32_t k = lane; k < n_l; k += DSB_WAVE) main_anc[w.n_anc + k] = src[k];
 					w.n_anc += n_l;
@@ -964,7 +949,7 @@ DN void slow_classify(WCtx &w, SDir *sd, uint32_t read_len)
 			int k_idx = sv_f[i].offset + j;
 			int s_idx = k_idx + l_ek - 1;
 			uint64_t pre_v = prefix13(bin_read, s_idx);
-			int n = bwt_MEM_search(x, bin_read + s_idx, pre_v, 8, min_match_len, s_idx, sp_set, mem_rst + mem_rst_num);
+			int n = bwt_MEM_search(x, w.k, bin_read + s_idx, pre_v, 8, min_match_len, s_idx, sp_set, mem_rst + mem_rst_num);
 			for (int q = mem_rst_num; q < mem_rst_num + n; q++) mem_rst[q].read_offset = k_idx + l_ek - 1 - mem_rst[q].match_len;
 			mem_rst_num += n;
 		}
@@ -982,7 +967,7 @@ DN void slow_classify(WCtx &w, SDir *sd, uint32_t read_len)
 // ---- chaining (src/cly.c:72-112,201-349) ------------------------------------------------------
 DV DsbChain *push_hit(WCtx &w)
 {
-	if (w.n_hit >= DSB_HIT_CAP) { w.status |= DSB_ST_HIT_OVF; return w.hit + DSB_HIT_CAP - 1; }
+	if (w.n_hit >= w.hit_cap) { w.status |= DSB_ST_HIT_OVF; return w.hit + w.hit_cap - 1; }
 	DsbChain *h = w.hit + w.n_hit++;
 	h->primary = 0; h->pri_index = 0;
 	return h;
@@ -1030,8 +1015,8 @@ DV void chain_insert_M2(WCtx &w, int32_t ai)
 // Any stable sort equals glibc's merge sort for a consistent comparator.
 DN uint32_t *stable_sort_keys(WCtx &w, uint32_t n)
 {
-	uint64_t *ka = w.sortkey, *kb = w.sortkey + DSB_ANC_CAP;
-	uint32_t *ia = w.sortidx, *ib = w.sortidx + DSB_ANC_CAP;
+	uint64_t *ka = w.sortkey, *kb = w.sortkey + w.anc_cap_main;
+	uint32_t *ia = w.sortidx, *ib = w.sortidx + w.anc_cap_main;
 	for (uint32_t width = 1; width < n; width <<= 1) {
 		// lanes take whole merges; each merge is independent
 		uint32_t n_merge = (n + 2 * width - 1) / (2 * width);
@@ -1434,7 +1419,7 @@ DV void sdp_emit(const SdpArgsT<P8> &a, int i, P8 c_t, uint32_t q_pos, DsbSms *o
 	}
 }
 template <bool FWD, bool WRITE, class P8>
-DV uint32_t sdp_visit(uint32_t &lsteps, int &st, const SdpArgsT<P8> &a, int i, DsbSms *out, uint32_t out_cap)
+DV uint32_t sdp_visit(uint32_t &lsteps, const uint32_t step_limit, int &st, const SdpArgsT<P8> &a, int i, DsbSms *out, uint32_t out_cap)
 {
 	uint32_t cnt = 0;
 	P8 c_t; uint64_t kmer = 0;
@@ -1460,7 +1445,7 @@ DV uint32_t sdp_visit(uint32_t &lsteps, int &st, const SdpArgsT<P8> &a, int i, D
 	const uint32_t slots = wtab_size(a.n_q);
 	const uint32_t k32 = (uint32_t)kmer, sl0 = wtab_slot(k32, slots);
 	for (uint32_t sl = sl0;;) {
-		if (++lsteps > DSB_STEP_LIMIT) { st |= DSB_ST_TIMEOUT; break; }
+		if (++lsteps > step_limit) { st |= DSB_ST_TIMEOUT; break; }
 		uint32_t e = a.tab[sl];
 		if (e == DSB_WTAB_EMPTY) break;
 		if ((e >> 12) == k32) { if (nc < DSB_SDP_CAND) cand[nc++] = a.q_bg + (e & 0xfffu); else { many = true; break; } }
@@ -1473,7 +1458,7 @@ DV uint32_t sdp_visit(uint32_t &lsteps, int &st, const SdpArgsT<P8> &a, int i, D
 		uint32_t *const bm = a.bm; const uint32_t nbw = (a.n_q + 31) >> 5;
 		for (uint32_t w_ = 0; w_ < nbw; w_++) bm[w_ * DSB_WAVE] = 0;
 		for (uint32_t sl = sl0;;) {
-			if (++lsteps > DSB_STEP_LIMIT) { st |= DSB_ST_TIMEOUT; break; }
+			if (++lsteps > step_limit) { st |= DSB_ST_TIMEOUT; break; }
 			uint32_t e = a.tab[sl];
 			if (e == DSB_WTAB_EMPTY) break;
 			if ((e >> 12) == k32) { uint32_t r = e & 0xfffu; bm[(r >> 5) * DSB_WAVE] |= 1u << (r & 31); }
@@ -1497,11 +1482,11 @@ DN uint32_t sdp_match_t(WCtx &w, const SdpArgsT<P8> a, uint32_t n_sms)
 	uint32_t n_pos = (t_kmer_num - 4 + 3) / 4;                      // i = 4, 8, ... < t_kmer_num
 	// the context lives in memory (it is shared by reference with non-inlined callers): work on copies
 	const int lane = w.lane; uint32_t *const red = w.red; DsbSms *const sms = w.sms; const uint32_t sms_cap = w.x->sms_cap;
-	uint32_t lsteps = w.lsteps, mirror_bad = 0; int st = 0;
+	uint32_t lsteps = w.lsteps, mirror_bad = 0; int st = 0; const uint32_t step_limit = w.step_limit;
 	for (uint32_t g = 0; g < n_pos; g += DSB_WAVE) {
 		uint32_t pI = g + lane; bool valid = pI < n_pos; int i = 4 + 4 * (int)pI;
 		DsbSms keep[DSB_SDP_KEEP];
-		uint32_t cnt = valid ? sdp_visit<FWD, true, P8>(lsteps, st, a, i, keep, DSB_SDP_KEEP) : 0;
+		uint32_t cnt = valid ? sdp_visit<FWD, true, P8>(lsteps, step_limit, st, a, i, keep, DSB_SDP_KEEP) : 0;
 		uint32_t total, off = grp_excl_scan_u(red, lane, cnt, &total);
 		if (total == 0) continue;
 		if (n_sms + total > sms_cap) { st |= DSB_ST_SMS_OVF; break; }
@@ -1512,7 +1497,7 @@ DN uint32_t sdp_match_t(WCtx &w, const SdpArgsT<P8> a, uint32_t n_sms)
 				// the first 64 nodes of the list are mirrored in LDS for the in-register DP of sdp_middle_M2
 				if (a.lnodes && n_sms + off + k < 64u) { uint4 r; r.x = keep[k].t_pos; r.y = keep[k].q_pos; r.z = keep[k].len; r.w = 0; a.lnodes[n_sms + off + k] = r; }
 			}
-		} else sdp_visit<FWD, true, P8>(lsteps, st, a, i, dst, 0xffffffffu);
+		} else sdp_visit<FWD, true, P8>(lsteps, step_limit, st, a, i, dst, 0xffffffffu);
 		if (a.lnodes && dsb_ballot64(cnt > DSB_SDP_KEEP)) mirror_bad = 0x80000000u;
 		n_sms += total;
 		wave_sync();
@@ -1890,7 +1875,7 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 				for (uint32_t k = 8 * lane; k < q_bytes; k += 8 * DSB_WAVE) *reinterpret_cast<uint64_t *>(lq + k) = ld_u64(q_str + q_lo + (int32_t)k);
 				ref = lt; qs = nullptr; lq_st = lq;
 			}
-			get_ref_wave(x->refbin, lane, ref, ref_offset, total_ref_len);
+			get_ref_wave(x->refbin, lane, ref, ref_offset, total_ref_len); cnt_add(Cnt{w.k.c, 1u}, 3, (uint32_t)total_ref_len);
 			for (int k = total_ref_len + lane; k < total_ref_len + 64; k += DSB_WAVE) ref[k] = DSB_TPAD_VAL;   // reads reach <= 58 past the window
 			wave_sync();
 			n_sms = lq_st ? sdp_match_lds(w, n_sms, q_bg, q_ed, lq_st, q_lo, ref, total_ref_len, pre_refoffset + pre_mch, lnodes)
@@ -1982,7 +1967,7 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 				max_search_ref = l_read - c_h->q_ed + 60;
 			} else max_search_ref = t_length - c_t_offset;
 			max_search_ref = MINV(600u, max_search_ref);
-			get_ref_wave(x->refbin, w.lane, ref, c_t_offset + t_offset_global, max_search_ref + 50);
+			get_ref_wave(x->refbin, w.lane, ref, c_t_offset + t_offset_global, max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50);
 			wave_sync();
 			int search_q_ed = (int)best_q + 1000;
 			search_q_ed = MINV((uint32_t)search_q_ed, l_read);
@@ -2061,9 +2046,9 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 			} else max_search_ref = c_t_offset;
 			max_search_ref = MINV(600u, max_search_ref);
 			if (t_offset_global == 0 && c_t_offset < 50 + max_search_ref)
-				get_ref_wave(x->refbin, w.lane, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref), max_search_ref);
+				{ get_ref_wave(x->refbin, w.lane, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref), max_search_ref); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref); }
 			else
-				get_ref_wave(x->refbin, w.lane, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref - 50), max_search_ref + 50);
+				{ get_ref_wave(x->refbin, w.lane, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref - 50), max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50); }
 			wave_sync();
 			int search_q_st = (int)best_q - 1000;
 			search_q_st = MAXV(search_q_st, 0);
@@ -2230,7 +2215,7 @@ DN void detect_primary(WCtx &w, uint32_t read_len)
 DN uint32_t classify_read(WCtx &w, const uint64_t *bitsF, const uint64_t *bitsR)
 {
 	uint32_t read_len = w.L;
-	w.n_anc = 0; w.n_hit = 0; w.n_sms = 0; w.steps = 0; w.lsteps = 0; w.dp_preds = 0; w.boosted = 0;
+	w.n_anc = 0; w.n_hit = 0; w.n_sms = 0; w.steps = 0; w.lsteps = 0; w.dp_preds = 0; w.boosted = 0; w.k.uni = 1;
 	uint32_t fast = 1;
 	if (read_len < 40) return fast;
 	SDir *sd = w.sd;

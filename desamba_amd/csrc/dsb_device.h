@@ -39,6 +39,7 @@ struct DsbDevIndex {
 	const int *qlv;            // [20][20]
 	int filter_min_length, filter_min_score, filter_min_score_LV3;
 	uint32_t sms_cap;          // entries of the per-wave match-node arena (sized from the longest read of the batch)
+	uint32_t step_limit;       // loop budget per read of this launch (DSB_STEP_LIMIT; 16x in the second run)
 };
 
 // ---- per-read records produced on the device -------------------------------------------------
@@ -68,6 +69,7 @@ struct DsbReadOut { uint32_t first, n; int32_t status; uint32_t fast; uint32_t n
 #define DSB_QPAD_R_VAL 5
 #define DSB_TPAD_VAL 4
 #define DSB_ANC_CAP 8192
+#define DSB_STEP_LIMIT 20000000u
 #define DSB_HIT_CAP 4096
 #define DSB_SMS_CAP 16384
 // The extension loops keep every match node of one uninterrupted extension (src/cly.c:2532-2819, a kvec there), so the

@@ -263,10 +263,11 @@ __global__ void __launch_bounds__(1024) k_order(const uint32_t *score, uint32_t 
 // ---- classify kernel: persistent waves, one read each ------------------------------------------
 struct DsbSlotArena {
 	uint8_t *base; size_t stride;                 // per-slot bytes
-	size_t off_seeds, off_anc, off_anc_tmp, off_hit, off_hit_tmp, off_sms, off_kh, off_sc, off_mem, off_spset, off_scorev,
-	       off_sortkey, off_sortidx, off_win, off_lane_anc, off_lane_sp, off_top, off_round;   /* off_kh: unused since the 9-mer tables moved to LDS */
+	size_t off_seeds, off_anc, off_anc_tmp, off_hit, off_hit_tmp, off_sms, off_sc, off_mem, off_spset, off_scorev,
+	       off_sortkey, off_sortidx, off_win, off_lane_anc, off_lane_sp, off_top, off_round;
 	uint32_t max_len;                             // longest read the arena was sized for
 	uint32_t sms_cap;                             // entries of the match-node arena (off_sms)
+	uint32_t anc_cap, hit_cap;                    // entries of the anchor / chain arrays
 };
 
 // One kernel body, two instantiations.  Work items come from an atomic counter; with `list` == nullptr
@@ -277,7 +278,7 @@ struct DsbSlotArena {
 #define DSB_DEFINE_CLASSIFY(KNAME, NS, THREADS)                                                                         \
 __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,   \
         const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout,  \
-        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg, uint32_t item_base, uint32_t slot_base)  \
+        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg, uint32_t item_base, uint32_t slot_base, unsigned long long *work_cnt)  \
 {                                                                                                                       \
 	const int lane = threadIdx.x;                                                                                       \
 	const uint32_t slot_id = slot_base + blockIdx.x;            /* arena slot (and debug row) of this wave */          \
@@ -289,10 +290,12 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	__shared__ __attribute__((aligned(16))) uint32_t lds_wtab[DSB_WTAB_SLOTS];                                                                       \
 	__shared__ uint32_t lds_red[THREADS / 64 + 1];                                                                      \
 	__shared__ unsigned int s_word;                                                                                     \
+	__shared__ uint32_t lds_cnt[4];                                                                                     \
+	if (lane < 4) lds_cnt[lane] = 0;                                                                                    \
 	if (lane == 0) sx = x;                                                                                              \
 	__syncthreads();                                                                                                    \
 	NS::WCtx w;                                                                                                         \
-	w.ring = lds_ring; w.red = lds_red;                                                                                 \
+	w.ring = lds_ring; w.red = lds_red; w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1;                                                                               \
 	w.x = (NS::DsbXP)&sx; w.lane = lane; w.dbg = dbg ? dbg + 4 * slot_id : nullptr;                                             \
 	for (int i = 0; i < 14; i++) w.tacc[i] = 0;                                                                         \
 	w.seeds = (DsbSeed *)(slot + ar.off_seeds);                                                                         \
@@ -307,7 +310,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	w.win_mid = slot + ar.off_win; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;         \
 	w.lane_anc = (DsbAnchor *)(slot + ar.off_lane_anc); w.lane_spset = (uint64_t *)(slot + ar.off_lane_sp);             \
 	w.top_idx = (uint32_t *)(slot + ar.off_top); w.round_info = (uint32_t *)(slot + ar.off_round);                      \
-	w.anc_cap = DSB_ANC_CAP; w.sp_gen = 0;                                                                              \
+	w.anc_cap = ar.anc_cap; w.anc_cap_main = ar.anc_cap; w.hit_cap = ar.hit_cap; w.step_limit = x.step_limit; w.sp_gen = 0;                                                                            \
 	/* visited-row sets are generation-tagged: clear them once per launch */                                          \
 	for (uint32_t i = lane; i < (uint32_t)THREADS * DSB_SPHASH; i += THREADS) w.lane_spset[i] = 0;                       \
 	for (uint32_t i = lane; i < DSB_SPHASH; i += THREADS) w.spset[i] = 0;                                                \
@@ -320,6 +323,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 		unsigned int k = s_word + item_base;                                                                            \
 		__syncthreads();                                                                                                \
 		if (k >= n_items) {   /* every group reaches this: the grid always drains */                                   \
+			if (lane < 4 && lds_cnt[lane]) atomicAdd(work_cnt + lane, (unsigned long long)lds_cnt[lane]);               \
 			if (w.dbg && lane == 0) { w.dbg[0] = 999; for (int i = 0; i < 14; i++) dbg[4 * 65536 + 14 * slot_id + i] += (uint32_t)(w.tacc[i] / 100); } \
 			break;                                                                                                      \
 		}                                                                                                               \
@@ -356,51 +360,171 @@ DSB_DEFINE_CLASSIFY(k_classify_early, dsb_g64, 64)
 // ... and a third one for the second run of reads whose match-node arena overflowed (usually an empty launch)
 DSB_DEFINE_CLASSIFY(k_classify_second, dsb_g64, 64)
 
-// reads whose match-node arena overflowed are listed for a second run
-__global__ void k_collect_retry(const DsbReadOut *rout, uint32_t n, uint32_t *list, unsigned int *count)
+// reads of a finished launch whose status has one of the `mask` bits are listed for another run
+__global__ void k_collect_retry(const DsbReadOut *rout, uint32_t n, uint32_t *list, unsigned int *count, int mask, int clear_n)
 {
 	uint32_t i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= n) return;
 	int st = rout[i].status & 0xff;
-	// (a step-budget timeout after the overflow is a consequence of the truncated list: the second run starts from scratch)
-	if ((st & DSB_ST_SMS_OVF) && !(st & DSB_ST_OUT_OVF)) list[atomicAdd(count, 1u)] = i;
+	if (st & mask) list[atomicAdd(count, 1u)] = i;
+	(void)clear_n;
 }
 
 // ================================== host side ====================================================
-struct dsb_ctx {
-	dsb_index *idx; int device; hipStream_t stream;
-	DsbDevIndex dx;
-	std::vector<void *> dev_allocs;
-	// batch buffers (grown on demand)
-	DsbReadDesc *d_rd; DsbWordDesc *d_wd; char *d_ascii; uint8_t *d_bin; uint64_t *d_pk; uint64_t *d_bits;
-	size_t cap_rd, cap_wd, cap_ascii, cap_bin, cap_pk, cap_bits;
-	DsbReadOut *d_rout; DsbHitOut *d_hout; size_t cap_rout, cap_hout;
-	unsigned int *d_counters;                      // [0] work, [1] hits; +8: u64 p1 counter
-	DsbSlotArena arena; size_t arena_bytes; int n_slots;
-	DsbSlotArena arena_big; int n_slots_big;      // second run of reads whose match-node arena overflowed
-	uint32_t *d_score, *d_order; size_t cap_score, cap_order;
-	unsigned n_early;                              // reads of the last run that went through the early launch
-	uint8_t *d_summ; int summ_shift;               // cache-resident summary of exist table 0 (k_ek_summary); null = off
-	// host mirrors
-	std::vector<DsbReadDesc> h_rd; std::vector<DsbWordDesc> h_wd;
-	std::vector<DsbReadOut> h_rout; std::vector<DsbHitOut> h_hout;
-	std::vector<dsb_read_result> res_reads; std::vector<dsb_hit> res_hits;
-	size_t n_reads; uint64_t n_words_total, total_bases, total_windows; uint32_t max_len;
-	int hist_max;
-	hipEvent_t ev[4]; dsb_timing timing; unsigned long long p1;
-	hipStream_t stream2; hipEvent_t ev_order, ev_heavy, ev_hprobe, ev_cls;   // the LPT ordering kernels (and the heaviest reads) run beside the seed probe
-	uint32_t *dbg_host, *dbg_dev;
-	dsb_opts opts;
-};
+#include <mutex>
+#include <thread>
 
-template <class T> static int dev_upload(dsb_ctx *c, const T *src, size_t n, const T **dst)
+// ---- the index staged in one device's HBM, shared by all contexts of that (index, device) pair -------------
+struct DsbStaged {
+	const dsb_index *idx; int device; int refs;
+	DsbDevIndex dx;                                // filter parameters / per-launch fields are filled in by the ctx
+	std::vector<void *> allocs;
+	uint8_t *d_summ; int summ_shift;               // cache-resident summary of exist table 0 (k_ek_summary); null = off
+};
+static std::mutex g_stage_mu;
+static std::vector<DsbStaged *> g_staged;
+
+template <class T> static int stage_upload(DsbStaged *s, const T *src, size_t n, const T **dst)
 {
 	void *p = nullptr;
 	if (hipMalloc(&p, n * sizeof(T) + 256) != hipSuccess) return DSB_ENOMEM;
+	s->allocs.push_back(p);
 	if (hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return DSB_ENODEV;
-	c->dev_allocs.push_back(p);
 	*dst = (const T *)p;
 	return 0;
+}
+static void stage_free(DsbStaged *s)
+{
+	hipSetDevice(s->device);
+	for (void *p : s->allocs) hipFree(p);
+	delete s;
+}
+static int stage_build(dsb_index *idx, int device, DsbStaged **out)
+{
+	const DsbHostIndex *h = dsb_index_host(idx);
+	DsbStaged *s = new DsbStaged(); s->idx = idx; s->device = device; s->refs = 0; s->d_summ = nullptr; s->summ_shift = 0;
+	DsbDevIndex &dx = s->dx; memset(&dx, 0, sizeof dx);
+	int rc = 0;
+#define ST(call) do { if (!rc) rc = (call); } while (0)
+	ST(stage_upload(s, h->ek0, h->ek_size, &dx.ek0));
+	ST(stage_upload(s, h->ek1, h->ek_size, &dx.ek1));
+	dx.ek_mask = h->ek_mask; dx.ek_len = h->ek_len; dx.single_base_max = h->single_base_max;
+	if (!rc) {
+		// DSB_EK_SUMMARY=0 turns the summary off, 3..8 choose its granularity.  Default: one bit per 64 table bits while that
+		// keeps the summary L2-sized (tables up to 256 MiB -> <= 4 MiB), one per 256 up to 1 GiB tables, none beyond (the
+		// multi-GiB tables of the big indexes are also much fuller: a summary bit would rarely be clear)
+		const char *lv = getenv("DSB_EK_SUMMARY");
+		int shift = lv ? atoi(lv) : (h->ek_size <= (256ull << 20) ? 6 : h->ek_size <= (1024ull << 20) ? 8 : 0);
+		if (shift >= 3 && shift <= 8 && (h->ek_size >> (shift - 3)) >= 4096) {
+			uint64_t n_out = h->ek_size >> shift;              // table bits / 2^shift / 8
+			void *p = nullptr;
+			if (hipMalloc(&p, n_out + 256) != hipSuccess) rc = DSB_ENOMEM;
+			else {
+				s->allocs.push_back(p); s->d_summ = (uint8_t *)p; s->summ_shift = shift;
+				hipLaunchKernelGGL(k_ek_summary, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, 0, dx.ek0, n_out, shift, s->d_summ);
+				if (hipDeviceSynchronize() != hipSuccess) rc = DSB_ENODEV;
+				if (!rc && !lv) {
+					// a summary bit helps only where it is clear: tables filled beyond ~4 % (here: > 90 % of the summary
+					// bits set) answer no window from the summary, so it is dropped again
+					std::vector<uint64_t> hs((n_out + 7) / 8, 0);
+					if (hipMemcpy(hs.data(), s->d_summ, n_out, hipMemcpyDeviceToHost) != hipSuccess) rc = DSB_ENODEV;
+					uint64_t ones = 0; for (uint64_t v : hs) ones += (uint64_t)__builtin_popcountll(v);
+					if ((double)ones > 0.9 * 8.0 * (double)n_out) { s->d_summ = nullptr; s->summ_shift = 0; }
+				}
+			}
+		}
+	}
+	ST(stage_upload(s, h->fm, h->n_fm, &dx.fm));
+	if (h->fm_sb) ST(stage_upload(s, h->fm_sb, h->n_fm_sb * 5, &dx.fm_sb));
+	dx.bwt_len = h->bwt_len; memcpy(dx.rank, h->rank, sizeof dx.rank); dx.dollar_pos = h->dollar_pos; dx.dollar_row = h->dollar_row;
+	ST(stage_upload(s, h->hash_index, ((size_t)1 << 26) + 1, &dx.hash_index));
+	ST(stage_upload(s, (const uint2 *)h->sa, h->sa_size, &dx.sa));
+	ST(stage_upload(s, (const uint2 *)h->uni, h->n_uni + 1, &dx.uni));
+	ST(stage_upload(s, h->refpos, h->n_refpos + 1, &dx.refpos));
+	ST(stage_upload(s, h->refbin, h->n_refbin + 4096, &dx.refbin));
+	ST(stage_upload(s, h->refinfo, h->n_ref, &dx.refinfo));
+	ST(stage_upload(s, h->Q_MEM, (size_t)2000, &dx.qmem));
+	ST(stage_upload(s, &h->Q_LV[0][0], (size_t)400, &dx.qlv));
+#undef ST
+	if (rc) { stage_free(s); return rc; }
+	*out = s;
+	return 0;
+}
+// one staged copy per (index, device): a second context on the same device costs only its arenas
+static int stage_acquire(dsb_index *idx, int device, DsbStaged **out)
+{
+	std::lock_guard<std::mutex> g(g_stage_mu);
+	for (DsbStaged *s : g_staged) if (s->idx == idx && s->device == device) { s->refs++; *out = s; return 0; }
+	DsbStaged *s = nullptr; int rc = stage_build(idx, device, &s);
+	if (rc) return rc;
+	s->refs = 1; g_staged.push_back(s); *out = s;
+	return 0;
+}
+static void stage_release(DsbStaged *s)
+{
+	std::lock_guard<std::mutex> g(g_stage_mu);
+	if (--s->refs > 0) return;
+	for (size_t i = 0; i < g_staged.size(); i++) if (g_staged[i] == s) { g_staged.erase(g_staged.begin() + i); break; }
+	stage_free(s);
+}
+
+// ---- a staged input batch ("input slot"): what dsb_batch_upload* leaves in HBM ------------------------------
+struct InSlot {
+	DsbReadDesc *d_rd = nullptr; char *d_ascii = nullptr; size_t cap_rd = 0, cap_ascii = 0;
+	std::vector<DsbReadDesc> h_rd;
+	size_t n_reads = 0; uint64_t n_words_total = 0, total_bases = 0, total_windows = 0; uint32_t max_len = 0;
+};
+
+struct dsb_ctx {
+	dsb_index *idx = nullptr; int device = 0; hipStream_t stream = nullptr;
+	DsbStaged *staged = nullptr; DsbDevIndex dx;
+	std::vector<InSlot> in; int cur = 0;          // input slots (dsb_ctx_select_slot); upload / run / fetch work on slot `cur`
+	// per-run buffers (grown on demand to the largest staged batch)
+	DsbWordDesc *d_wd = nullptr; uint8_t *d_bin = nullptr; uint64_t *d_pk = nullptr; uint64_t *d_bits = nullptr;
+	size_t cap_wd = 0, cap_bin = 0, cap_pk = 0, cap_bits = 0;
+	DsbReadOut *d_rout = nullptr; DsbHitOut *d_hout = nullptr; size_t cap_rout = 0, cap_hout = 0;
+	unsigned int *d_counters = nullptr;            // u32: [0] work, [1] hits, [2..3] u64 table-1 probes, [4] early work, [6] listed reads, [7] work of the second run, [8] third run list, [9] its work; u64 x 4 at +16 (main launch), +24 (early launch), +32 (second runs): occ, MEM searches, SA lookups, reference bases
+	DsbSlotArena arena; int n_slots = 0;
+	DsbSlotArena arena_big; int n_slots_big = 0;  // second run of reads that outgrew an arena or their loop budget
+	uint32_t *d_score = nullptr, *d_order = nullptr; size_t cap_score = 0, cap_order = 0;
+	unsigned n_early = 0;                          // reads of the last run that went through the early launch
+	std::vector<DsbReadOut> h_rout; std::vector<DsbHitOut> h_hout;
+	std::vector<dsb_read_result> res_reads;
+	int hist_max = 0;
+	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; dsb_timing timing; unsigned long long p1 = 0;
+	hipStream_t stream2 = nullptr; hipEvent_t ev_order = nullptr, ev_heavy = nullptr, ev_hprobe = nullptr, ev_cls = nullptr;   // the heaviest reads run beside the seed probe
+	uint32_t *dbg_host = nullptr, *dbg_dev = nullptr;
+	dsb_opts opts;
+	dsb_ctx() { memset(&dx, 0, sizeof dx); memset(&arena, 0, sizeof arena); memset(&arena_big, 0, sizeof arena_big); memset(&timing, 0, sizeof timing); memset(&opts, 0, sizeof opts); }
+};
+
+extern "C" int dsb_device_count(void)
+{
+	int n = 0;
+	return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_bytes, uint64_t pk_words, uint64_t bit_words);
+
+extern "C" void dsb_ctx_destroy(dsb_ctx *c)
+{
+	if (!c) return;
+	hipSetDevice(c->device);
+	if (c->stream) hipStreamSynchronize(c->stream);
+	if (c->stream2) hipStreamSynchronize(c->stream2);
+	for (InSlot &s : c->in) { hipFree(s.d_rd); hipFree(s.d_ascii); }
+	hipFree(c->d_wd); hipFree(c->d_bin); hipFree(c->d_pk); hipFree(c->d_bits);
+	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->arena_big.base); hipFree(c->d_score); hipFree(c->d_order);
+	if (c->dbg_host) hipHostFree(c->dbg_host);
+	for (int i = 0; i < 4; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+	if (c->ev_order) hipEventDestroy(c->ev_order);
+	if (c->ev_cls) hipEventDestroy(c->ev_cls);
+	if (c->ev_heavy) hipEventDestroy(c->ev_heavy);
+	if (c->ev_hprobe) hipEventDestroy(c->ev_hprobe);
+	if (c->stream2) hipStreamDestroy(c->stream2);
+	if (c->stream) hipStreamDestroy(c->stream);
+	if (c->staged) stage_release(c->staged);
+	delete c;
 }
 
 extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opts, dsb_ctx **out)
@@ -414,78 +538,48 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { fprintf(stderr, "[desamba_amd] device %d is %s, kernels are built for gfx950 only\n", device_id, prop.gcnArchName); return DSB_ENODEV; }
 	dsb_ctx *c = new dsb_ctx();
 	c->idx = idx; c->device = device_id;
-	c->opts.L_min_matching = opts ? opts->L_min_matching : 170; c->opts.min_score = opts ? opts->min_score : 64;
-	c->opts.max_sec_N = opts ? opts->max_sec_N : 5; c->opts.n_slots = opts ? opts->n_slots : 0;
-	HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));   // contexts on one device overlap each other's copies and kernels
-	for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c->ev[i]));
-	HIPCHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)); HIPCHK(hipEventCreate(&c->ev_order)); HIPCHK(hipEventCreate(&c->ev_cls)); HIPCHK(hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_hprobe, hipEventDisableTiming));
-	// stage the index into HBM once
-	const DsbHostIndex *h = dsb_index_host(idx);
-	DsbDevIndex &dx = c->dx; memset(&dx, 0, sizeof dx);
-	int rc;
-	if ((rc = dev_upload(c, h->ek0, h->ek_size, &dx.ek0))) return rc;
-	if ((rc = dev_upload(c, h->ek1, h->ek_size, &dx.ek1))) return rc;
-	dx.ek_mask = h->ek_mask; dx.ek_len = h->ek_len; dx.single_base_max = h->single_base_max;
-	{
-		// DSB_EK_SUMMARY=0 turns the summary off, 3..8 choose its granularity.  Default: one bit per 64 table bits while that
-		// keeps the summary L2-sized (tables up to 256 MiB -> <= 4 MiB), one per 256 up to 1 GiB tables, none beyond (the
-		// multi-GiB tables of the big indexes are also much fuller: a summary bit would rarely be clear)
-		const char *lv = getenv("DSB_EK_SUMMARY");
-		int shift = lv ? atoi(lv) : (h->ek_size <= (256ull << 20) ? 6 : h->ek_size <= (1024ull << 20) ? 8 : 0);
-		if (shift >= 3 && shift <= 8 && (h->ek_size >> (shift - 3)) >= 4096) {
-			uint64_t n_out = h->ek_size >> shift;              // table bits / 2^shift / 8
-			HIPCHK(hipMalloc((void **)&c->d_summ, n_out + 256)); c->dev_allocs.push_back(c->d_summ);
-			hipLaunchKernelGGL(k_ek_summary, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, c->stream, dx.ek0, n_out, shift, c->d_summ);
-			HIPCHK(hipStreamSynchronize(c->stream));
-			c->summ_shift = shift;
-			if (!lv) {
-				// a summary bit helps only where it is clear: tables filled beyond ~4 % (here: > 90 % of the summary
-				// bits set) answer no window from the summary, so it is dropped again
-				std::vector<uint64_t> hs((n_out + 7) / 8, 0);
-				HIPCHK(hipMemcpy(hs.data(), c->d_summ, n_out, hipMemcpyDeviceToHost));
-				uint64_t ones = 0; for (uint64_t v : hs) ones += (uint64_t)__builtin_popcountll(v);
-				if ((double)ones > 0.9 * 8.0 * (double)n_out) { c->d_summ = nullptr; c->summ_shift = 0; }
-			}
+	if (opts) c->opts = *opts;
+	else { c->opts.L_min_matching = 170; c->opts.min_score = 64; c->opts.max_sec_N = 5; }
+	int rc = DSB_OK;
+	// every failure from here on goes through dsb_ctx_destroy: nothing allocated so far is leaked
+#define CK(e) do { if (rc == DSB_OK && (e) != hipSuccess) { fprintf(stderr, "[desamba_amd] HIP error %s at %s:%d\n", hipGetErrorString(hipGetLastError()), __FILE__, __LINE__); rc = DSB_ENODEV; } } while (0)
+	CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));   // contexts on one device overlap each other's copies and kernels
+	for (int i = 0; i < 4; i++) CK(hipEventCreate(&c->ev[i]));
+	CK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)); CK(hipEventCreate(&c->ev_order)); CK(hipEventCreate(&c->ev_cls));
+	CK(hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&c->ev_hprobe, hipEventDisableTiming));
+	if (rc == DSB_OK) rc = stage_acquire(idx, device_id, &c->staged);           // the index goes to HBM once per (index, device)
+	if (rc == DSB_OK) {
+		c->dx = c->staged->dx;
+		c->dx.filter_min_length = c->opts.L_min_matching; c->dx.filter_min_score = c->opts.min_score; c->dx.filter_min_score_LV3 = c->opts.min_score + 10;
+		if (hipMalloc((void **)&c->d_counters, 256) != hipSuccess) rc = DSB_ENOMEM;
+	}
+	if (rc == DSB_OK && getenv("DSB_DEBUG")) {
+		CK(hipHostMalloc((void **)&c->dbg_host, 32 * 65536 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+		if (rc == DSB_OK) { memset(c->dbg_host, 0, 32 * 65536 * sizeof(uint32_t)); CK(hipHostGetDevicePointer((void **)&c->dbg_dev, c->dbg_host, 0)); }
+	}
+#undef CK
+	if (rc == DSB_OK) {
+		c->in.resize(c->opts.input_slots > 1 ? (size_t)c->opts.input_slots : 1);
+		// hints: arenas and batch buffers are allocated now instead of inside the first batch
+		if (c->opts.max_read_len && c->opts.max_batch_reads) {
+			const uint32_t L = c->opts.max_read_len; const size_t n = c->opts.max_batch_reads; const int k = c->dx.ek_len;
+			const uint64_t nwin = L >= 40 ? L - k + 1 : 0;
+			rc = ensure_buffers(c, n, L, n * ((DSB_QPAD_L + 2 * (uint64_t)L + DSB_QPAD_R + 255) & ~(uint64_t)255), n * 2 * ((L + 31) / 32 + 1), n * 2 * ((nwin + 63) / 64));
 		}
 	}
-	if ((rc = dev_upload(c, h->fm, h->n_fm, &dx.fm))) return rc;
-	if (h->fm_sb && (rc = dev_upload(c, h->fm_sb, h->n_fm_sb * 5, &dx.fm_sb))) return rc;
-	dx.bwt_len = h->bwt_len; memcpy(dx.rank, h->rank, sizeof dx.rank); dx.dollar_pos = h->dollar_pos; dx.dollar_row = h->dollar_row;
-	if ((rc = dev_upload(c, h->hash_index, ((size_t)1 << 26) + 1, &dx.hash_index))) return rc;
-	if ((rc = dev_upload(c, (const uint2 *)h->sa, h->sa_size, &dx.sa))) return rc;
-	if ((rc = dev_upload(c, (const uint2 *)h->uni, h->n_uni + 1, &dx.uni))) return rc;
-	if ((rc = dev_upload(c, h->refpos, h->n_refpos + 1, &dx.refpos))) return rc;
-	if ((rc = dev_upload(c, h->refbin, h->n_refbin + 4096, &dx.refbin))) return rc;
-	if ((rc = dev_upload(c, h->refinfo, h->n_ref, &dx.refinfo))) return rc;
-	if ((rc = dev_upload(c, h->Q_MEM, (size_t)2000, &dx.qmem))) return rc;
-	if ((rc = dev_upload(c, &h->Q_LV[0][0], (size_t)400, &dx.qlv))) return rc;
-	dx.filter_min_length = c->opts.L_min_matching; dx.filter_min_score = c->opts.min_score; dx.filter_min_score_LV3 = c->opts.min_score + 10;
-	HIPCHK(hipMalloc((void **)&c->d_counters, 64));
-	c->dbg_host = c->dbg_dev = nullptr;
-	if (getenv("DSB_DEBUG")) {
-		HIPCHK(hipHostMalloc((void **)&c->dbg_host, 32 * 65536 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
-		memset(c->dbg_host, 0, 32 * 65536 * sizeof(uint32_t));
-		HIPCHK(hipHostGetDevicePointer((void **)&c->dbg_dev, c->dbg_host, 0));
-	}
-	c->n_slots = c->opts.n_slots > 0 ? c->opts.n_slots : 0;
+	if (rc != DSB_OK) { dsb_ctx_destroy(c); return rc; }
 	*out = c;
 	return DSB_OK;
 }
 
-extern "C" void dsb_ctx_destroy(dsb_ctx *c)
-{
-	if (!c) return;
-	hipSetDevice(c->device);
-	for (void *p : c->dev_allocs) hipFree(p);
-	hipFree(c->d_rd); hipFree(c->d_wd); hipFree(c->d_ascii); hipFree(c->d_bin); hipFree(c->d_pk); hipFree(c->d_bits);
-	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->arena_big.base); hipFree(c->d_score); hipFree(c->d_order);
-	for (int i = 0; i < 4; i++) hipEventDestroy(c->ev[i]);
-	hipEventDestroy(c->ev_order); hipEventDestroy(c->ev_cls); hipEventDestroy(c->ev_heavy); hipEventDestroy(c->ev_hprobe); hipStreamDestroy(c->stream2);
-	hipStreamDestroy(c->stream);
-	delete c;
-}
 extern "C" void dsb_ctx_reset_history(dsb_ctx *c) { if (c) c->hist_max = 0; }
 extern "C" void dsb_ctx_set_history(dsb_ctx *c, uint32_t max_len_before) { if (c) c->hist_max = (int)max_len_before; }
+extern "C" int dsb_ctx_select_slot(dsb_ctx *c, int slot)
+{
+	if (!c || slot < 0 || (size_t)slot >= c->in.size()) return DSB_EINVAL;
+	c->cur = slot;
+	return DSB_OK;
+}
 extern "C" void *dsb_host_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
 extern "C" void dsb_host_free(void *p) { if (p) hipHostFree(p); }
 
@@ -502,53 +596,112 @@ static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // slots [n_slots, n_slots + DSB_HEAVY_SLOTS) belong to the early launch of the heaviest reads (dsb_batch_run)
 #define DSB_HEAVY_SLOTS 512
-// the arena of the second run (dsb_batch_run): few slots, DSB_RETRY_GROW times the match nodes
+// the arena of the second run (dsb_batch_run): few slots; DSB_RETRY_GROW times the match nodes, DSB_RETRY_ANC anchors, DSB_RETRY_HIT chains
 #define DSB_RETRY_SLOTS 64
 #define DSB_RETRY_GROW 32
 #define DSB_RETRY_MAX_NODES (8u << 20)
-static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int n_slots, int group, uint32_t sms_cap, int extra_slots, bool exact_cap = false)
+#define DSB_RETRY_ANC (8u * DSB_ANC_CAP)
+#define DSB_RETRY_HIT (4u * DSB_HIT_CAP)
+static size_t arena_layout(DsbSlotArena &a, uint32_t max_len, int group, uint32_t sms_cap, uint32_t anc_cap, uint32_t hit_cap)
 {
-	if (a.base && a.max_len >= max_len && *cur_slots >= n_slots && (exact_cap ? a.sms_cap == sms_cap : a.sms_cap >= sms_cap)) return 0;
-	if (a.max_len > max_len) max_len = a.max_len;
-	if (a.base) { hipFree(a.base); a.base = nullptr; }
 	size_t o = 0;
-	a.max_len = max_len; a.sms_cap = sms_cap;
+	a.max_len = max_len; a.sms_cap = sms_cap; a.anc_cap = anc_cap; a.hit_cap = hit_cap;
 	a.off_seeds = o;   o += al256(((size_t)(max_len >> 1) + 64) * sizeof(DsbSeed));
-	a.off_anc = o;     o += al256((size_t)DSB_ANC_CAP * sizeof(DsbAnchor));
-	a.off_anc_tmp = o; o += al256((size_t)DSB_ANC_CAP * sizeof(DsbAnchor));
-	a.off_hit = o;     o += al256((size_t)DSB_HIT_CAP * sizeof(DsbChain));
-	a.off_hit_tmp = o; o += al256((size_t)DSB_HIT_CAP * sizeof(DsbChain));
+	a.off_anc = o;     o += al256((size_t)anc_cap * sizeof(DsbAnchor));
+	a.off_anc_tmp = o; o += al256((size_t)anc_cap * sizeof(DsbAnchor));
+	a.off_hit = o;     o += al256((size_t)hit_cap * sizeof(DsbChain));
+	a.off_hit_tmp = o; o += al256((size_t)hit_cap * sizeof(DsbChain));
 	a.off_sms = o;     o += al256((size_t)sms_cap * sizeof(DsbSms));
-	a.off_kh = o;
 	a.off_sc = o;      o += al256((size_t)(256 + 2 * 400 + 64) * sizeof(DsbScHash));
 	a.off_mem = o;     o += al256((size_t)DSB_MEMSLOW_CAP * sizeof(DsbMem));
 	a.off_spset = o;   o += al256((size_t)DSB_SPHASH * 8);
 	a.off_scorev = o;  o += al256((size_t)1024 * sizeof(int));
-	a.off_sortkey = o; o += al256((size_t)2 * DSB_ANC_CAP * sizeof(uint64_t));
-	a.off_sortidx = o; o += al256((size_t)2 * DSB_ANC_CAP * sizeof(uint32_t));
+	a.off_sortkey = o; o += al256((size_t)2 * anc_cap * sizeof(uint64_t));
+	a.off_sortidx = o; o += al256((size_t)2 * anc_cap * sizeof(uint32_t));
 	a.off_win = o;     o += al256((size_t)3 * DSB_REFWIN);
 	a.off_lane_anc = o; o += al256((size_t)group * DSB_LANE_ANC_CAP * sizeof(DsbAnchor));
 	a.off_lane_sp = o;  o += al256((size_t)group * DSB_SPHASH * 8);
 	a.off_top = o;      o += al256(((size_t)(max_len >> 1) + 64) * 4);
 	a.off_round = o;    o += al256(((size_t)(max_len >> 1) + 64) * 4);
 	a.stride = al256(o);
-	*cur_slots = n_slots;
-	if (hipMalloc((void **)&a.base, a.stride * ((size_t)n_slots + extra_slots)) != hipSuccess) { a.base = nullptr; return DSB_ENOMEM; }
+	return a.stride;
+}
+// (Re)allocate an arena of up to `want_slots` (+ extra_slots) slots for reads of up to max_len bases.  The slot size grows
+// with the longest read (seeds, top-seed lists, match nodes), so the slot count gives way when the arena would not
+// fit into `budget` bytes: never fewer than min_slots.  An arena that was sized for a much longer read than the
+// current batch holds (an outlier: one ultra-long read) is given back and rebuilt at the current size.
+static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int want_slots, int min_slots, uint32_t sms_cap, uint32_t anc_cap, uint32_t hit_cap,
+                      int extra_slots, size_t budget, bool exact_cap = false)
+{
+	const bool fits = a.base && a.max_len >= max_len && (exact_cap ? a.sms_cap == sms_cap : a.sms_cap >= sms_cap);
+	const bool oversized = a.base && a.max_len > 4 * (uint64_t)max_len + 65536 && a.stride * ((size_t)*cur_slots + extra_slots) > ((size_t)4 << 30);
+	if (fits && !oversized && (*cur_slots >= want_slots || a.max_len > max_len)) return 0;   // (fewer slots than wanted are kept if they were a budget decision for longer reads)
+	if (a.base && !oversized && a.max_len > max_len) max_len = a.max_len;
+	if (a.base) { hipFree(a.base); a.base = nullptr; budget += a.stride * ((size_t)*cur_slots + extra_slots); }
+	DsbSlotArena n = a;
+	const size_t stride = arena_layout(n, max_len, 64, sms_cap, anc_cap, hit_cap);
+	int slots = want_slots;
+	while (slots > min_slots && stride * ((size_t)slots + extra_slots) > budget) slots = slots * 3 / 4 > min_slots ? slots * 3 / 4 : min_slots;
+	for (;;) {
+		if (hipMalloc((void **)&n.base, stride * ((size_t)slots + extra_slots)) == hipSuccess) break;
+		(void)hipGetLastError();
+		n.base = nullptr;
+		if (slots <= min_slots) { a.base = nullptr; *cur_slots = 0; return DSB_ENOMEM; }
+		slots = slots / 2 > min_slots ? slots / 2 : min_slots;
+	}
+	a = n; *cur_slots = slots;
 	return 0;
 }
 
+// buffers of one run + arenas, for a batch of n reads (longest max_len) with the given derived sizes
+static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_bytes, uint64_t pk_words, uint64_t bit_words)
+{
+	int rc;
+	if ((rc = grow(&c->d_wd, &c->cap_wd, (size_t)bit_words + 1))) return rc;
+	if ((rc = grow(&c->d_bin, &c->cap_bin, (size_t)bin_bytes + 256))) return rc;
+	if ((rc = grow(&c->d_pk, &c->cap_pk, (size_t)pk_words + 8))) return rc;
+	if ((rc = grow(&c->d_bits, &c->cap_bits, (size_t)bit_words + 8))) return rc;
+	if ((rc = grow(&c->d_rout, &c->cap_rout, n + 1))) return rc;
+	size_t want_hout = 16 * n + 4096;
+	if (const char *e = getenv("DSB_HOUT_CAP")) want_hout = (size_t)atol(e) > 0 ? (size_t)atol(e) : 1;   // diagnostics: a small hit buffer forces the regrow path
+	if (c->cap_hout < want_hout || getenv("DSB_HOUT_CAP")) {
+		if (c->cap_hout != want_hout) { if (c->d_hout) hipFree(c->d_hout); c->d_hout = nullptr; c->cap_hout = 0; if (hipMalloc((void **)&c->d_hout, want_hout * sizeof(DsbHitOut)) != hipSuccess) return DSB_ENOMEM; c->cap_hout = want_hout; }
+	}
+	if ((rc = grow(&c->d_score, &c->cap_score, n + 1))) return rc;
+	if ((rc = grow(&c->d_order, &c->cap_order, n + 1))) return rc;
+	// reads in flight: one wavefront each; default = what is resident at once (12 waves per CU: LDS), bounded by the batch
+	int want = c->opts.n_slots > 0 ? c->opts.n_slots : 256 * 12;
+	if ((size_t)want > n) want = (int)(n ? n : 1);
+	if (want < c->n_slots) want = c->n_slots;
+	uint32_t cap1 = dsb_sms_cap_for(max_len);
+	const bool cap_forced = getenv("DSB_SMS_CAP") != NULL;                      // diagnostics: a small arena forces second runs
+	if (cap_forced) { cap1 = (uint32_t)atol(getenv("DSB_SMS_CAP")); if (cap1 < 64) cap1 = 64; }
+	uint64_t cap2 = (uint64_t)cap1 * DSB_RETRY_GROW; if (cap2 > DSB_RETRY_MAX_NODES) cap2 = cap1 > DSB_RETRY_MAX_NODES ? cap1 : DSB_RETRY_MAX_NODES;
+	uint32_t anc1 = DSB_ANC_CAP;
+	if (const char *e = getenv("DSB_ANC_CAP_RT")) { anc1 = (uint32_t)atol(e); if (anc1 < 64) anc1 = 64; if (anc1 > DSB_ANC_CAP) anc1 = DSB_ANC_CAP; }   // diagnostics
+	// memory budget: what the device has free now, minus a reserve for the other buffers of this and a sibling context
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { free_b = (size_t)64 << 30; }
+	const size_t reserve = (size_t)2 << 30;
+	const size_t budget_big = free_b > reserve ? (free_b - reserve) / 4 : 0, budget_main = free_b > reserve ? (free_b - reserve) / 2 : 0;
+	if ((rc = size_arena(c->arena_big, &c->n_slots_big, max_len, DSB_RETRY_SLOTS, 4, (uint32_t)cap2, DSB_RETRY_ANC, DSB_RETRY_HIT, 0, budget_big))) return rc;
+	if ((rc = size_arena(c->arena, &c->n_slots, max_len, want, 64 < want ? 64 : want, cap1, anc1, DSB_HIT_CAP, DSB_HEAVY_SLOTS, budget_main, cap_forced || getenv("DSB_ANC_CAP_RT")))) return rc;
+	return DSB_OK;
+}
+
 struct SeqView { const char *p; uint32_t len; };
-// `ext_text` != nullptr: the sequences already lie in one host blob (read i at ext_text + reads[i].p's offset is given by
-// ext_off[i]); the blob is copied to the device as it is (no per-read gather) and the descriptors point into it
+// `ext_text` != nullptr: the sequences already lie in one host blob (read i at ext_text + ext_off[i]); the blob is copied
+// to the device as it is (no per-read gather) and the descriptors point into it
 static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *ext_text = nullptr, size_t ext_len = 0, const uint64_t *ext_off = nullptr)
 {
 	if (!c || (!reads && n)) return DSB_EINVAL;
 	HIPCHK(hipSetDevice(c->device));
+	InSlot &s = c->in[c->cur];
 	const int k = c->dx.ek_len;
-	c->h_rd.resize(n);
+	s.h_rd.resize(n);
 	uint64_t seq_off = 0, bin_off = 0, pk_off = 0, bit_off = 0, windows = 0; uint32_t max_len = 64; int hist = c->hist_max;
 	for (size_t i = 0; i < n; i++) {
-		DsbReadDesc &d = c->h_rd[i];
+		DsbReadDesc &d = s.h_rd[i];
 		d.len = reads[i].len; d.seq_off = ext_text ? ext_off[i] : seq_off; d.bin_off = bin_off; d.pk_off = pk_off; d.bit_off = bit_off;
 		d.n_win = d.len >= 40 ? d.len - k + 1 : 0; d.n_words = (d.n_win + 63) / 64;
 		d.hist_max = hist; if ((int)d.len > hist) hist = d.len;
@@ -558,40 +711,23 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 		windows += 2 * (uint64_t)d.n_win;
 	}
 	c->hist_max = hist;
-	c->n_reads = n; c->n_words_total = bit_off; c->total_bases = seq_off; c->total_windows = windows; c->max_len = max_len;
+	s.n_reads = n; s.n_words_total = bit_off; s.total_bases = seq_off; s.total_windows = windows; s.max_len = max_len;
 	int rc;
-	if ((rc = grow(&c->d_rd, &c->cap_rd, n + 1))) return rc;
-	if ((rc = grow(&c->d_wd, &c->cap_wd, (size_t)bit_off + 1))) return rc;
-	if ((rc = grow(&c->d_ascii, &c->cap_ascii, (ext_text ? ext_len : (size_t)seq_off) + 64))) return rc;
-	if ((rc = grow(&c->d_bin, &c->cap_bin, (size_t)bin_off + 256))) return rc;
-	if ((rc = grow(&c->d_pk, &c->cap_pk, (size_t)pk_off + 8))) return rc;
-	if ((rc = grow(&c->d_bits, &c->cap_bits, (size_t)bit_off + 8))) return rc;
-	if ((rc = grow(&c->d_rout, &c->cap_rout, n + 1))) return rc;
-	if ((rc = grow(&c->d_hout, &c->cap_hout, 16 * n + 4096))) return rc;
-	// reads in flight: one wavefront each; default = what is resident at once (12 waves per CU: LDS), bounded by the batch
-	int want = c->opts.n_slots > 0 ? c->opts.n_slots : 256 * 12;
-	if ((size_t)want > n) want = (int)(n ? n : 1);
-	uint32_t cap1 = dsb_sms_cap_for(max_len);
-	const bool cap_forced = getenv("DSB_SMS_CAP") != NULL;                      // diagnostics: a small arena forces second runs
-	if (cap_forced) { cap1 = (uint32_t)atol(getenv("DSB_SMS_CAP")); if (cap1 < 64) cap1 = 64; }
-	uint64_t cap2 = (uint64_t)cap1 * DSB_RETRY_GROW; if (cap2 > DSB_RETRY_MAX_NODES) cap2 = cap1 > DSB_RETRY_MAX_NODES ? cap1 : DSB_RETRY_MAX_NODES;
-	if ((rc = size_arena(c->arena, &c->n_slots, max_len, want > c->n_slots ? want : c->n_slots, 64, cap1, DSB_HEAVY_SLOTS, cap_forced))) return rc;
-	if ((rc = size_arena(c->arena_big, &c->n_slots_big, max_len, DSB_RETRY_SLOTS, 64, (uint32_t)cap2, 0))) return rc;
-	if ((rc = grow(&c->d_score, &c->cap_score, n + 1))) return rc;
-	if ((rc = grow(&c->d_order, &c->cap_order, n + 1))) return rc;
+	if ((rc = grow(&s.d_rd, &s.cap_rd, n + 1))) return rc;
+	if ((rc = grow(&s.d_ascii, &s.cap_ascii, (ext_text ? ext_len : (size_t)seq_off) + 64))) return rc;
+	if ((rc = ensure_buffers(c, n, max_len, bin_off, pk_off, bit_off))) return rc;
 	if (n) {
-		HIPCHK(hipMemcpyAsync(c->d_rd, c->h_rd.data(), n * sizeof(DsbReadDesc), hipMemcpyHostToDevice, c->stream));
-		if (bit_off) hipLaunchKernelGGL(k_build_wd, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_rd, c->d_wd);
-		if (ext_text) HIPCHK(hipMemcpyAsync(c->d_ascii, ext_text, ext_len, hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(s.d_rd, s.h_rd.data(), n * sizeof(DsbReadDesc), hipMemcpyHostToDevice, c->stream));
+		if (ext_text) HIPCHK(hipMemcpyAsync(s.d_ascii, ext_text, ext_len, hipMemcpyHostToDevice, c->stream));
 		else {
 			// sequences: copied read by read out of the caller's buffers (caller owns read memory)
 			std::vector<char> stage((size_t)seq_off);
-			for (size_t i = 0; i < n; i++) memcpy(stage.data() + c->h_rd[i].seq_off, reads[i].p, reads[i].len);
-			HIPCHK(hipMemcpyAsync(c->d_ascii, stage.data(), (size_t)seq_off, hipMemcpyHostToDevice, c->stream));
+			for (size_t i = 0; i < n; i++) memcpy(stage.data() + s.h_rd[i].seq_off, reads[i].p, reads[i].len);
+			HIPCHK(hipMemcpyAsync(s.d_ascii, stage.data(), (size_t)seq_off, hipMemcpyHostToDevice, c->stream));
 			HIPCHK(hipStreamSynchronize(c->stream));       // `stage` goes out of scope
 		}
 	}
-	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));               // the caller's buffers are free again when this returns
 	return DSB_OK;
 }
 
@@ -611,8 +747,9 @@ extern "C" int dsb_batch_upload_text(dsb_ctx *c, const char *text, size_t text_l
 	return upload_views(c, v.data(), n, text, text_len, seq_off);
 }
 
-// read_reads (src/cly_mt.c:42-56) for a plain-text FASTQ/FASTA file: parse up to max_reads records starting
-// at record `skip` straight out of the mapped file and stage them into HBM (no per-read host copies).
+// read_reads (src/cly_mt.c:42-56) for a plain-text FASTQ/FASTA file: the records [skip, skip + max_reads) of the file,
+// found with the reference's kseq rules (dsb_fastq_scan.h) in a private mapping of the file, staged into HBM
+#include "dsb_fastq_scan.h"
 extern "C" long dsb_batch_upload_fastq(dsb_ctx *c, const char *path, size_t skip, size_t max_reads)
 {
 	if (!c || !path) return DSB_EINVAL;
@@ -620,101 +757,93 @@ extern "C" long dsb_batch_upload_fastq(dsb_ctx *c, const char *path, size_t skip
 	if (fd < 0) return DSB_EIO;
 	struct stat st; if (fstat(fd, &st) != 0) { close(fd); return DSB_EIO; }
 	size_t sz = (size_t)st.st_size;
-	const char *b = sz ? (const char *)mmap(nullptr, sz, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+	char *b = sz ? (char *)mmap(nullptr, sz, PROT_READ | PROT_WRITE, MAP_PRIVATE, fd, 0) : nullptr;   // private: multi-line records are joined in place
 	close(fd);
 	if (sz && b == MAP_FAILED) return DSB_EIO;
-	std::vector<SeqView> v; std::vector<std::vector<char>> joined; std::vector<size_t> joined_of;   // joined: multi-line records only
-	const char *p = b, *e = b + sz; size_t rec = 0;
-	while (p < e && v.size() < max_reads) {
-		while (p < e && *p != '>' && *p != '@') p++;
-		if (p >= e) break;
-		bool fq = *p == '@';
-		while (p < e && *p != '\n') p++;
-		p++;
-		const char *s0 = p; while (p < e && *p != '\n') p++;
-		const char *s1 = p; if (s1 > s0 && s1[-1] == '\r') s1--;
-		p++;
-		size_t len = (size_t)(s1 - s0); const char *sp = s0; bool multi = false;
-		if (p < e && *p != '>' && *p != '+' && *p != '@') {   // sequence continues on further lines: join them
-			joined.emplace_back(s0, s1); multi = true;
-			while (p < e && *p != '>' && *p != '+' && *p != '@') { const char *l0 = p; while (p < e && *p != '\n') p++; const char *l1 = p; if (l1 > l0 && l1[-1] == '\r') l1--; joined.back().insert(joined.back().end(), l0, l1); p++; }
-			len = joined.back().size();
-		}
-		if (fq && p < e && *p == '+') {
-			while (p < e && *p != '\n') p++;
-			p++;
-			size_t ql = 0; while (p < e && ql < len) { const char *l0 = p; while (p < e && *p != '\n') p++; ql += (size_t)(p - l0) - ((p > l0 && p[-1] == '\r') ? 1 : 0); p++; }
-		}
-		if (rec++ < skip) { if (multi) joined.pop_back(); continue; }
-		if (len > 0xffffffffu) { if (b) munmap((void *)b, sz); return DSB_EINVAL; }
-		SeqView sv; sv.p = multi ? nullptr : sp; sv.len = (uint32_t)len;
-		if (multi) joined_of.push_back(v.size());
+	std::vector<SeqView> v;
+	size_t pos = 0, rec = 0; int last = 0; dsb_rec_t r;
+	while (v.size() < max_reads) {
+		int rc = dsb_scan_record(b, pos, sz, 1, last, 0, &r);
+		if (rc == 1 && !r.plain) rc = dsb_scan_record(b, pos, sz, 1, last, 1, &r);
+		if (rc == -2) { pos = r.next; last = r.next_last; continue; }            // dropped, as read_reads does
+		if (rc != 1) break;
+		pos = r.next; last = r.next_last;
+		if (rec++ < skip) continue;
+		if (r.seq_len > 0xffffffffu) { if (b) munmap(b, sz); return DSB_EINVAL; }
+		SeqView sv; sv.p = b + r.seq_off; sv.len = (uint32_t)r.seq_len;
 		v.push_back(sv);
 	}
-	for (size_t k = 0; k < joined_of.size(); k++) v[joined_of[k]].p = joined[k].data();   // after the vectors stopped growing
 	int rc = upload_views(c, v.data(), v.size());
-	if (b) munmap((void *)b, sz);
+	if (b) munmap(b, sz);
 	return rc ? rc : (long)v.size();
+}
+
+// one k_classify-family launch
+template <class K>
+static void launch_classify(K kern, dsb_ctx *c, hipStream_t st, unsigned grid, const DsbDevIndex &dx, const InSlot &s, uint32_t n_fixed, const unsigned int *n_ptr,
+                            const uint32_t *list, const DsbSlotArena &ar, unsigned int *work_counter, uint32_t *dbg, uint32_t item_base, uint32_t slot_base, int cnt_set)
+{
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, st, dx, (const DsbReadDesc *)s.d_rd, n_fixed, n_ptr, list, c->d_bin, (const uint64_t *)c->d_bits, ar, work_counter,
+	                   c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, dbg, item_base, slot_base, (unsigned long long *)(c->d_counters + 16 + 8 * cnt_set));
 }
 
 extern "C" int dsb_batch_run(dsb_ctx *c)
 {
 	if (!c) return DSB_EINVAL;
 	HIPCHK(hipSetDevice(c->device));
-	size_t n = c->n_reads;
+	InSlot &s = c->in[c->cur];
+	size_t n = s.n_reads;
 	memset(&c->timing, 0, sizeof c->timing);
 	if (n == 0) return DSB_OK;
-	HIPCHK(hipMemsetAsync(c->d_counters, 0, 64, c->stream));
+	HIPCHK(hipMemsetAsync(c->d_counters, 0, 256, c->stream));
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
-	hipLaunchKernelGGL(k_encode_bytes, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_rd, c->d_ascii, c->d_bin);
-	hipLaunchKernelGGL(k_encode_pack, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_rd, c->d_bin, c->d_pk);
+	hipLaunchKernelGGL(k_encode_bytes, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, s.d_ascii, c->d_bin);
+	hipLaunchKernelGGL(k_encode_pack, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, c->d_bin, c->d_pk);
+	if (s.n_words_total) hipLaunchKernelGGL(k_build_wd, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, c->d_wd);
 	HIPCHK(hipEventRecord(c->ev[1], c->stream));
-	const bool dbg = getenv("DSB_DEBUG") != NULL;
+	const bool dbg = getenv("DSB_DEBUG") != NULL && c->dbg_dev;
 	if (dbg) { HIPCHK(hipStreamSynchronize(c->stream)); fprintf(stderr, "[dsb] encode done\n"); }
 	// the LPT order needs only the packed reads.  (Run beside the seed probe its scoring kernel takes 90 ms instead
 	// of 12: both stream the packed reads.)
-	hipLaunchKernelGGL(k_repeat_score, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_rd, c->d_pk, c->d_score);
+	hipLaunchKernelGGL(k_repeat_score, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, c->d_pk, c->d_score);
 	hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, c->stream, c->d_score, (uint32_t)n, c->d_order);
 	HIPCHK(hipEventRecord(c->ev_order, c->stream));
 	// Head start for the tail: the kernel's duration is the duration of its heaviest read (tandem repeats: minutes of
 	// sparse DP on the CPU, ~0.2 s here).  The first n_heavy reads of the LPT order get their probes and their own
 	// k_classify launch on the second stream right away, beside the main seed probe, instead of after it.
 	unsigned n_heavy = 0;
-	if (!dbg && c->n_words_total) {
+	if (!dbg && s.n_words_total) {
 		const char *hv = getenv("DSB_HEAVY_FIRST");
 		n_heavy = hv ? (unsigned)atoi(hv) : (n >= 4096 ? (unsigned)(n / 64) : 0u);
 		if (n_heavy > DSB_HEAVY_SLOTS) n_heavy = DSB_HEAVY_SLOTS;
 		if (n_heavy > n / 2) n_heavy = (unsigned)(n / 2);
 	}
 	c->n_early = n_heavy;
-	DsbDevIndex dx1 = c->dx; dx1.sms_cap = c->arena.sms_cap;
+	uint32_t step_limit = DSB_STEP_LIMIT;
+	if (const char *e = getenv("DSB_STEP_LIMIT_RT")) { long v = atol(e); if (v > 0) step_limit = (uint32_t)v; }   // diagnostics: a small budget forces second runs
+	DsbDevIndex dx1 = c->dx; dx1.sms_cap = c->arena.sms_cap; dx1.step_limit = step_limit;
 	if (n_heavy) {
 		// their probes first, alone on the device (about a millisecond), then their classify launch on the second stream
-		hipLaunchKernelGGL(k_seed_probe_reads, dim3(n_heavy * DSB_HPROBE_SPLIT), dim3(256), 0, c->stream, c->dx, c->d_rd, (const uint32_t *)c->d_order, c->d_pk, c->d_bits, c->d_summ, c->summ_shift);
+		hipLaunchKernelGGL(k_seed_probe_reads, dim3(n_heavy * DSB_HPROBE_SPLIT), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const uint32_t *)c->d_order, c->d_pk, c->d_bits, c->staged->d_summ, c->staged->summ_shift);
 		HIPCHK(hipEventRecord(c->ev_hprobe, c->stream));
 		HIPCHK(hipEventRecord(c->ev_order, c->stream));             // order_ms covers scoring, ordering and these probes
 		HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_hprobe, 0));
-		hipLaunchKernelGGL(k_classify_early, dim3(n_heavy), dim3(64), 0, c->stream2, dx1, c->d_rd, (uint32_t)n_heavy, (const unsigned int *)nullptr, (const uint32_t *)c->d_order,
-		                   c->d_bin, c->d_bits, c->arena, c->d_counters + 4, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout,
-		                   (uint32_t *)nullptr, 0u, (uint32_t)c->n_slots);
+		launch_classify(k_classify_early, c, c->stream2, n_heavy, dx1, s, (uint32_t)n_heavy, nullptr, (const uint32_t *)c->d_order, c->arena, c->d_counters + 4, nullptr, 0u, (uint32_t)c->n_slots, 1);
 		HIPCHK(hipEventRecord(c->ev_heavy, c->stream2));
 	}
-	if (c->n_words_total) {
-		uint64_t waves = (c->n_words_total + DSB_PROBE_UN - 1) / DSB_PROBE_UN; unsigned blocks = (unsigned)((waves + 3) / 4);
+	if (s.n_words_total) {
+		uint64_t waves = (s.n_words_total + DSB_PROBE_UN - 1) / DSB_PROBE_UN; unsigned blocks = (unsigned)((waves + 3) / 4);
 		if (blocks > 256u * 32u) blocks = 256u * 32u;       // >= 8 blocks of 4 waves per CU, grid-stride beyond
-		hipLaunchKernelGGL(k_seed_probe, dim3(blocks), dim3(256), 0, c->stream, c->dx, c->d_rd, c->d_wd, c->n_words_total, c->d_pk, c->d_bits,
-		                   (unsigned long long *)(c->d_counters + 2), c->d_summ, c->summ_shift);
+		hipLaunchKernelGGL(k_seed_probe, dim3(blocks), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const DsbWordDesc *)c->d_wd, s.n_words_total, c->d_pk, c->d_bits,
+		                   (unsigned long long *)(c->d_counters + 2), c->staged->d_summ, c->staged->summ_shift);
 	}
 	HIPCHK(hipEventRecord(c->ev[2], c->stream));
 	if (dbg) { HIPCHK(hipStreamSynchronize(c->stream)); fprintf(stderr, "[dsb] seed probe done\n"); }
+	unsigned slots = (unsigned)c->n_slots; if (slots > n - n_heavy) slots = (unsigned)(n - n_heavy);
 	{
-		unsigned slots = (unsigned)c->n_slots; if (slots > n - n_heavy) slots = (unsigned)(n - n_heavy);
 		uint32_t *dbgp = dbg ? c->dbg_dev : nullptr;
 		if (dbg) memset(c->dbg_host, 0, 32 * 65536 * sizeof(uint32_t));
-		// counters: [0] work, [1] hits, [2..3] u64 table-1 probes
-		hipLaunchKernelGGL(k_classify, dim3(slots), dim3(64), 0, c->stream, dx1, c->d_rd, (uint32_t)n, (const unsigned int *)nullptr, (const uint32_t *)c->d_order,
-		                   c->d_bin, c->d_bits, c->arena, c->d_counters, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout,
-		                   dbgp, (uint32_t)n_heavy, 0u);
+		launch_classify(k_classify, c, c->stream, slots, dx1, s, (uint32_t)n, nullptr, (const uint32_t *)c->d_order, c->arena, c->d_counters, dbgp, (uint32_t)n_heavy, 0u, 0);
 		HIPCHK(hipEventRecord(c->ev_cls, c->stream));
 		if (n_heavy) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_heavy, 0));
 		if (dbg) {
@@ -729,24 +858,41 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 			}
 		}
 	}
-	{
-		// Second run: the match-node arena of a slot holds 2 nodes per base of the longest read (dsb_sms_cap_for); the
-		// reference's vector is unbounded (tandem repeats under a long extension).  Reads that overflowed it are listed
-		// on the device and run again in DSB_RETRY_SLOTS slots whose arena is DSB_RETRY_GROW times larger; with an
-		// empty list the launch drains at once.  counters: [6] listed reads, [7] work counter of the second run.
-		DsbDevIndex dx2 = c->dx; dx2.sms_cap = c->arena_big.sms_cap;
-		hipLaunchKernelGGL(k_collect_retry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const DsbReadOut *)c->d_rout, (uint32_t)n, c->d_score, c->d_counters + 6);
-		hipLaunchKernelGGL(k_classify_second, dim3(DSB_RETRY_SLOTS), dim3(64), 0, c->stream, dx2, c->d_rd, 0u, (const unsigned int *)(c->d_counters + 6), (const uint32_t *)c->d_score,
-		                   c->d_bin, c->d_bits, c->arena_big, c->d_counters + 7, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout,
-		                   (uint32_t *)nullptr, 0u, 0u);
-	}
+	// Second run.  The reference's per-read vectors are unbounded and it has no loop budget; a wave slot here holds 2 match
+	// nodes per base of the longest read (dsb_sms_cap_for), DSB_ANC_CAP anchors, DSB_HIT_CAP chains, and a read may spend
+	// DSB_STEP_LIMIT loop iterations.  Reads that outgrew any of these are listed on the device and run again from
+	// scratch in DSB_RETRY_SLOTS slots with DSB_RETRY_GROW times the match nodes, 8x the anchors, 4x the chains and 16x
+	// the budget; with an empty list the launch drains at once.  counters: [6] listed reads, [7] work counter of the second run.
+	DsbDevIndex dx2 = c->dx; dx2.sms_cap = c->arena_big.sms_cap; dx2.step_limit = step_limit > 0xffffffffu / 16 ? 0xffffffffu : step_limit * 16u;
+	const int retry_mask = DSB_ST_SMS_OVF | DSB_ST_ANC_OVF | DSB_ST_HIT_OVF | DSB_ST_TIMEOUT;
+	hipLaunchKernelGGL(k_collect_retry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const DsbReadOut *)c->d_rout, (uint32_t)n, c->d_score, c->d_counters + 6, retry_mask, 0);
+	launch_classify(k_classify_second, c, c->stream, (unsigned)c->n_slots_big, dx2, s, 0u, (const unsigned int *)(c->d_counters + 6), (const uint32_t *)c->d_score, c->arena_big, c->d_counters + 7, nullptr, 0u, 0u, 2);
 	HIPCHK(hipEventRecord(c->ev[3], c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	{
+		// The hit buffer holds 16 n + 4096 records (the reference's lists are unbounded).  The device counts every
+		// hit it wanted to write; if that is more than the buffer holds, the buffer is regrown (contents kept) and
+		// the reads that found it full run once more -- rare enough for a host round trip.
+		unsigned int cnt[2] = {0, 0};
+		HIPCHK(hipMemcpy(cnt, c->d_counters, 8, hipMemcpyDeviceToHost));
+		if (cnt[1] > c->cap_hout) {
+			const size_t new_cap = 2 * (size_t)cnt[1] + 4096;
+			DsbHitOut *nh = nullptr;
+			if (hipMalloc((void **)&nh, new_cap * sizeof(DsbHitOut)) != hipSuccess) return DSB_ENOMEM;
+			HIPCHK(hipMemcpy(nh, c->d_hout, c->cap_hout * sizeof(DsbHitOut), hipMemcpyDeviceToDevice));
+			hipFree(c->d_hout); c->d_hout = nh; c->cap_hout = new_cap;
+			hipLaunchKernelGGL(k_collect_retry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const DsbReadOut *)c->d_rout, (uint32_t)n, c->d_score, c->d_counters + 8, DSB_ST_OUT_OVF, 0);
+			launch_classify(k_classify_second, c, c->stream, (unsigned)c->n_slots_big, dx2, s, 0u, (const unsigned int *)(c->d_counters + 8), (const uint32_t *)c->d_score, c->arena_big, c->d_counters + 9, nullptr, 0u, 0u, 2);
+			HIPCHK(hipStreamSynchronize(c->stream));
+			unsigned int n3 = 0; HIPCHK(hipMemcpy(&n3, c->d_counters + 8, 4, hipMemcpyDeviceToHost));
+			c->timing.n_regrow = n3;
+		}
+	}
 	if (dbg) {
 		static const char *nm[10] = {"seed_vector", "fast_classify", "resolve_tree", "slow+resolve", "hash_build", "sdp_middle", "sdp_right", "sdp_left", "sort/filter", "primary"};
-		double tot[10] = {0}, all = 0; unsigned slots = (unsigned)c->n_slots; if (slots > n) slots = (unsigned)n;
+		double tot[10] = {0}, all = 0; unsigned sl = (unsigned)c->n_slots; if (sl > n) sl = (unsigned)n;
 		double sub[4] = {0};
-		for (unsigned sI = 0; sI < slots; sI++) { for (int i = 0; i < 10; i++) { tot[i] += c->dbg_host[4 * 65536 + 14 * sI + i]; all += c->dbg_host[4 * 65536 + 14 * sI + i]; } for (int i = 0; i < 4; i++) sub[i] += c->dbg_host[4 * 65536 + 14 * sI + 10 + i]; }
+		for (unsigned sI = 0; sI < sl; sI++) { for (int i = 0; i < 10; i++) { tot[i] += c->dbg_host[4 * 65536 + 14 * sI + i]; all += c->dbg_host[4 * 65536 + 14 * sI + i]; } for (int i = 0; i < 4; i++) sub[i] += c->dbg_host[4 * 65536 + 14 * sI + 10 + i]; }
 		fprintf(stderr, "[dsb] inside sdp_right/left (ms): sdp_match %.1f  dp %.1f  combine %.1f  [3] %.1f\n", sub[0] / 1e3, sub[1] / 1e3, sub[2] / 1e3, sub[3] / 1e3);
 		{	// stage split of the slowest read of the batch (as it ran, i.e. under load)
 			size_t worst = 0; uint64_t wsum = 0;
@@ -767,10 +913,13 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	hipEventElapsedTime(&c->timing.tail_ms, c->ev_cls, c->ev[3]);           // waiting for the early launch, if it is still running
 	c->timing.n_early = c->n_early;
 	hipEventElapsedTime(&c->timing.total_ms, c->ev[0], c->ev[3]);
-	HIPCHK(hipMemcpyAsync(&c->p1, c->d_counters + 2, 8, hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipMemcpyAsync(&c->timing.n_retry, c->d_counters + 6, 4, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream));
-
-	c->timing.windows = c->total_windows; c->timing.probes_t1 = c->p1; c->timing.bases = c->total_bases;
+	unsigned long long wk[12] = {0};                   // work counters: main launch, early launch, second runs
+	HIPCHK(hipMemcpy(&c->p1, c->d_counters + 2, 8, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(&c->timing.n_retry, c->d_counters + 6, 4, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(wk, c->d_counters + 16, 96, hipMemcpyDeviceToHost));
+	c->timing.windows = s.total_windows; c->timing.probes_t1 = c->p1; c->timing.bases = s.total_bases;
+	c->timing.n_occ = wk[0] + wk[4] + wk[8]; c->timing.n_mem = wk[1] + wk[5] + wk[9]; c->timing.n_sa = wk[2] + wk[6] + wk[10]; c->timing.ref_bases = wk[3] + wk[7] + wk[11];
+	c->timing.main_occ = wk[0]; c->timing.main_mem = wk[1]; c->timing.main_sa = wk[2]; c->timing.main_ref_bases = wk[3];
 	return DSB_OK;
 }
 
@@ -778,7 +927,7 @@ extern "C" int dsb_batch_fetch(dsb_ctx *c, dsb_result *out)
 {
 	if (!c || !out) return DSB_EINVAL;
 	HIPCHK(hipSetDevice(c->device));
-	size_t n = c->n_reads;
+	const size_t n = c->in[c->cur].n_reads;
 	c->h_rout.resize(n); c->res_reads.resize(n);
 	unsigned int cnt[2] = {0, 0};
 	if (n) {
@@ -786,26 +935,22 @@ extern "C" int dsb_batch_fetch(dsb_ctx *c, dsb_result *out)
 		HIPCHK(hipMemcpyAsync(c->h_rout.data(), c->d_rout, n * sizeof(DsbReadOut), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(hipStreamSynchronize(c->stream));
 	}
-	size_t nh = cnt[1] < c->cap_hout ? cnt[1] : c->cap_hout;
+	const size_t nh = cnt[1] < c->cap_hout ? cnt[1] : c->cap_hout;
 	c->h_hout.resize(nh);
 	if (nh) { HIPCHK(hipMemcpyAsync(c->h_hout.data(), c->d_hout, nh * sizeof(DsbHitOut), hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); }
-	// pack hits in read order
-	c->res_hits.clear(); c->res_hits.reserve(nh);
+	// The hits of a read lie together in the device's hit buffer, in the order the reads finished; dsb_hit has the
+	// layout of the device record, so nothing is repacked: the per-read `first` points into the buffer as fetched.
+	static_assert(sizeof(DsbHitOut) == sizeof(dsb_hit), "dsb_hit mirrors DsbHitOut");
 	int worst = DSB_OK;
 	for (size_t i = 0; i < n; i++) {
 		const DsbReadOut &r = c->h_rout[i];
 		dsb_read_result &o = c->res_reads[i];
-		o.first = (uint32_t)c->res_hits.size(); o.n = r.n; o.fast = r.fast & 1u; o.device_us = r.fast >> 1; o.n_anc = r.n_anc;
+		o.first = r.first; o.n = r.n; o.fast = r.fast & 1u; o.device_us = r.fast >> 1; o.n_anc = r.n_anc;
 		o.status = r.status ? (DSB_ECAP * 256 - r.status) : 0;
 		if (r.status) worst = DSB_ECAP;
-		for (uint32_t k = 0; k < r.n; k++) {
-			const DsbHitOut &h = c->h_hout[r.first + k]; dsb_hit q;
-			q.ref_ID = h.ref_ID; q.t_st = h.t_st; q.t_ed = h.t_ed; q.q_st = h.q_st; q.q_ed = h.q_ed; q.sum_score = h.sum_score; q.indel = h.indel;
-			q.direction = h.direction; q.primary = h.primary; q.pri_index = h.pri_index; q.pad = 0;
-			c->res_hits.push_back(q);
-		}
+		if ((size_t)r.first + r.n > nh) { o.n = 0; o.first = 0; }
 	}
-	out->reads = c->res_reads.data(); out->hits = c->res_hits.data(); out->n_hits = c->res_hits.size();
+	out->reads = c->res_reads.data(); out->hits = reinterpret_cast<const dsb_hit *>(c->h_hout.data()); out->n_hits = nh;
 	return worst;
 }
 
@@ -821,9 +966,9 @@ extern "C" int dsb_batch_timing(const dsb_ctx *c, dsb_timing *t) { if (!c || !t)
 
 extern "C" int dsb_batch_exist_bits(dsb_ctx *c, size_t read, int strand, uint8_t *out, size_t cap, uint32_t *n_out)
 {
-	if (!c || read >= c->n_reads) return DSB_EINVAL;
+	if (!c || read >= c->in[c->cur].n_reads) return DSB_EINVAL;
 	HIPCHK(hipSetDevice(c->device));
-	const DsbReadDesc &d = c->h_rd[read];
+	const DsbReadDesc &d = c->in[c->cur].h_rd[read];
 	if (n_out) *n_out = d.n_win;
 	if (cap < d.n_win) return DSB_EINVAL;
 	std::vector<uint64_t> wv(d.n_words);
@@ -836,9 +981,11 @@ extern "C" int dsb_batch_exist_bits(dsb_ctx *c, size_t read, int strand, uint8_t
 __global__ void __launch_bounds__(64) k_seed_dump(DsbDevIndex x, DsbReadDesc d, uint8_t *bin, const uint64_t *bits, int strand, DsbSeed *out, uint32_t *n_out)
 {
 	__shared__ DsbDevIndex sx;
+	__shared__ uint32_t lds_cnt[4];
 	if (threadIdx.x == 0) sx = x;
 	__syncthreads();
 	dsb_g64::WCtx w; w.x = (dsb_g64::DsbXP)&sx; w.lane = threadIdx.x; w.L = d.len; w.status = 0; w.dbg = nullptr; w.anc_cap = 0; w.wtab = nullptr;
+	w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1;
 	dsb_g64::SDir sd;
 	uint32_t n = d.len - x.ek_len + 1;
 	if (strand) dsb_g64::seed_vector(w, bin + d.bin_off + DSB_QPAD_L, bits + d.bit_off, n, out, D_FORWARD, &sd);
@@ -847,9 +994,9 @@ __global__ void __launch_bounds__(64) k_seed_dump(DsbDevIndex x, DsbReadDesc d, 
 }
 extern "C" int dsb_batch_seeds(dsb_ctx *c, size_t read, int strand, dsb_seed *out, size_t cap, uint32_t *n, uint32_t *total_score)
 {
-	if (!c || read >= c->n_reads) return DSB_EINVAL;
+	if (!c || read >= c->in[c->cur].n_reads) return DSB_EINVAL;
 	HIPCHK(hipSetDevice(c->device));
-	const DsbReadDesc &d = c->h_rd[read];
+	const DsbReadDesc &d = c->in[c->cur].h_rd[read];
 	if (d.len < 40) { if (n) *n = 0; if (total_score) *total_score = 0; return DSB_OK; }
 	DsbSeed *ds; uint32_t *dn; size_t m = (d.len >> 1) + 64;
 	HIPCHK(hipMalloc((void **)&ds, m * sizeof(DsbSeed))); HIPCHK(hipMalloc((void **)&dn, 8));
@@ -863,4 +1010,111 @@ extern "C" int dsb_batch_seeds(dsb_ctx *c, size_t read, int strand, dsb_seed *ou
 	if (cap < hn[0]) return DSB_EINVAL;
 	for (uint32_t i = 0; i < hn[0]; i++) { out[i].offset = hs[i].offset; out[i].len = hs[i].len; out[i].top = (uint8_t)hs[i].top; out[i].pad[0] = out[i].pad[1] = out[i].pad[2] = 0; }
 	return DSB_OK;
+}
+
+// ---- several devices: reads sharded, index replicated, no collective ----------------------------
+// dsb_shard_plan: contiguous chunks of the input order (a chunk ends at chunk_bases bases or chunk_reads reads), dealt
+// round-robin over `world` ranks.  The only cross-read state of the reference -- the running max_read_l of
+// delete_small_score_rst (src/cly.c:2958) -- travels in the chunk header as the prefix maximum of read length
+// before the chunk (oracle U4).  Order of results = order of input (kt_pipeline's guarantee, src/lib/kthread.c:122-136).
+extern "C" int dsb_shard_plan(const uint32_t *lengths, size_t n, int world, uint64_t chunk_bases, uint32_t chunk_reads, dsb_chunk *out, size_t cap, size_t *n_out)
+{
+	if ((!lengths && n) || world < 1 || !n_out) return DSB_EINVAL;
+	if (!chunk_bases) chunk_bases = 64000000ULL;
+	if (!chunk_reads) chunk_reads = 4096;
+	size_t k = 0, start = 0; uint64_t bases = 0; uint32_t hist = 0, run_max = 0;
+	for (size_t i = 0; i < n; i++) {
+		bases += lengths[i];
+		if (lengths[i] > run_max) run_max = lengths[i];
+		if (bases >= chunk_bases || i + 1 - start >= chunk_reads || i + 1 == n) {
+			if (out && k < cap) { out[k].start = start; out[k].end = i + 1; out[k].hist_max_before = hist; out[k].rank = (int32_t)(k % (size_t)world); }
+			k++;
+			if (run_max > hist) hist = run_max;
+			start = i + 1; bases = 0;
+		}
+	}
+	*n_out = k;
+	return (out && k > cap) ? DSB_EINVAL : DSB_OK;
+}
+
+struct dsb_multi {
+	dsb_index *idx = nullptr; std::vector<dsb_ctx *> ctx; uint32_t hist = 0;
+	std::vector<dsb_read_result> reads; std::vector<dsb_hit> hits;
+};
+
+extern "C" void dsb_multi_destroy(dsb_multi *m)
+{
+	if (!m) return;
+	for (dsb_ctx *c : m->ctx) dsb_ctx_destroy(c);
+	delete m;
+}
+// classify_main's set-up for several GPUs: one context per entry of device_ids (a device may be listed more than once:
+// its contexts share the staged index and overlap each other's copies and kernels)
+extern "C" int dsb_ctx_create_multi(dsb_index *idx, const int *device_ids, int n_dev, const dsb_opts *opts, dsb_multi **out)
+{
+	if (!idx || !device_ids || n_dev < 1 || !out) return DSB_EINVAL;
+	dsb_multi *m = new dsb_multi(); m->idx = idx;
+	for (int i = 0; i < n_dev; i++) {
+		dsb_ctx *c = nullptr; int rc = dsb_ctx_create(idx, device_ids[i], opts, &c);
+		if (rc) { dsb_multi_destroy(m); return rc; }
+		m->ctx.push_back(c);
+	}
+	*out = m;
+	return DSB_OK;
+}
+extern "C" int dsb_multi_n(const dsb_multi *m) { return m ? (int)m->ctx.size() : 0; }
+extern "C" dsb_ctx *dsb_multi_ctx(dsb_multi *m, int i) { return (m && i >= 0 && (size_t)i < m->ctx.size()) ? m->ctx[i] : nullptr; }
+extern "C" void dsb_multi_reset_history(dsb_multi *m) { if (m) m->hist = 0; }
+
+// the kt_for seam (src/cly_mt.c:389) over several devices: the batch is cut by dsb_shard_plan, every context takes its
+// chunks in turn on a host thread of its own, results come back in input order
+extern "C" int dsb_multi_classify_batch(dsb_multi *m, const dsb_read *reads, size_t n, dsb_result *out)
+{
+	if (!m || (!reads && n) || !out) return DSB_EINVAL;
+	const int W = (int)m->ctx.size();
+	std::vector<uint32_t> len(n);
+	for (size_t i = 0; i < n; i++) len[i] = reads[i].len;
+	const char *cr = getenv("DSB_SHARD_CHUNK_READS"); const uint32_t chunk_reads = cr ? (uint32_t)atol(cr) : 0;
+	size_t nc = 0;
+	dsb_shard_plan(len.data(), n, W, 0, chunk_reads, nullptr, 0, &nc);
+	std::vector<dsb_chunk> plan(nc ? nc : 1);
+	dsb_shard_plan(len.data(), n, W, 0, chunk_reads, plan.data(), nc, &nc);
+	m->reads.assign(n, dsb_read_result());
+	std::vector<std::vector<dsb_hit>> chunk_hits(nc);
+	std::vector<int> rcs(W, DSB_OK);
+	const uint32_t hist0 = m->hist;
+	auto worker = [&](int w) {
+		dsb_ctx *c = m->ctx[w];
+		for (size_t k = (size_t)w; k < nc; k += (size_t)W) {
+			const dsb_chunk &ch = plan[k];
+			dsb_ctx_set_history(c, ch.hist_max_before > hist0 ? ch.hist_max_before : hist0);
+			dsb_result r;
+			int rc = dsb_classify_batch(c, reads + ch.start, (size_t)(ch.end - ch.start), &r);
+			if (rc && rc != DSB_ECAP) { rcs[w] = rc; return; }
+			if (rc == DSB_ECAP) rcs[w] = DSB_ECAP;
+			std::vector<dsb_hit> &H = chunk_hits[k];
+			for (uint64_t i = ch.start; i < ch.end; i++) {
+				dsb_read_result rr = r.reads[i - ch.start];
+				const uint32_t first = (uint32_t)H.size();
+				H.insert(H.end(), r.hits + rr.first, r.hits + rr.first + rr.n);
+				rr.first = first;                                    // chunk-local for now
+				m->reads[i] = rr;
+			}
+		}
+	};
+	std::vector<std::thread> th;
+	for (int w = 1; w < W; w++) th.emplace_back(worker, w);
+	worker(0);
+	for (std::thread &t : th) t.join();
+	int worst = DSB_OK;
+	for (int w = 0; w < W; w++) { if (rcs[w] && rcs[w] != DSB_ECAP) return rcs[w]; if (rcs[w]) worst = rcs[w]; }
+	m->hits.clear();
+	for (size_t k = 0; k < nc; k++) {
+		const uint32_t base = (uint32_t)m->hits.size();
+		for (uint64_t i = plan[k].start; i < plan[k].end; i++) m->reads[i].first += base;
+		m->hits.insert(m->hits.end(), chunk_hits[k].begin(), chunk_hits[k].end());
+	}
+	for (size_t i = 0; i < n; i++) if (len[i] > m->hist) m->hist = len[i];
+	out->reads = m->reads.data(); out->hits = m->hits.data(); out->n_hits = m->hits.size();
+	return worst;
 }

@@ -197,8 +197,9 @@ extern "C" uint64_t dsb_index_occ_host(const dsb_index *x, uint64_t r, uint8_t *
 // output_one_result_sam, src/cly_mt.c:245-344
 extern "C" long dsb_format_sam(const dsb_index *x, const dsb_read *rd_, const dsb_hit *h, uint32_t n, int max_sec, int full, char *buf, size_t cap)
 {
-	const char *seq_s = full ? rd_->seq : "*", *qual_s = full ? (rd_->qual ? rd_->qual : "") : "*";
-	int seq_n = full ? (int)rd_->len : 1, qual_n = full ? (int)(rd_->qual ? rd_->len : 0) : 1;
+	// a record without quality (FASTA): the reference hands printf the NULL kseq_t.qual.s, glibc prints "(null)"
+	const char *seq_s = full ? rd_->seq : "*", *qual_s = full ? (rd_->qual ? rd_->qual : "(null)") : "*";
+	int seq_n = full ? (int)rd_->len : 1, qual_n = full ? (int)(rd_->qual ? rd_->len : 6) : 1;
 	size_t o = 0; int w;
 #define EMIT(...) do { w = snprintf(buf + o, cap > o ? cap - o : 0, __VA_ARGS__); if (w < 0 || (size_t)w >= (cap > o ? cap - o : 0)) return -1; o += (size_t)w; } while (0)
 	if (n == 0) { EMIT("%s\t4\t*\t0\t0\t*\t*\t0\t0\t%.*s\t%.*s\t\n", rd_->name, seq_n, seq_s, qual_n, qual_s); return (long)o; }
@@ -234,7 +235,7 @@ extern "C" const char *dsb_strerror(int code)
 	}
 	return "unknown error";
 }
-extern "C" const char *dsb_version(void) { return "desamba_amd 0.1 (gfx950)"; }
+extern "C" const char *dsb_version(void) { return "desamba_amd 0.2 (gfx950)"; }
 
 // output_one_result_des / output_one_result_full (src/cly_mt.c:158-243; print_hit :60-104).  Anchors are never listed:
 // MAP_opt.show_anchor is false and no option sets it (src/cly_mt.c:486).

@@ -6,7 +6,8 @@
  * This header is that seam as a C ABI: plain pointers and sizes, no torch / HIP types.
  * Every entry point returns 0 on success or a negative DSB_E* code; nothing here calls
  * exit() (the reference's print-and-exit convention, src/lib/utils.c:144-176, lives only
- * in the CLI).  One dsb_ctx per host thread and GPU; batches run in submission order.
+ * in the CLI).  One dsb_ctx per host thread and GPU; batches run in submission order;
+ * dsb_ctx_create_multi / dsb_multi_classify_batch spread one batch over a list of GPUs.
  *
  * There is NO CPU fallback: every compute stage runs as a HIP kernel on gfx950, and
  * dsb_ctx_create fails with DSB_ENODEV when no such device is present.
@@ -29,6 +30,7 @@ extern "C" {
 
 typedef struct dsb_index dsb_index;   /* replaces DA_IDX (src/idx.h:68-91) */
 typedef struct dsb_ctx dsb_ctx;       /* replaces Classify_buff_pool + MAP_opt (src/cly.h:139-158,17-26) */
+typedef struct dsb_multi dsb_multi;   /* one dsb_ctx per GPU of a device list: the T worker threads of kt_for (src/cly_mt.c:389) with GPUs for threads */
 
 /* replaces MAP_opt's classify-relevant fields, defaults {170, 64, 5} (src/cly_mt.c:486) */
 typedef struct {
@@ -36,6 +38,10 @@ typedef struct {
 	int min_score;        /* -s, idx.filter_min_score    (src/cly_mt.c:522) */
 	int max_sec_N;        /* -r, used by the SAM writer only */
 	int n_slots;          /* 0 = default: reads in flight on the device (one wavefront each) */
+	uint32_t max_read_len;     /* hints, 0 = none: with both set, arenas and batch buffers are allocated by dsb_ctx_create */
+	uint32_t max_batch_reads;  /*   for batches of that many reads of up to that length, instead of inside the first batch */
+	int input_slots;      /* batches a ctx can hold staged in HBM at once (dsb_ctx_select_slot); 0 or 1 = one */
+	int reserved;         /* 0 */
 } dsb_opts;
 
 /* replaces kseq_t as consumed by classify_seq (src/cly.c:3064): only seq/len reach the kernel */
@@ -55,7 +61,8 @@ typedef struct {
 /* replaces cly_r.hit (src/cly.h:93-100): hits of read i are hits[first .. first+n) in final order */
 typedef struct {
 	uint32_t first, n;
-	int32_t status;       /* 0, or DSB_ECAP with the overflowing arena in the low bits */
+	int32_t status;       /* 0, or DSB_ECAP * 256 - bits: a capacity the read exceeded even in the second run (bits: 1 anchors,
+	                         2 chains, 4 match nodes, 8 hit buffer, 16 loop budget) */
 	uint32_t fast;        /* cly_r.fast_classify */
 	uint32_t device_us;   /* time the read occupied its wavefront (100 MHz wall clock), diagnostics */
 	uint32_t n_anc;       /* cly_r.anchor_v.n when classify_seq returns (printed by the DES writers) */
@@ -79,7 +86,15 @@ typedef struct {
 	float order_ms;        /* scoring + ordering of the reads (longest first) + the probes of the early launch */
 	float tail_ms;         /* after the main launch: waiting for the early launch (heaviest reads, second stream) + the second run */
 	uint32_t n_early;      /* reads that went through the early launch */
-	uint32_t n_retry;      /* reads run a second time with the large match-node arena (theirs overflowed) */
+	uint32_t n_retry;      /* reads run a second time (32x match nodes, 8x anchors, 4x chains, 16x loop budget): theirs ran out */
+	uint32_t n_regrow;     /* reads run again after the hit buffer had to be regrown */
+	uint32_t pad;
+	/* work counters of the classify kernels, counted on the device (the terms of the algorithmic bytes) */
+	uint64_t n_occ;        /* occ() evaluations (src/bwt.c:43) */
+	uint64_t n_mem;        /* bwt_MEM_search calls = hash_index pairs read (src/cly.c:1388) */
+	uint64_t n_sa;         /* get_uni calls = SA sample + unitig + ref-position lookups (src/cly.c:471) */
+	uint64_t ref_bases;    /* reference bases fetched by get_ref (src/cly.c:435) */
+	uint64_t main_occ, main_mem, main_sa, main_ref_bases;   /* the same for the main k_classify launch alone (what classify_ms times) */
 } dsb_timing;
 
 /* load_idx (src/idx.c:1103-1160, src/bwt.c:68-104): read <dir>/deSAMBA.* into host memory */
@@ -93,14 +108,36 @@ int         dsb_index_ek_len(const dsb_index *idx);
 /* host mirror of the device rank structure, for layout tests without a GPU (occ, src/bwt.c:43-65) */
 uint64_t dsb_index_occ_host(const dsb_index *idx, uint64_t r, uint8_t *c);
 
-/* classify_main's set-up (src/cly_mt.c:518-550): stage the index into HBM, allocate arenas */
+/* classify_main's set-up (src/cly_mt.c:518-550): stage the index into HBM, allocate arenas.  The staged index is shared
+ * by all contexts of one (index, device) pair: a second context on a device costs only its arenas and buffers. */
+int  dsb_device_count(void);           /* gfx950 or not: HIP devices visible to the process */
 int  dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opts, dsb_ctx **ctx);
 void dsb_ctx_destroy(dsb_ctx *ctx);
-/* reset the running max_read_l (src/cly.c:2958) -- start of a new input file */
+/* reset the running max_read_l (src/cly.c:2958).  The reference never resets it during a run -- its per-thread buffers
+ * are allocated once, before the loop over the input files (src/cly_mt.c:538-556) -- so a drop-in caller calls this only
+ * where a new `deSAMBA classify` process would start */
 void dsb_ctx_reset_history(dsb_ctx *ctx);
-/* set it explicitly: the longest read of this input file before the next batch (for callers that deal the batches of one
- * file to several contexts and therefore carry the prefix maximum themselves) */
+/* set it explicitly: the longest read of the run before the next batch (for callers that deal batches to several
+ * contexts and therefore carry the prefix maximum themselves) */
 void dsb_ctx_set_history(dsb_ctx *ctx, uint32_t max_len_before);
+/* input slots (dsb_opts.input_slots > 1): the upload / run / fetch / timing calls below work on the selected slot, so a
+ * ctx can keep several batches staged in HBM and run them in any order */
+int  dsb_ctx_select_slot(dsb_ctx *ctx, int slot);
+
+/* several GPUs of one node: reads sharded, index replicated, no collective.  One dsb_ctx per entry of
+ * device_ids (a device listed twice gets two contexts that overlap each other's copies and kernels). */
+int  dsb_ctx_create_multi(dsb_index *idx, const int *device_ids, int n_dev, const dsb_opts *opts, dsb_multi **m);
+void dsb_multi_destroy(dsb_multi *m);
+int  dsb_multi_n(const dsb_multi *m);
+dsb_ctx *dsb_multi_ctx(dsb_multi *m, int i);          /* for callers that drive the contexts themselves (the CLI) */
+void dsb_multi_reset_history(dsb_multi *m);
+/* the kt_for seam over all contexts: the batch is cut by dsb_shard_plan, results in input order, valid until the next call */
+int  dsb_multi_classify_batch(dsb_multi *m, const dsb_read *reads, size_t n, dsb_result *out);
+/* the sharding rule: contiguous chunks of the input order (a chunk ends after chunk_bases bases or chunk_reads reads;
+ * 0 = 64 Mbases / 4096 reads) dealt round-robin over `world` ranks; hist_max_before = longest read before the chunk,
+ * the only cross-read state (max_read_l, src/cly.c:2958).  out may be NULL to count (n_out). */
+typedef struct { uint64_t start, end; uint32_t hist_max_before; int32_t rank; } dsb_chunk;
+int  dsb_shard_plan(const uint32_t *lengths, size_t n, int world, uint64_t chunk_bases, uint32_t chunk_reads, dsb_chunk *out, size_t cap, size_t *n_out);
 
 /* the kt_for seam (src/cly_mt.c:389): classify n reads; results valid until the next call */
 int  dsb_classify_batch(dsb_ctx *ctx, const dsb_read *reads, size_t n, dsb_result *out);

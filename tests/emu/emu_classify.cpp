@@ -15,6 +15,8 @@ struct EmuCtx {
 	DsbDevIndex dx; std::vector<uint8_t> arena; uint32_t max_len; WCtx w; size_t sms_off;
 	std::vector<uint8_t> bin; std::vector<uint64_t> pk, bits;
 	std::vector<DsbSeed> seedsF, seedsR;
+	uint32_t limit_set = 0;
+	uint32_t cnt[4];          // work counters of the last read (occ, MEM searches, SA lookups, reference bases)
 };
 
 static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -66,6 +68,7 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	static uint4 emu_ring[DSB_RING]; w.ring = emu_ring;
 	static uint32_t emu_red[4]; w.red = emu_red; w.round_info = (uint32_t *)(s + off[17]);
 	w.lane_anc = (DsbAnchor *)(s + off[14]); w.lane_spset = (uint64_t *)(s + off[15]); w.top_idx = (uint32_t *)(s + off[16]); w.anc_cap = DSB_ANC_CAP;
+	w.anc_cap_main = DSB_ANC_CAP; w.hit_cap = DSB_HIT_CAP; w.step_limit = getenv("DSB_EMU_STEP_LIMIT") ? (uint32_t)atol(getenv("DSB_EMU_STEP_LIMIT")) : DSB_STEP_LIMIT;
 }
 
 // returns n_hits (or -status when a cap/timeout status was raised); hits as DsbHitOut
@@ -99,6 +102,8 @@ extern "C" int emu_classify(void *p, const char *seq, uint32_t L, int hist_max, 
 			if (bo) bo[q] = (uint8_t)hit;
 		}
 	WCtx &w = e->w;
+	if (e->limit_set) w.step_limit = e->limit_set;
+	memset(e->cnt, 0, sizeof e->cnt); w.k.c = e->cnt; w.k.uni = 1;
 	w.bin = F; w.L = L; w.status = 0; w.max_read_l = hist_max;
 	classify_read(w, e->bits.data(), e->bits.data() + n_words);
 	if (w.status) return -(w.status | (w.stage << 8));
@@ -153,5 +158,10 @@ extern "C" uint32_t emu_sms_peak(void *p)
 	while (n && a[n - 1] == 0xCDCDCDCDu) n--;
 	return (uint32_t)((n + 3) / 4);
 }
+// loop budget of the following reads (DSB_STEP_LIMIT by default); steps the last read charged
+extern "C" void emu_set_step_limit(void *p, uint32_t v) { ((EmuCtx *)p)->w.step_limit = v; ((EmuCtx *)p)->limit_set = v; }
+extern "C" void emu_steps(void *p, uint32_t out[2]) { out[0] = ((EmuCtx *)p)->w.steps; out[1] = ((EmuCtx *)p)->w.lsteps; }
+// work counters of the last read: occ, MEM searches, SA lookups, reference bases fetched
+extern "C" void emu_counters(void *p, uint32_t out[4]) { memcpy(out, ((EmuCtx *)p)->cnt, 16); }
 // cly_r.anchor_v.n when classify_seq returned (printed by the DES writers)
 extern "C" uint32_t emu_n_anc(void *p) { return ((EmuCtx *)p)->w.n_anc; }

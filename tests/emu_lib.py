@@ -27,6 +27,7 @@ class Emu:
         L.emu_n_anc.argtypes = [C.c_void_p]; L.emu_n_anc.restype = C.c_uint32
         L.emu_sms_peak.argtypes = [C.c_void_p]; L.emu_sms_peak.restype = C.c_uint32
         L.emu_seeds.argtypes = [C.c_void_p, C.c_int, C.POINTER(EmuSeed), C.c_int, C.POINTER(C.c_uint32)]
+        L.emu_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         self.L = L
         self.idx = C.c_void_p()
         rc = L.dsb_index_open(os.fsencode(index_dir), C.byref(self.idx))
@@ -47,6 +48,12 @@ class Emu:
 
     def n_anc(self):
         return int(self.L.emu_n_anc(self.e))
+
+    def counters(self):
+        """work counters of the last read: (occ, MEM searches, SA lookups, reference bases fetched)"""
+        out = (C.c_uint32 * 4)()
+        self.L.emu_counters(self.e, out)
+        return tuple(out)
 
     def seeds(self, strand):
         buf = (EmuSeed * 65536)(); ts = C.c_uint32()

@@ -27,9 +27,40 @@ def strain():
     open(os.path.join(out, "reads.fq.md5"), "w").write(hashlib.md5(open(os.path.join(d, "reads.fq"), "rb").read()).hexdigest() + "\n")
 
 
+def kseq():
+    """tests/golden/kseq: awkward FASTQ/FASTA texts of reads shorter than 40 bases (unmapped whatever the index, so the
+    SAM_FULL output is the parser's view of name / sequence / quality) and the reference's output for each: pins the
+    record rules of kseq_read (src/lib/utils.c:939-977) -- '\\r' kept, empty lines inside a sequence, whole-line
+    quality, records with a quality string of the wrong length dropped -- and documents what the reference does
+    with FASTA input (every other record lost on the first use of a slot)."""
+    import random
+    out = os.path.join(ROOT, "tests", "golden", "kseq"); os.makedirs(out, exist_ok=True)
+    rnd = random.Random(5)
+    dna = lambda k: bytes(rnd.choice(b"ACGTN") for _ in range(k))
+    q = lambda k: bytes(rnd.choice(b"@>+5I#!") for _ in range(k))
+    four = b"".join(b"@r%d some text\n%s\n+\n%s\n" % (i, s, q(len(s))) for i, s in enumerate(dna(rnd.randint(1, 38)) for _ in range(24)))
+    multi = b""
+    for i in range(16):
+        lines = [dna(rnd.randint(1, 12)) for _ in range(rnd.randint(1, 3))]; tot = sum(map(len, lines)); qq = q(tot)
+        cut = sorted(rnd.sample(range(1, tot), min(2, tot - 1))) if tot > 2 else []
+        qs = [qq[a:b] for a, b in zip([0] + cut, cut + [tot])]
+        multi += b"@m%d\n" % i + b"\n".join(lines) + b"\n+m%d\n" % i + b"\n".join(qs) + b"\n"
+    blank = b"junk before\n\n" + four[:400].rsplit(b"\n@", 1)[0] + b"\n\n\n" + b"@b1\nACGT\n\nTTGA\n+\n55555555\n@b2\nAC\n+\n55\n\n\n"
+    badqual = b"@g1\nACGTACGT\n+\n55555555\n@short\nACGTACGT\n+\n555\n@g2\nTTTT\n+\n5555\n@long\nACGT\n+\n555555\n@g3\nGGGG\n+\n5555\n"
+    fasta = b"".join(b">c%d\n%s\n" % (i, dna(rnd.randint(5, 38))) for i in range(8))
+    sets = {"four.fq": four, "crlf.fq": four.replace(b"\n", b"\r\n"), "multi.fq": multi, "blank.fq": blank, "badqual.fq": badqual,
+            "no_nl.fq": four.rstrip(b"\n"), "records.fa": fasta}
+    idx = os.path.join(DEMO, "index")
+    for name, data in sets.items():
+        path = os.path.join(out, name)
+        open(path, "wb").write(data)
+        run([os.path.join(REF, "deSAMBA"), "classify", "-t", "1", "-f", "SAM_FULL", idx, path, "-o", path + ".full.ref.sam"])
+
+
 def main():
-    strain()
     subprocess.check_call([os.path.join(ROOT, "tools", "make_demo_index.sh"), DEMO])
+    strain()
+    kseq()
     idx = os.path.join(DEMO, "index")
     sim = os.path.join(ROOT, "tools", "readsim")
     sets = [("ont20k", 12, 20000, 0.15, 11, "ont"), ("ngs150", 400, 150, 0.01, 12, "ngs"), ("pb", 24, 0, 0.13, 13, "pacbio"),
@@ -64,6 +95,16 @@ def main():
         f.write("@r57290\nAATGCTCAGGTGGAGGAGGTCAGAGTGTATGATGGTACGGAGGAACTACCAGGGGATCCAGATATGATGAGATACATTGATAGATATGGTCAACACCAAACAAAAGATGCTGTAGAACAGGTGCTGCTTTATTAAGATGCTGTAGAACAGG\n+\n" + "5" * 151 + "\n")
     run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx, appc, "-o", os.path.join(OUT, "appc.ubfree.sam")])
     run([os.path.join(REF, "deSAMBA"), "classify", "-t", "1", idx, appc, "-o", os.path.join(OUT, "appc.stock.sam")])
+    # several input files in one run: max_read_l (src/cly.c:2958) runs over all of them (the per-thread buffers are allocated
+    # once, before the loop over the files, src/cly_mt.c:538-556), so the 150-bp reads behind the 20-kbp file are filtered in
+    # 3G mode -- one reference run over the five files, not the concatenation of five runs
+    # (ngs_e14: 150-bp reads at 14 % error, some of which score between the 2G and the short-3G cut)
+    run([sim, idx, os.path.join(OUT, "ngs_e14.fq"), "120", "150", "0.14", "21", "ngs"])
+    run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx, os.path.join(OUT, "ngs_e14.fq"), "-o", os.path.join(OUT, "ngs_e14.ubfree.sam")])
+    multi = [os.path.join(OUT, n + ".fq") for n in ("ont20k", "ngs_e14", "pb", "appc", "wrapq", "ngs150")]
+    run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx] + multi + ["-o", os.path.join(OUT, "multi6.ubfree.sam")])
+    multi = [os.path.join(OUT, n + ".fq") for n in ("pb", "ngs_e14", "ngs150", "appc")]
+    run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx] + multi + ["-o", os.path.join(OUT, "multi4.ubfree.sam")])
     # demo: the reference's own quick-start output (README.md:30-42): md5 + first 60 lines
     demo_sam = os.path.join(DEMO, "ref_demo.sam")
     run([os.path.join(REF, "deSAMBA"), "classify", "-t", "4", idx, os.path.join(DEMO, "ERR1050068.fastq"), "-o", demo_sam])

@@ -1,6 +1,8 @@
 """The CLI's input side (desamba_amd/csrc/desamba_main.c: pinned-buffer filling, carry-over between buffers, in-place
-record parser) against an independent character-level restatement of kseq_read (src/lib/utils.c:939-977), on awkward
-inputs and with buffers barely larger than one record.  No GPU."""
+record parser) against an independent character-level restatement of the reference's kseq_read (src/lib/utils.c:939-977,
+the old kseq that keeps '\\r' and takes the first character of every sequence line as data), on awkward inputs and with
+buffers barely larger than one record; tests/test_oracle_golden.py::test_kseq_rules_against_reference pins the
+restatement to the compiled reference.  No GPU."""
 import gzip
 import os
 import random
@@ -12,14 +14,31 @@ from conftest import ROOT
 
 
 def kseq_records(data: bytes):
-    """character-level kseq_read: yields (name, seq, qual or None)"""
+    """character-level restatement of the reference's kseq_read (the OLD kseq: ks_getc / ks_getuntil2 with '\\n' as the
+    only line delimiter) driven as read_reads drives it (src/cly_mt.c:42-56: a record whose kseq_read returns -2 is
+    dropped and reading goes on behind it): yields (name, seq, qual or None)"""
     pos = 0; n = len(data); last = 0
+
     def getc():
         nonlocal pos
         if pos >= n:
             return -1
         c = data[pos]; pos += 1
         return c
+
+    def getuntil(delims, out):
+        """ks_getuntil2: append up to the first delimiter (consumed, not appended); -1 only at EOF with nothing read;
+        returns (code, delimiter or 0)"""
+        nonlocal pos
+        if pos >= n:
+            return -1, 0
+        while pos < n:
+            c = data[pos]; pos += 1
+            if c in delims:
+                return 0, c
+            out.append(c)
+        return 0, 0
+
     while True:
         if last == 0:
             c = getc()
@@ -29,46 +48,33 @@ def kseq_records(data: bytes):
                 return
             last = c
         name = bytearray(); seq = bytearray(); qual = bytearray()
-        c = getc()
-        while c != -1 and c not in b" \t\n\r\x0b\x0c":
-            name.append(c); c = getc()
-        if c == -1 and not name:
+        rc, c = getuntil(b" \t\n\r\x0b\x0c", name)
+        if rc < 0:
             return
         if c != 10:
-            while c != -1 and c != 10:
-                c = getc()
+            getuntil(b"\n", bytearray())
         c = getc()
         while c != -1 and c not in (62, 43, 64):
-            if c == 10:
-                c = getc(); continue
-            seq.append(c)
-            c = getc()
-            while c != -1 and c != 10:
-                if c != 13:
-                    seq.append(c)
-                c = getc()
+            seq.append(c)                      # whatever it is, '\n' and '\r' included
+            getuntil(b"\n", seq)
             c = getc()
         if c in (62, 64):
             last = c
         if c != 43:
-            if c == -1:
-                last = 0
             yield bytes(name), bytes(seq), None
             continue
         c = getc()
         while c != -1 and c != 10:
             c = getc()
         if c == -1:
-            raise ValueError("truncated")
-        while len(qual) < len(seq):
-            c = getc()
-            if c == -1:
+            return                             # -2 at the end of the input
+        while True:
+            rc, _ = getuntil(b"\n", qual)
+            if rc < 0 or len(qual) >= len(seq):
                 break
-            if c not in (10, 13):
-                qual.append(c)
         last = 0
         if len(qual) != len(seq):
-            raise ValueError("truncated")
+            continue                           # -2: the record is dropped
         yield bytes(name), bytes(seq), bytes(qual)
 
 
@@ -83,10 +89,12 @@ def harness(built, tmp_path_factory):
 
 def run_harness(harness, cap, path):
     out = subprocess.run([harness, str(cap), path], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    def unesc(b):
+        return b.replace(b"\\n", b"\n").replace(b"\\r", b"\r").replace(b"\\t", b"\t").replace(b"\\\\", b"\\") if b"\\" in b else b
     recs = []
     for line in out.split(b"\n")[:-1]:
         name, seq, qual, hist = line.split(b"\t")
-        recs.append((name, seq, qual, int(hist)))
+        recs.append((unesc(name), unesc(seq), unesc(qual), int(hist)))
     return recs
 
 
@@ -135,13 +143,15 @@ def test_parser_matches_kseq(harness, tmp_path, name):
                 run_max = max(run_max, len(s))
 
 
-def test_two_files_reset_history(harness, tmp_path):
+def test_history_runs_over_all_files(harness, tmp_path):
+    """max_read_l is never reset between input files (the reference allocates its per-thread buffers once, before the
+    loop over the files: src/cly_mt.c:538-556, src/cly.c:2958)"""
     a = tmp_path / "a.fq"; b = tmp_path / "b.fq"
     a.write_bytes(b"@a1\n" + b"A" * 500 + b"\n+\n" + b"5" * 500 + b"\n")
     b.write_bytes(b"@b1\nACGT\n+\n5555\n@b2\nAC\n+\n55\n")
     out = subprocess.run([harness, "2000", str(a), str(b)], check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.split(b"\n")[:-1]
     assert [l.split(b"\t")[0] for l in out] == [b"a1", b"b1", b"b2"]
-    assert [int(l.split(b"\t")[3]) for l in out] == [0, 0, 0]      # second file starts a new history; both of its reads share a batch
+    assert [int(l.split(b"\t")[3]) for l in out] == [0, 500, 500]  # both reads of the second file share a batch
 
 
 def test_parallel_pread_path(harness, tmp_path, monkeypatch):

@@ -43,7 +43,7 @@ def test_demo_sam_md5(gpu, demo, golden_md5):
     assert hashlib.md5(sam).hexdigest() == golden_md5
 
 
-@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq"])
+@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq", "ngs_e14"])
 def test_synthetic_golden_sam(gpu, name):
     D, idx, ctx = gpu
     hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))
@@ -184,11 +184,15 @@ def test_cli_options(gpu, tmp_path, args, fq, exp):
 
 def test_cli_many_batches_files_and_gzip(gpu, tmp_path, monkeypatch):
     """the CLI pipeline with buffers of 256 KB (dozens of batches alternating between the two device contexts, records
-    carried over buffer ends), several input files (history restarts per file) and gzip input"""
+    carried over buffer ends), several input files and gzip input.  max_read_l runs over ALL files, as in the reference
+    (its per-thread buffers are allocated once, before the loop over the files: src/cly_mt.c:538-556): the expected
+    output is ONE reference run over the six files, in which the 150-bp reads behind the 20-kbp file are filtered in 3G
+    mode -- not the concatenation of six single-file runs"""
     import gzip
     import subprocess
-    names = ["ont20k", "ngs150", "pb", "appc", "wrapq"]
-    exp = b"".join(open(os.path.join(GOLDEN, "synth", n + ".ubfree.sam"), "rb").read() for n in names)
+    names = ["ont20k", "ngs_e14", "pb", "appc", "wrapq", "ngs150"]
+    exp = open(os.path.join(GOLDEN, "synth", "multi6.ubfree.sam"), "rb").read()
+    assert exp != b"".join(open(os.path.join(GOLDEN, "synth", n + ".ubfree.sam"), "rb").read() for n in names)
     files = []
     for i, n in enumerate(names):
         src = os.path.join(GOLDEN, "synth", n + ".fq")
@@ -258,3 +262,136 @@ def test_second_index_golden(strain):
         assert sam == open(strain["sam"], "rb").read()
     finally:
         ctx.close(); idx.close()
+
+
+def _cli(args, out):
+    import subprocess
+    p = subprocess.run([os.path.join(ROOT, "desamba_amd", "bin", "deSAMBA"), "classify"] + args + ["-o", str(out)], stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr
+    return p.stderr
+
+
+def test_cli_two_logical_shards_on_one_device(gpu, tmp_path, monkeypatch):
+    """`-g 0,0`: the multi-GPU host path (one worker thread and two contexts per listed device, batches dealt to whichever
+    is free, max_read_l carried in the batch header, ordered writer) with two logical shards on the one device of the
+    test box; expected = ONE reference run over the four files"""
+    monkeypatch.setenv("DSB_CLI_BATCH_KB", "128")
+    files = [os.path.join(GOLDEN, "synth", n + ".fq") for n in ("pb", "ngs_e14", "ngs150", "appc")]
+    out = tmp_path / "out.sam"
+    _cli(["-g", "0,0", os.path.join(ROOT, "data", "demo", "index")] + files, out)
+    assert out.read_bytes() == open(os.path.join(GOLDEN, "synth", "multi4.ubfree.sam"), "rb").read()
+    out2 = tmp_path / "out2.sam"
+    _cli(["-g", "all", os.path.join(ROOT, "data", "demo", "index")] + files, out2)
+    assert out2.read_bytes() == out.read_bytes()
+
+
+def test_multi_api_shards_a_batch(gpu, monkeypatch):
+    """dsb_ctx_create_multi + dsb_multi_classify_batch: one batch cut by dsb_shard_plan into chunks of 50 reads over two
+    contexts (device 0 listed twice): same hits as the single context, in input order, history carried per chunk"""
+    D, idx, ctx = gpu
+    recs = D.read_fastq(os.path.join(GOLDEN, "synth", "pb.fq")) + D.read_fastq(os.path.join(GOLDEN, "synth", "ngs_e14.fq")) + \
+        D.read_fastq(os.path.join(GOLDEN, "synth", "ngs150.fq"), 150)
+    single, sam_single = classify_all(D, ctx, recs)
+    monkeypatch.setenv("DSB_SHARD_CHUNK_READS", "50")
+    m = D.Multi(idx, [0, 0])
+    try:
+        reads = D.make_reads(recs)
+        res = m.classify(reads)
+        got = [[res.hits[res.reads[i].first + k].key() for k in range(res.reads[i].n)] for i in range(len(recs))]
+        assert got == single
+        assert D.format_sam(idx, reads, res) == sam_single
+        # a second batch continues the history of the first (150-bp reads stay in 3G mode)
+        tail = D.read_fastq(os.path.join(GOLDEN, "synth", "ngs_e14.fq"))
+        res2 = m.classify(D.make_reads(tail))
+        ctx.reset_history(); ctx.classify(D.make_reads(recs))
+        exp2 = ctx.classify(D.make_reads(tail))
+        assert [[res2.hits[res2.reads[i].first + k].key() for k in range(res2.reads[i].n)] for i in range(len(tail))] == \
+            [[exp2.hits[exp2.reads[i].first + k].key() for k in range(exp2.reads[i].n)] for i in range(len(tail))]
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("knob,value,counter", [("DSB_HOUT_CAP", "8", "n_regrow"), ("DSB_STEP_LIMIT_RT", "300", "n_retry"), ("DSB_ANC_CAP_RT", "64", "n_retry")])
+def test_capacity_overruns_are_rerun_not_fatal(gpu, monkeypatch, knob, value, counter):
+    """the reference's per-read lists are unbounded and it has no loop budget; here a full hit buffer is regrown and the
+    reads that found it full run again, and reads that outgrow the anchor array or the loop budget of their wave slot run
+    again in the large second-run slots (8x anchors, 16x budget) -- forced by tiny capacities; results unchanged"""
+    D, idx, ctx = gpu
+    for name in ("ont20k", "pb", "ngs150"):
+        monkeypatch.setenv(knob, value)
+        hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))
+        if name != "ngs150" or knob == "DSB_HOUT_CAP":      # (150-bp reads stay below the tiny anchor array and loop budget)
+            assert getattr(ctx.timing(), counter) > 0, (name, knob)
+        assert sam == open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read(), (name, knob)
+        monkeypatch.delenv(knob)
+    hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", "pb.fq")))
+    assert ctx.timing().n_retry == 0 and ctx.timing().n_regrow == 0
+
+
+def test_input_slots_keep_batches_resident(demo):
+    """a ctx with several input slots holds several staged batches in HBM; they can be run in any order, repeatedly"""
+    import desamba_amd as D
+    idx = D.Index(demo["index"]); ctx = D.Ctx(idx, 0, input_slots=3)
+    try:
+        names = ["pb", "ont20k", "ngs150"]
+        reads = []
+        for k, n in enumerate(names):
+            ctx.select_slot(k); ctx.set_history(0)
+            reads.append(D.make_reads(D.read_fastq(os.path.join(GOLDEN, "synth", n + ".fq"))))
+            ctx.upload(reads[k])
+        for k in (2, 0, 1, 0, 2):
+            ctx.select_slot(k); ctx.run()
+            assert ctx.sam(ctx.fetch(), reads=reads[k]) == open(os.path.join(GOLDEN, "synth", names[k] + ".ubfree.sam"), "rb").read(), names[k]
+        with pytest.raises(D.DsbError):
+            ctx.select_slot(3)
+    finally:
+        ctx.close(); idx.close()
+
+
+@pytest.mark.parametrize("name", ["four.fq", "crlf.fq", "multi.fq", "blank.fq", "badqual.fq", "no_nl.fq"])
+def test_cli_reads_what_the_reference_reads(gpu, tmp_path, name, monkeypatch):
+    """the record rules of the reference's kseq_read ('\\r' kept, empty lines inside a sequence, whole-line quality, records
+    with a quality string of the wrong length dropped): SAM_FULL of the CLI == SAM_FULL of the reference binary
+    (tests/golden/kseq), also with a buffer barely larger than a record"""
+    path = os.path.join(GOLDEN, "kseq", name)
+    exp = open(path + ".full.ref.sam", "rb").read()
+    for kb in (None, "64"):
+        if kb:
+            monkeypatch.setenv("DSB_CLI_BATCH_KB", kb)
+        out = tmp_path / "o.sam"
+        _cli(["-f", "SAM_FULL", os.path.join(ROOT, "data", "demo", "index"), path], out)
+        assert out.read_bytes() == exp
+
+
+def test_cli_fasta_classifies_every_record(gpu, tmp_path):
+    """FASTA: the reference loses every other record (tests/golden/kseq/records.fa.full.ref.sam: c0, c2, c4, c6 of eight);
+    this CLI classifies all eight, and the records the reference keeps are byte-identical (documented deviation)"""
+    path = os.path.join(GOLDEN, "kseq", "records.fa")
+    ref = open(path + ".full.ref.sam", "rb").read().splitlines(True)
+    out = tmp_path / "o.sam"
+    _cli(["-f", "SAM_FULL", os.path.join(ROOT, "data", "demo", "index"), path], out)
+    ours = out.read_bytes().splitlines(True)
+    assert len(ours) == 8 and ours[0::2] == ref
+
+
+def test_device_work_counters_match_the_oracle(gpu, demo, oracle, tmp_path):
+    """dsb_timing.n_occ / n_mem / n_sa / ref_bases (the terms of the classify kernels' algorithmic bytes, counted on the
+    device) against the oracle's counters on the same reads: within 1 % (the device also walks the few islands that the
+    reference skips after a score > 512)"""
+    import subprocess
+    D, idx, ctx = gpu
+    fq = tmp_path / "c.fq"
+    subprocess.check_call([os.path.join(ROOT, "tools", "readsim"), demo["index"], str(fq), "1024", "50000", "0.15", "99", "ont"])
+    recs = D.read_fastq(str(fq))
+    classify_all(D, ctx, recs)
+    t = ctx.timing()
+    tot = [0, 0, 0, 0]
+    for (nm, seq, q) in recs:
+        oracle.classify(seq, 50000)
+        oc = oracle.counters()
+        for k, j in enumerate((2, 5, 3, 4)):
+            tot[k] += oc[j]
+    got = [t.n_occ, t.n_mem, t.n_sa, t.ref_bases]
+    for a, b in zip(got, tot):
+        assert b <= a <= 1.01 * b, (got, tot)
+    assert t.main_occ <= t.n_occ

@@ -8,7 +8,7 @@ import pytest
 
 from conftest import GOLDEN, ROOT, md5_file, sam_lines
 
-SETS = ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq"]
+SETS = ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq", "ngs_e14"]
 
 
 def test_demo_md5(demo, oracle, golden_md5, tmp_path):
@@ -27,7 +27,7 @@ def test_synthetic_golden(demo, oracle, name, tmp_path):
     assert sam_lines(str(out)) == sam_lines(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"))
 
 
-@pytest.mark.parametrize("name", SETS)
+@pytest.mark.parametrize("name", [n for n in SETS if n != "ngs_e14"])
 def test_distance_to_stock_reference(name):
     """the stock binary differs from the UB-free build only in AS / POS / CIGAR digits, never in the
     per-read list of (flag, reference) -- SURVEY.md 8a-UB"""
@@ -37,6 +37,20 @@ def test_distance_to_stock_reference(name):
     for x, y in zip(a, b):
         fx, fy = x.split(b"\t"), y.split(b"\t")
         assert fx[:3] == fy[:3]
+
+
+def test_history_runs_over_all_input_files(demo, oracle, tmp_path):
+    """max_read_l is never reset between input files (src/cly_mt.c:538-556, src/cly.c:2958): the golden SAM of ONE reference
+    run over six files (150-bp reads behind a 20-kbp file are filtered in 3G mode) equals the oracle's for their
+    concatenation, and differs from the concatenation of six single-file runs"""
+    names = ["ont20k", "ngs_e14", "pb", "appc", "wrapq", "ngs150"]
+    cat = tmp_path / "cat.fq"
+    cat.write_bytes(b"".join(open(os.path.join(GOLDEN, "synth", n + ".fq"), "rb").read() for n in names))
+    out = tmp_path / "cat.sam"
+    oracle.classify_file(str(cat), str(out), threads=2)
+    exp = open(os.path.join(GOLDEN, "synth", "multi6.ubfree.sam"), "rb").read()
+    assert out.read_bytes() == exp
+    assert exp != b"".join(open(os.path.join(GOLDEN, "synth", n + ".ubfree.sam"), "rb").read() for n in names)
 
 
 def test_appendix_c_history_independence(demo, oracle):
@@ -77,3 +91,45 @@ def test_second_index_golden(strain, tmp_path):
     out = str(tmp_path / "strain.sam")
     ora.classify_file(strain["fastq"], out)
     assert open(out, "rb").read() == open(strain["sam"], "rb").read()
+
+
+KSEQ = ["four.fq", "crlf.fq", "multi.fq", "blank.fq", "badqual.fq", "no_nl.fq"]
+
+
+def _unmapped_full(recs):
+    return b"".join(n + b"\t4\t*\t0\t0\t*\t*\t0\t0\t" + s + b"\t" + (q if q is not None else b"(null)") + b"\t\n" for n, s, q in recs)
+
+
+@pytest.mark.parametrize("name", KSEQ)
+def test_kseq_rules_against_reference(demo, oracle, name, tmp_path):
+    """tests/golden/kseq: awkward texts of reads shorter than 40 bases (unmapped, so SAM_FULL shows name / sequence /
+    quality as parsed) with the output of the reference binary: pins the three restatements of the reference's
+    kseq_read (the oracle's reader, the Python reader of the test helpers, and tests/test_cli_parser.py's
+    character-level one that the CLI's in-place parser is tested against)"""
+    import desamba_amd as D
+    import test_cli_parser as T
+    path = os.path.join(GOLDEN, "kseq", name)
+    exp = open(path + ".full.ref.sam", "rb").read()
+    data = open(path, "rb").read()
+    assert _unmapped_full(T.kseq_records(data)) == exp
+    assert _unmapped_full(D.parse_fastq(data)) == exp
+    out = tmp_path / "o.sam"
+    oracle.classify_file(path, str(out), full=1)
+    assert out.read_bytes() == exp
+
+
+def test_fasta_every_record_is_classified(demo, oracle, tmp_path):
+    """FASTA input: the reference loses every other record on the first use of a kseq_t slot (its look-ahead character
+    lives in the slot, the stream is shared: src/cly_mt.c:42-56, src/lib/utils.c:939-945) -- tests/golden/kseq/records.fa
+    shows it: c0, c2, c4, c6 of eight.  This build classifies every record (documented deviation); the records
+    the reference does keep are byte-identical."""
+    import desamba_amd as D
+    path = os.path.join(GOLDEN, "kseq", "records.fa")
+    ref = open(path + ".full.ref.sam", "rb").read().splitlines(True)
+    recs = D.parse_fastq(open(path, "rb").read())
+    assert [r[0] for r in recs] == [b"c%d" % i for i in range(8)]
+    ours = _unmapped_full(recs).splitlines(True)
+    assert ref == ours[0::2]
+    out = tmp_path / "o.sam"
+    oracle.classify_file(path, str(out), full=1)
+    assert out.read_bytes().splitlines(True) == ours
