@@ -85,6 +85,8 @@ class Gen:
 def run_ref(binary, index_dir, fq, out, threads):
     p = subprocess.run([binary, "classify", "-t", str(threads), index_dir, fq, "-o", out], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
     m = re.search(rb"(\d+) sequences processed in ([0-9.]+)s", p.stderr)
+    if not m:
+        sys.stderr.write("bench.py: %s exited with %d: %s\n" % (binary, p.returncode, p.stderr[-400:].decode(errors="replace")))
     return float(m.group(2)) if m else None
 
 

@@ -288,10 +288,13 @@ DV uint64_t fm_occ(DsbXP x, uint64_t r, uint32_t &c)
 }
 
 // ---- get_ref (src/cly.c:435-466); small windows are fetched redundantly by every lane ------
-DV void get_ref_small(const uint8_t *txt, uint8_t *out, int64_t off, int32_t length, bool fwd)
+// (oracle U6: a window whose start offset lies beyond the text -- `lim` bases -- reads as all 0; the reference's unsigned
+// window arithmetic produces such offsets when a hit hangs over the start of a reference, src/cly.c:2727,2742)
+DV void get_ref_small(const uint8_t *txt, uint64_t lim, uint8_t *out, int64_t off, int32_t length, bool fwd)
 {	// up to 24 bases per unaligned 8-byte load of the 2-bit text (4 KiB zero pad behind it), first base of a byte in its top bits
 	if (off < 0) off = 0;
 	if (length < 0) length = 0;
+	if ((uint64_t)off >= lim) { for (int32_t k = 0; k < length; k++) out[k] = 0; return; }
 	if (fwd) {
 		for (int32_t k0 = 0; k0 < length; k0 += 24) {
 			const uint64_t p = (uint64_t)off + (uint32_t)k0;
@@ -316,11 +319,12 @@ DV void get_ref_small(const uint8_t *txt, uint8_t *out, int64_t off, int32_t len
 	}
 }
 // forward window of any length, lanes split the bases; caller must wave_sync() before reading
-DV void get_ref_wave(const uint8_t *txt, int lane, uint8_t *out, int64_t off, int32_t length)
+DV void get_ref_wave(const uint8_t *txt, uint64_t lim, int lane, uint8_t *out, int64_t off, int32_t length)
 {	// `out` is 8-byte aligned (window buffers in the arena or in LDS): a lane unpacks 8 bases per step from one
 	// unaligned 4-byte load of the 2-bit text (refbin carries a 4 KiB zero pad) and stores them as one u64
 	if (off < 0) off = 0;
 	if (length < 0) length = 0;
+	if ((uint64_t)off >= lim) { for (int32_t k = lane; k < length; k += DSB_WAVE) out[k] = 0; return; }      // U6
 	for (int32_t k = 8 * lane; k < length; k += 8 * DSB_WAVE) {
 		uint64_t p = (uint64_t)off + (uint32_t)k;
 		const uint32_t raw = dsb_g32u(txt + (p >> 2));
@@ -513,7 +517,7 @@ DV void get_new_ed(DsbXP x, const Cnt &k, uint32_t *e_d, uint32_t *len_, uint32_
 		for (uint32_t k = 0; k < len; k++) q[k] = qp[k];
 	}
 	uint32_t n_rw = len;
-	get_ref_small(t_b, t, t_off, len, !is_FWD);
+	get_ref_small(t_b, x->ref_bases, t, t_off, len, !is_FWD);
 	if (len > 0 && t[0] == q[0]) {
 		int mtc;
 		do {
@@ -522,7 +526,7 @@ DV void get_new_ed(DsbXP x, const Cnt &k, uint32_t *e_d, uint32_t *len_, uint32_
 				*l_mem_ext += mtc; max_len -= mtc; len = MINV(12, max_len);
 				if (is_FWD) { q_off -= mtc; t_off -= mtc; for (uint32_t k = 0; k < len; k++) q[k] = q_b[q_off - k]; }
 				else { t_off += mtc; qp += mtc; for (uint32_t k = 0; k < len; k++) q[k] = qp[k]; }
-				get_ref_small(t_b, t, t_off, len, !is_FWD); n_rw += len;
+				get_ref_small(t_b, x->ref_bases, t, t_off, len, !is_FWD); n_rw += len;
 			}
 		} while (mtc > 0);
 	}
@@ -573,7 +577,7 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 		if (uni >= 0) {
 			if (DSB_G32(x->uni, 2 * uni + 1) < 35) break;
 			l_pre = MINV(l_pre, u_off);
-			get_ref_small(t_b, t_pre, t_off - 1, l_pre, false); n_rw += l_pre;
+			get_ref_small(t_b, x->ref_bases, t_pre, t_off - 1, l_pre, false); n_rw += l_pre;
 		}
 		t_pre[l_pre] = '#'; q_pre[l_pre] = '$';
 		d_pre = lv_extd(t_pre, l_pre, q_pre, l_pre);
@@ -589,7 +593,7 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 		if (l_max_suf != 0) {
 			l_suf = MINV(l_max_suf, 12);
 			const uint8_t *q_suf = q_b + q_off_r;
-			get_ref_small(t_b, t_suf, t_off + l_m, l_suf, true); n_rw += l_suf;
+			get_ref_small(t_b, x->ref_bases, t_suf, t_off + l_m, l_suf, true); n_rw += l_suf;
 			if (t_suf[0] == q_suf[0]) {
 				int mtc;
 				do {
@@ -598,7 +602,7 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 						l_m += mtc;
 						s = Q_MEM[l_m] + Q_LV[d_pre * 20 + l_pre];
 						l_max_suf -= mtc; l_suf = MINV(l_max_suf, 12); q_suf += mtc;
-						get_ref_small(t_b, t_suf, t_off + l_m, l_suf, true); n_rw += l_suf;
+						get_ref_small(t_b, x->ref_bases, t_suf, t_off + l_m, l_suf, true); n_rw += l_suf;
 					}
 				} while (mtc > 0);
 			}
@@ -1875,7 +1879,7 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 				for (uint32_t k = 8 * lane; k < q_bytes; k += 8 * DSB_WAVE) *reinterpret_cast<uint64_t *>(lq + k) = ld_u64(q_str + q_lo + (int32_t)k);
 				ref = lt; qs = nullptr; lq_st = lq;
 			}
-			get_ref_wave(x->refbin, lane, ref, ref_offset, total_ref_len); cnt_add(Cnt{w.k.c, 1u}, 3, (uint32_t)total_ref_len);
+			get_ref_wave(x->refbin, x->ref_bases, lane, ref, ref_offset, total_ref_len); cnt_add(Cnt{w.k.c, 1u}, 3, (uint32_t)total_ref_len);
 			for (int k = total_ref_len + lane; k < total_ref_len + 64; k += DSB_WAVE) ref[k] = DSB_TPAD_VAL;   // reads reach <= 58 past the window
 			wave_sync();
 			n_sms = lq_st ? sdp_match_lds(w, n_sms, q_bg, q_ed, lq_st, q_lo, ref, total_ref_len, pre_refoffset + pre_mch, lnodes)
@@ -1967,7 +1971,7 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 				max_search_ref = l_read - c_h->q_ed + 60;
 			} else max_search_ref = t_length - c_t_offset;
 			max_search_ref = MINV(600u, max_search_ref);
-			get_ref_wave(x->refbin, w.lane, ref, c_t_offset + t_offset_global, max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50);
+			get_ref_wave(x->refbin, x->ref_bases, w.lane, ref, c_t_offset + t_offset_global, max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50);
 			wave_sync();
 			int search_q_ed = (int)best_q + 1000;
 			search_q_ed = MINV((uint32_t)search_q_ed, l_read);
@@ -2046,9 +2050,9 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 			} else max_search_ref = c_t_offset;
 			max_search_ref = MINV(600u, max_search_ref);
 			if (t_offset_global == 0 && c_t_offset < 50 + max_search_ref)
-				{ get_ref_wave(x->refbin, w.lane, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref), max_search_ref); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref); }
+				{ get_ref_wave(x->refbin, x->ref_bases, w.lane, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref), max_search_ref); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref); }
 			else
-				{ get_ref_wave(x->refbin, w.lane, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref - 50), max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50); }
+				{ get_ref_wave(x->refbin, x->ref_bases, w.lane, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref - 50), max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50); }
 			wave_sync();
 			int search_q_st = (int)best_q - 1000;
 			search_q_st = MAXV(search_q_st, 0);

@@ -35,6 +35,7 @@ struct DsbDevIndex {
 	const uint64_t *fm_sb;     // BWT of >= 2^32 symbols: 5 u64 per superblock (2^22 symbols), block counts are relative to them; else null
 	const uint64_t *hash_index;
 	const uint2 *sa; const uint2 *uni; const uint64_t *refpos; const uint8_t *refbin; const DsbRefInfo *refinfo;
+	uint64_t ref_bases;        // bases of the 2-bit reference text (windows that start beyond it read as 0, oracle U6)
 	const int *qmem;           // [2000]
 	const int *qlv;            // [20][20]
 	int filter_min_length, filter_min_score, filter_min_score_LV3;

@@ -441,7 +441,7 @@ static int stage_build(dsb_index *idx, int device, DsbStaged **out)
 	ST(stage_upload(s, (const uint2 *)h->sa, h->sa_size, &dx.sa));
 	ST(stage_upload(s, (const uint2 *)h->uni, h->n_uni + 1, &dx.uni));
 	ST(stage_upload(s, h->refpos, h->n_refpos + 1, &dx.refpos));
-	ST(stage_upload(s, h->refbin, h->n_refbin + 4096, &dx.refbin));
+	ST(stage_upload(s, h->refbin, h->n_refbin + 4096, &dx.refbin)); dx.ref_bases = h->n_refbin * 4;
 	ST(stage_upload(s, h->refinfo, h->n_ref, &dx.refinfo));
 	ST(stage_upload(s, h->Q_MEM, (size_t)2000, &dx.qmem));
 	ST(stage_upload(s, &h->Q_LV[0][0], (size_t)400, &dx.qlv));

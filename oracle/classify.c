@@ -60,6 +60,7 @@ struct ora_ctx {
 	ora_hit_t *out; uint32_t m_out;
 	sdir_t sd[2]; uint32_t read_len;
 	uint64_t cnt[8];      /* P0,P1,OCC,SA,RW,MEMS */
+	uint64_t ref_bases;   /* bases of the 2-bit reference text (U6) */
 	void *sort_tmp; size_t m_sort_tmp;
 };
 
@@ -248,6 +249,7 @@ static void get_ref(ora_ctx_t *c, const uint8_t *txt, uint8_t *out, int64_t off,
 	if (off < 0) off = 0;
 	if (length < 0) length = 0;
 	c->cnt[4] += (uint64_t)length;
+	if ((uint64_t)off >= c->ref_bases) { memset(out, 0, (size_t)length); return; }   /* U6 */
 	uint64_t o = (uint64_t)off >> 2; uint8_t odd = off & 3;
 	if (fwd)
 		for (uint32_t k = 0; k < (uint32_t)length; k++) {
@@ -1192,6 +1194,7 @@ static void detect_primary(chain_t *hit, uint32_t n_hit, uint32_t read_len)
 int ora_classify(ora_ctx_t *c, const ora_idx_t *x, const char *seq, uint32_t read_len, const ora_hit_t **hits)
 {
 	c->n_anc = 0; c->n_hit = 0; c->read_len = read_len;
+	c->ref_bases = x->n_refbin * 4;
 	memset(c->cnt, 0, sizeof c->cnt);
 	c->sd[0].l_seed_v = c->sd[1].l_seed_v = 0;
 	if (hits) *hits = NULL;

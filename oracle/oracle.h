@@ -20,6 +20,10 @@
  *   U5  lv_extd (src/cly.c:594) can read the byte in front of either string: for a
  *       string inside the read buffer that is the previous base (defined); for
  *       the local 13-byte buffers of map_seed/get_new_ed it never matches.
+ *   U6  a reference window whose start offset lies beyond the 2-bit text reads as all 0 ('A').  The reference computes
+ *       window offsets in unsigned 32-bit arithmetic (src/cly.c:2727,2742: c_t_offset - max_search_ref wraps when a
+ *       hit hangs over the start of a reference) and then reads up to 1 GB behind the text: a segmentation fault on
+ *       small indexes, arbitrary bytes on large ones (found with a read running over the start of its reference).
  *   U4  max_read_l (src/cly.c:2958) is the prefix maximum of read length in
  *       input order (= the reference's `-t 1` behaviour).
  */

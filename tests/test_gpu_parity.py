@@ -43,7 +43,7 @@ def test_demo_sam_md5(gpu, demo, golden_md5):
     assert hashlib.md5(sam).hexdigest() == golden_md5
 
 
-@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq", "ngs_e14"])
+@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq", "ngs_e14", "overhang"])
 def test_synthetic_golden_sam(gpu, name):
     D, idx, ctx = gpu
     hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))

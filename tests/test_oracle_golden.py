@@ -8,7 +8,7 @@ import pytest
 
 from conftest import GOLDEN, ROOT, md5_file, sam_lines
 
-SETS = ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq", "ngs_e14"]
+SETS = ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq", "ngs_e14", "overhang"]
 
 
 def test_demo_md5(demo, oracle, golden_md5, tmp_path):
@@ -27,7 +27,8 @@ def test_synthetic_golden(demo, oracle, name, tmp_path):
     assert sam_lines(str(out)) == sam_lines(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"))
 
 
-@pytest.mark.parametrize("name", [n for n in SETS if n != "ngs_e14"])
+# (no stock output for `overhang`: the stock binary crashes on it, oracle.h U6)
+@pytest.mark.parametrize("name", [n for n in SETS if n not in ("ngs_e14", "overhang")])
 def test_distance_to_stock_reference(name):
     """the stock binary differs from the UB-free build only in AS / POS / CIGAR digits, never in the
     per-read list of (flag, reference) -- SURVEY.md 8a-UB"""

@@ -23,7 +23,7 @@
 #include <pthread.h>
 
 typedef struct { char name[128]; uint64_t seq_l, seq_offset; } refinfo_t;
-typedef struct { uint8_t *txt; uint64_t nb; refinfo_t *ri; uint64_t nr; } gen_t;
+typedef struct { uint8_t *txt; uint64_t nb; refinfo_t *ri; uint64_t nr; uint64_t *by_len; } gen_t;   /* by_len: reference indexes, longest first */
 
 static inline uint64_t sm64(uint64_t *s)
 {
@@ -45,9 +45,16 @@ long readgen_open(const char *dir)
 	f = fopen(path, "rb"); if (!f) { perror(path); return 0; }
 	if (fread(&g->nr, 8, 1, f) != 1) return 0;
 	g->ri = malloc(g->nr * sizeof *g->ri); if (fread(g->ri, sizeof *g->ri, g->nr, f) != g->nr) return 0; fclose(f);
+	g->by_len = malloc(g->nr * 8);
+	for (uint64_t i = 0; i < g->nr; i++) g->by_len[i] = i;
+	for (uint64_t i = 1; i < g->nr; i++) {          /* insertion sort, a few thousand references at most matter here */
+		uint64_t v = g->by_len[i], j = i;
+		while (j > 0 && g->ri[g->by_len[j - 1]].seq_l < g->ri[v].seq_l) { g->by_len[j] = g->by_len[j - 1]; j--; }
+		g->by_len[j] = v;
+	}
 	return (long)g;
 }
-void readgen_close(long h) { gen_t *g = (gen_t *)h; if (g) { free(g->txt); free(g->ri); free(g); } }
+void readgen_close(long h) { gen_t *g = (gen_t *)h; if (g) { free(g->txt); free(g->ri); free(g->by_len); free(g); } }
 
 typedef struct { uint64_t state, r, start; long len; int rc, name_len; uint64_t off; } plan_t;
 typedef struct {
@@ -67,7 +74,7 @@ static void *gen_main(void *arg)
 		const long len = p->len;
 		uint64_t span = (uint64_t)(len * 1.2) + 64; if (span > ri->seq_l) span = ri->seq_l;
 		const uint64_t g0 = ri->seq_offset + p->start;
-		uint64_t k = 0;                                   /* source position inside the span; wraps if the span runs out */
+		uint64_t k = 0;                                   /* source position inside the span (1.2 x len + 64 bases: never runs out in practice; wraps if it does) */
 		char *seq = o; long n = 0;
 		j->seq_off[i] = (uint64_t)(seq - j->buf); j->seq_len[i] = (uint32_t)len;
 		while (n < len) {
@@ -108,8 +115,13 @@ long readgen_fill(long h, char *buf, size_t cap, long n_reads, long L, double e,
 			double z = sqrt(-2.0 * log(u1 + 1e-300)) * cos(6.283185307179586 * u2);
 			len = (long)exp(log(12000.0) - 0.18 + 0.6 * z); if (len < 500) len = 500; if (len > 80000) len = 80000;
 		}
-		uint64_t need = (uint64_t)(len * 1.2) + 64, r; int tries = 0;
-		do { r = sm64(&s) % g->nr; } while (g->ri[r].seq_l < need && ++tries < 64);
+		/* a reference uniformly among those long enough for the whole source span; none -> the longest, and a shorter read
+		 * (a read must not run over the end of its reference: the reference binary reads far out of bounds -- and
+		 * crashes on a small index -- when a hit hangs over the start of a reference, src/cly.c:2724-2727) */
+		uint64_t need = (uint64_t)(len * 1.2) + 64, r, n_ok = 0;
+		{ uint64_t lo = 0, hi = g->nr; while (lo < hi) { uint64_t m = (lo + hi) / 2; if (g->ri[g->by_len[m]].seq_l >= need) lo = m + 1; else hi = m; } n_ok = lo; }
+		if (n_ok) r = g->by_len[sm64(&s) % n_ok];
+		else { r = g->by_len[0]; len = (long)((g->ri[r].seq_l - 64) / 1.2); if (len < 1) len = 1; need = (uint64_t)(len * 1.2) + 64; }
 		uint64_t span = need < g->ri[r].seq_l ? need : g->ri[r].seq_l;
 		p->r = r; p->start = g->ri[r].seq_l > span ? sm64(&s) % (g->ri[r].seq_l - span) : 0; p->rc = (int)(sm64(&s) & 1); p->len = len; p->state = s;
 		char nm[160]; p->name_len = snprintf(nm, sizeof nm, "@r%ld_%lu_%lu_%c\n", i, (unsigned long)r, (unsigned long)p->start, p->rc ? 'R' : 'F');
