@@ -47,7 +47,7 @@ class DsbTiming(C.Structure):
     _fields_ = [("encode_ms", C.c_float), ("seed_probe_ms", C.c_float), ("classify_ms", C.c_float), ("total_ms", C.c_float),
                 ("windows", C.c_uint64), ("probes_t1", C.c_uint64), ("bases", C.c_uint64),
                 ("order_ms", C.c_float), ("tail_ms", C.c_float), ("n_early", C.c_uint32), ("n_retry", C.c_uint32),
-                ("n_regrow", C.c_uint32), ("pad", C.c_uint32),
+                ("n_regrow", C.c_uint32), ("seed_scan", C.c_uint32),
                 ("n_occ", C.c_uint64), ("n_mem", C.c_uint64), ("n_sa", C.c_uint64), ("ref_bases", C.c_uint64),
                 ("main_occ", C.c_uint64), ("main_mem", C.c_uint64), ("main_sa", C.c_uint64), ("main_ref_bases", C.c_uint64)]
 

@@ -178,6 +178,7 @@ struct WCtx {
 	int lane;
 	uint8_t *bin; uint32_t L;
 	DsbSeed *seeds;
+	DsbSeed *pre_seeds; const DsbSeedInfo *pre_info;   // seed lists made by k_seed_scan (null: scan the hit bits here)
 	DsbAnchor *anc, *anc_tmp; uint32_t n_anc, anc_cap;
 	uint32_t anc_cap_main, hit_cap, step_limit;   // capacities of this launch's arena (anchors, chains) and its loop budget
 	DsbAnchor *lane_anc; uint64_t *lane_spset; uint32_t *top_idx;   // per-lane scratch of the island-parallel fast_classify
@@ -2225,8 +2226,15 @@ DN uint32_t classify_read(WCtx &w, const uint64_t *bitsF, const uint64_t *bitsR)
 	SDir *sd = w.sd;
 	uint32_t n = read_len - w.x->ek_len + 1;
 	w.stage = 1; MARK(w, 1); if (w.dbg) w.tlast = DSB_CLOCK();
-	seed_vector(w, w.bin, bitsF, n, w.seeds, D_FORWARD, sd);
-	seed_vector(w, w.bin + read_len, bitsR, n, w.seeds + (read_len >> 2), D_REVERSE, sd + 1);
+	if (w.pre_seeds) {
+		// the seed lists of both strands came out of the seed-lookup kernel (k_seed_scan)
+		const DsbSeedInfo si = *w.pre_info;
+		sd[0].seed_v = w.pre_seeds; sd[0].l_seed_v = si.n_seed[0]; sd[0].bin_read = w.bin; sd[0].bits = bitsF; sd[0].direction = D_FORWARD; sd[0].total_score = si.total[0];
+		sd[1].seed_v = w.pre_seeds + (read_len >> 2); sd[1].l_seed_v = si.n_seed[1]; sd[1].bin_read = w.bin + read_len; sd[1].bits = bitsR; sd[1].direction = D_REVERSE; sd[1].total_score = si.total[1];
+	} else {
+		seed_vector(w, w.bin, bitsF, n, w.seeds, D_FORWARD, sd);
+		seed_vector(w, w.bin + read_len, bitsR, n, w.seeds + (read_len >> 2), D_REVERSE, sd + 1);
+	}
 	TICK(w, 0);
 	if (sd[0].total_score < sd[1].total_score) { SDir t = sd[0]; sd[0] = sd[1]; sd[1] = t; }
 	bool both_direction = ((sd[0].total_score - sd[1].total_score) <= (sd[0].total_score >> 3));

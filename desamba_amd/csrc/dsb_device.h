@@ -44,7 +44,9 @@ struct DsbDevIndex {
 };
 
 // ---- per-read records produced on the device -------------------------------------------------
-struct DsbSeed { uint32_t offset, len; uint32_t top; };                 // CLY_seed, src/cly.h:28-33
+struct DsbSeed { uint32_t offset; uint16_t len, top; };                  // CLY_seed, src/cly.h:28-33 (len <= 61)
+// per read: seeds of the forward strand at seed_off, of the reverse strand at seed_off + (len >> 2) (the reference's layout, src/cly.c:1241-1262)
+struct DsbSeedInfo { uint32_t n_seed[2], total[2]; uint32_t flags, pad; };   // [0] forward strand, [1] reverse strand; flags bit 0: a strand's seed list outgrew its place
 
 struct DsbAnchor {                                                       // Anchor, src/cly.h:44-61
 	uint16_t mtch_len; int16_t score; uint8_t left_len, left_ED, rigt_len, rigt_ED;

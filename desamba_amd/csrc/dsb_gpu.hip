@@ -19,6 +19,7 @@
 #include <sys/stat.h>
 #include "dsb_device.h"
 #include "dsb_probe.h"
+#include "dsb_seed_scan.h"
 // the per-read device code, instantiated for one wavefront per read
 #define DSB_GROUP 64
 #define DSB_NS dsb_g64
@@ -39,6 +40,7 @@ struct DsbReadDesc {
 	uint32_t n_win;        // len - k + 1 (0 if len < 40)
 	uint32_t n_words;      // ceil(n_win / 64)
 	int32_t  hist_max;     // max read length over the reads before this one (oracle U4)
+	uint64_t seed_off;     // into the seed blob, in DsbSeed records: (len >> 1) + 64 per read, forward strand first, reverse at + (len >> 2)
 };
 struct DsbWordDesc { uint32_t read; uint32_t word; };   // word: bit 31 = strand R, low bits = word index
 
@@ -217,6 +219,85 @@ __global__ void __launch_bounds__(256) k_seed_probe_reads(DsbDevIndex x, const D
 }
 
 
+// ---- seed lookup, one lane per read strand (dsb_seed_scan.h): probes what the reference's scan consumes and writes the seed lists
+// Strand g = 2 * (read slot) + (0 forward, 1 reverse); both strands of a read sit in neighbouring lanes and read the same
+// packed words.  A round of a lane: the (at most four) windows its scan wants next lie within 12 windows of each other, so
+// one 16-byte load of the forward strand's packed words holds all their k-mers; then, stage by stage with the loads of a
+// stage issued for all slots before the first is used: low-complexity filter + hash -> summary bit (L2) -> table 0 ->
+// table 1 (get_exist_kmer, src/cly.c:956-972).  `order` (optional) lists the reads longest first, so that the lanes of a
+// wavefront finish together on ragged batches.
+__global__ void __launch_bounds__(256) k_seed_scan(DsbDevIndex x, const DsbReadDesc *__restrict__ rd, const uint32_t *__restrict__ order, uint32_t n_reads,
+                                                   const uint64_t *__restrict__ pk, DsbSeed *__restrict__ seeds, DsbSeedInfo *__restrict__ sinfo,
+                                                   const uint8_t *__restrict__ summ, int summ_shift, unsigned long long *counters)
+{
+	const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	const bool active = g < 2ull * n_reads;
+	const uint32_t r = active ? (order ? order[g >> 1] : (uint32_t)(g >> 1)) : 0u;
+	const bool rc = (g & 1) != 0;
+	DsbReadDesc d = rd[r];
+	const uint64_t *__restrict__ P = pk + d.pk_off;                          // forward strand words
+	const uint32_t L = d.len, nF = L >> 2, cap = rc ? ((L >> 1) + 64 - nF) : nF;
+	DsbSeed *__restrict__ sv = seeds + d.seed_off + (rc ? nF : 0);
+	auto store = [&](uint32_t idx, uint32_t off, uint32_t len) { if (idx < cap) { DsbSeed v; v.offset = off; v.len = (uint16_t)len; v.top = 0; sv[idx] = v; } };
+	auto mark = [&](uint32_t idx) { if (idx < cap) sv[idx].top = 1; };
+	const int k = x.ek_len, sbm = x.single_base_max;
+	const uint64_t kmask = k >= 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+	DsbScan s; dsb_scan_init(s, active ? d.n_win : 0u);
+	uint32_t p0 = 0, p1 = 0;
+	for (;;) {
+		if (!__any(s.mode != DSB_SCAN_DONE)) break;                          // the wavefront leaves together: every lane reaches this
+		uint32_t want[4]; dsb_scan_want(s, want);
+		uint32_t lo = want[0] < want[1] ? want[0] : want[1];
+		{ const uint32_t l2 = want[2] < want[3] ? want[2] : want[3]; lo = l2 < lo ? l2 : lo; }
+		const bool any = lo != DSB_SCAN_NONE;
+		const uint32_t base = lo & ~31u;
+		uint64_t W0 = 0, W1 = 0;
+		if (any) { W0 = P[lo >> 5]; W1 = P[(lo >> 5) + 1]; }
+		uint64_t km[4], h1[4]; bool ok[4];
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			ok[t] = want[t] != DSB_SCAN_NONE; km[t] = 0; h1[t] = 0;
+			if (ok[t]) {
+				const uint32_t rel = want[t] - base;                          // < 64; a window that starts in W1 ends in W1
+				const uint64_t a = rel < 32 ? W0 : W1, b = rel < 32 ? W1 : 0ULL; const uint32_t sh = (rel & 31u) * 2;
+				const uint64_t hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
+				uint64_t v = (hi >> (64 - 2 * k)) & kmask;
+				if (rc) v = dsb_revcomp_kmer(v, k);
+				ok[t] = dsb_kmer_ok(v, k, sbm); km[t] = v;
+				if (ok[t]) { p0++; h1[t] = dsb_ph1(v) & x.ek_mask; }
+			}
+		}
+		if (summ) {
+			uint8_t sb[4];
+#pragma unroll
+			for (int t = 0; t < 4; t++) { sb[t] = 0xff; if (ok[t]) sb[t] = summ[(h1[t] >> summ_shift) >> 3]; }
+#pragma unroll
+			for (int t = 0; t < 4; t++) ok[t] = ok[t] && ((sb[t] >> ((h1[t] >> summ_shift) & 7)) & 1);
+		}
+		uint8_t t0[4];
+#pragma unroll
+		for (int t = 0; t < 4; t++) { t0[t] = 0; if (ok[t]) t0[t] = x.ek0[h1[t] >> 3]; }
+#pragma unroll
+		for (int t = 0; t < 4; t++) ok[t] = ok[t] && ((t0[t] >> (7 - (h1[t] & 7))) & 1);
+		uint32_t bits = 0;
+		if (__any(ok[0] | ok[1] | ok[2] | ok[3])) {
+			uint8_t t1[4]; uint64_t h2[4];
+#pragma unroll
+			for (int t = 0; t < 4; t++) { t1[t] = 0; h2[t] = 0; if (ok[t]) { h2[t] = dsb_ph2(km[t]) & x.ek_mask; t1[t] = x.ek1[h2[t] >> 3]; p1++; } }
+#pragma unroll
+			for (int t = 0; t < 4; t++) if (ok[t] && ((t1[t] >> (7 - (h2[t] & 7))) & 1)) bits |= 1u << t;
+		}
+		if (s.mode != DSB_SCAN_DONE) dsb_scan_consume(s, bits, rc, store, mark);
+	}
+	dsb_scan_finish(s, mark);
+	if (active) { sinfo[r].n_seed[rc ? 1 : 0] = s.ns; sinfo[r].total[rc ? 1 : 0] = s.total; if (!rc) { sinfo[r].flags = 0; sinfo[r].pad = 0; } }
+	if (counters) {
+		unsigned long long a0 = p0, a1 = p1;
+		for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_down(a0, o); a1 += __shfl_down(a1, o); }
+		if ((threadIdx.x & 63) == 0) { if (a0) atomicAdd(counters, a0); if (a1) atomicAdd(counters + 1, a1); }
+	}
+}
+
 // ---- work order: longest-processing-time-first -----------------------------------------------------
 // The batch ends when its slowest read ends, and the slow reads are the ones whose sparse DP explodes:
 // tandem-repeat-like reads, where every reference 9-mer matches many read positions.  k_repeat_score
@@ -278,7 +359,7 @@ struct DsbSlotArena {
 #define DSB_DEFINE_CLASSIFY(KNAME, NS, THREADS)                                                                         \
 __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,   \
         const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout,  \
-        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg, uint32_t item_base, uint32_t slot_base, unsigned long long *work_cnt)  \
+        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg, uint32_t item_base, uint32_t slot_base, unsigned long long *work_cnt, DsbSeed *seed_blob, const DsbSeedInfo *sinfo)  \
 {                                                                                                                       \
 	const int lane = threadIdx.x;                                                                                       \
 	const uint32_t slot_id = slot_base + blockIdx.x;            /* arena slot (and debug row) of this wave */          \
@@ -333,6 +414,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 		uint64_t tacc0[14]; if (w.dbg) for (int i = 0; i < 14; i++) tacc0[i] = w.tacc[i];                               \
 		if (w.dbg && lane == 0) { w.dbg[2] = r; w.dbg[0] = 100; }                                                       \
 		w.bin = bin + d.bin_off + DSB_QPAD_L; w.L = d.len; w.status = 0; w.max_read_l = d.hist_max;                     \
+		w.pre_seeds = seed_blob ? seed_blob + d.seed_off : nullptr; w.pre_info = sinfo + r;                             \
 		uint32_t fast = NS::classify_read(w, bits + d.bit_off, bits + d.bit_off + d.n_words);                           \
 		if (w.boosted) __builtin_amdgcn_s_setprio(0);                                                                   \
 		/* publish the hits of this read */                                                                             \
@@ -373,6 +455,7 @@ __global__ void k_collect_retry(const DsbReadOut *rout, uint32_t n, uint32_t *li
 // ================================== host side ====================================================
 #include <mutex>
 #include <thread>
+#include <algorithm>
 
 // ---- the index staged in one device's HBM, shared by all contexts of that (index, device) pair -------------
 struct DsbStaged {
@@ -472,7 +555,9 @@ static void stage_release(DsbStaged *s)
 struct InSlot {
 	DsbReadDesc *d_rd = nullptr; char *d_ascii = nullptr; size_t cap_rd = 0, cap_ascii = 0;
 	std::vector<DsbReadDesc> h_rd;
-	size_t n_reads = 0; uint64_t n_words_total = 0, total_bases = 0, total_windows = 0; uint32_t max_len = 0;
+	size_t n_reads = 0; uint64_t n_words_total = 0, total_bases = 0, total_windows = 0, seed_entries = 0; uint32_t max_len = 0, min_len = 0;
+	uint32_t *d_scan_order = nullptr; size_t cap_scan_order = 0;   // reads longest first (ragged batches only), for k_seed_scan
+	bool ragged = false;
 };
 
 struct dsb_ctx {
@@ -487,6 +572,8 @@ struct dsb_ctx {
 	DsbSlotArena arena; int n_slots = 0;
 	DsbSlotArena arena_big; int n_slots_big = 0;  // second run of reads that outgrew an arena or their loop budget
 	uint32_t *d_score = nullptr, *d_order = nullptr; size_t cap_score = 0, cap_order = 0;
+	DsbSeed *d_seeds = nullptr; DsbSeedInfo *d_sinfo = nullptr; size_t cap_seeds = 0, cap_sinfo = 0;   // seed lists of the batch (k_seed_scan)
+	bool bits_valid = false, seeds_valid = false;   // what the last run left on the device (stage dumps)
 	unsigned n_early = 0;                          // reads of the last run that went through the early launch
 	std::vector<DsbReadOut> h_rout; std::vector<DsbHitOut> h_hout;
 	std::vector<dsb_read_result> res_reads;
@@ -504,7 +591,7 @@ extern "C" int dsb_device_count(void)
 	return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 
-static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_bytes, uint64_t pk_words, uint64_t bit_words);
+static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_bytes, uint64_t pk_words, uint64_t bit_words, uint64_t seed_entries);
 
 extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 {
@@ -512,9 +599,9 @@ extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
 	if (c->stream2) hipStreamSynchronize(c->stream2);
-	for (InSlot &s : c->in) { hipFree(s.d_rd); hipFree(s.d_ascii); }
+	for (InSlot &s : c->in) { hipFree(s.d_rd); hipFree(s.d_ascii); hipFree(s.d_scan_order); }
 	hipFree(c->d_wd); hipFree(c->d_bin); hipFree(c->d_pk); hipFree(c->d_bits);
-	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->arena_big.base); hipFree(c->d_score); hipFree(c->d_order);
+	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->arena_big.base); hipFree(c->d_score); hipFree(c->d_order); hipFree(c->d_seeds); hipFree(c->d_sinfo);
 	if (c->dbg_host) hipHostFree(c->dbg_host);
 	for (int i = 0; i < 4; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	if (c->ev_order) hipEventDestroy(c->ev_order);
@@ -564,7 +651,7 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 		if (c->opts.max_read_len && c->opts.max_batch_reads) {
 			const uint32_t L = c->opts.max_read_len; const size_t n = c->opts.max_batch_reads; const int k = c->dx.ek_len;
 			const uint64_t nwin = L >= 40 ? L - k + 1 : 0;
-			rc = ensure_buffers(c, n, L, n * ((DSB_QPAD_L + 2 * (uint64_t)L + DSB_QPAD_R + 255) & ~(uint64_t)255), n * 2 * ((L + 31) / 32 + 1), n * 2 * ((nwin + 63) / 64));
+			rc = ensure_buffers(c, n, L, n * ((DSB_QPAD_L + 2 * (uint64_t)L + DSB_QPAD_R + 255) & ~(uint64_t)255), n * 2 * ((L + 31) / 32 + 1), n * 2 * ((nwin + 63) / 64), n * (((uint64_t)L >> 1) + 64));
 		}
 	}
 	if (rc != DSB_OK) { dsb_ctx_destroy(c); return rc; }
@@ -654,9 +741,11 @@ static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int wan
 }
 
 // buffers of one run + arenas, for a batch of n reads (longest max_len) with the given derived sizes
-static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_bytes, uint64_t pk_words, uint64_t bit_words)
+static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_bytes, uint64_t pk_words, uint64_t bit_words, uint64_t seed_entries)
 {
 	int rc;
+	if ((rc = grow(&c->d_seeds, &c->cap_seeds, (size_t)seed_entries + 64))) return rc;
+	if ((rc = grow(&c->d_sinfo, &c->cap_sinfo, n + 1))) return rc;
 	if ((rc = grow(&c->d_wd, &c->cap_wd, (size_t)bit_words + 1))) return rc;
 	if ((rc = grow(&c->d_bin, &c->cap_bin, (size_t)bin_bytes + 256))) return rc;
 	if ((rc = grow(&c->d_pk, &c->cap_pk, (size_t)pk_words + 8))) return rc;
@@ -699,25 +788,36 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 	InSlot &s = c->in[c->cur];
 	const int k = c->dx.ek_len;
 	s.h_rd.resize(n);
-	uint64_t seq_off = 0, bin_off = 0, pk_off = 0, bit_off = 0, windows = 0; uint32_t max_len = 64; int hist = c->hist_max;
+	uint64_t seq_off = 0, bin_off = 0, pk_off = 0, bit_off = 0, windows = 0, seed_off = 0; uint32_t max_len = 64, min_len = 0xffffffffu; int hist = c->hist_max;
 	for (size_t i = 0; i < n; i++) {
 		DsbReadDesc &d = s.h_rd[i];
 		d.len = reads[i].len; d.seq_off = ext_text ? ext_off[i] : seq_off; d.bin_off = bin_off; d.pk_off = pk_off; d.bit_off = bit_off;
 		d.n_win = d.len >= 40 ? d.len - k + 1 : 0; d.n_words = (d.n_win + 63) / 64;
 		d.hist_max = hist; if ((int)d.len > hist) hist = d.len;
+		d.seed_off = seed_off; seed_off += ((uint64_t)d.len >> 1) + 64;
+		if (d.len < min_len) min_len = d.len;
 		seq_off += d.len; bin_off += al256(DSB_QPAD_L + 2 * (size_t)d.len + DSB_QPAD_R);
 		pk_off += 2 * ((d.len + 31) / 32 + 1); bit_off += 2 * (size_t)d.n_words;
 		if (d.len > max_len) max_len = d.len;
 		windows += 2 * (uint64_t)d.n_win;
 	}
 	c->hist_max = hist;
-	s.n_reads = n; s.n_words_total = bit_off; s.total_bases = seq_off; s.total_windows = windows; s.max_len = max_len;
+	s.n_reads = n; s.n_words_total = bit_off; s.total_bases = seq_off; s.total_windows = windows; s.max_len = max_len; s.seed_entries = seed_off;
+	s.min_len = n ? min_len : 0; s.ragged = n && (uint64_t)max_len > (uint64_t)min_len + (min_len >> 3) + 64;
 	int rc;
 	if ((rc = grow(&s.d_rd, &s.cap_rd, n + 1))) return rc;
 	if ((rc = grow(&s.d_ascii, &s.cap_ascii, (ext_text ? ext_len : (size_t)seq_off) + 64))) return rc;
-	if ((rc = ensure_buffers(c, n, max_len, bin_off, pk_off, bit_off))) return rc;
+	if ((rc = ensure_buffers(c, n, max_len, bin_off, pk_off, bit_off, seed_off))) return rc;
 	if (n) {
 		HIPCHK(hipMemcpyAsync(s.d_rd, s.h_rd.data(), n * sizeof(DsbReadDesc), hipMemcpyHostToDevice, c->stream));
+		if (s.ragged) {
+			// k_seed_scan gives a lane a whole strand: reads of similar length share a wavefront (longest first)
+			std::vector<uint32_t> ord(n);
+			for (size_t i = 0; i < n; i++) ord[i] = (uint32_t)i;
+			std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return s.h_rd[a].len > s.h_rd[b].len; });
+			if ((rc = grow(&s.d_scan_order, &s.cap_scan_order, n + 1))) return rc;
+			HIPCHK(hipMemcpy(s.d_scan_order, ord.data(), n * 4, hipMemcpyHostToDevice));
+		}
 		if (ext_text) HIPCHK(hipMemcpyAsync(s.d_ascii, ext_text, ext_len, hipMemcpyHostToDevice, c->stream));
 		else {
 			// sequences: copied read by read out of the caller's buffers (caller owns read memory)
@@ -781,10 +881,12 @@ extern "C" long dsb_batch_upload_fastq(dsb_ctx *c, const char *path, size_t skip
 // one k_classify-family launch
 template <class K>
 static void launch_classify(K kern, dsb_ctx *c, hipStream_t st, unsigned grid, const DsbDevIndex &dx, const InSlot &s, uint32_t n_fixed, const unsigned int *n_ptr,
-                            const uint32_t *list, const DsbSlotArena &ar, unsigned int *work_counter, uint32_t *dbg, uint32_t item_base, uint32_t slot_base, int cnt_set)
+                            const uint32_t *list, const DsbSlotArena &ar, unsigned int *work_counter, uint32_t *dbg, uint32_t item_base, uint32_t slot_base, int cnt_set,
+                            bool pre_seeds)
 {
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, st, dx, (const DsbReadDesc *)s.d_rd, n_fixed, n_ptr, list, c->d_bin, (const uint64_t *)c->d_bits, ar, work_counter,
-	                   c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, dbg, item_base, slot_base, (unsigned long long *)(c->d_counters + 16 + 8 * cnt_set));
+	                   c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, dbg, item_base, slot_base, (unsigned long long *)(c->d_counters + 16 + 8 * cnt_set),
+	                   pre_seeds ? c->d_seeds : nullptr, (const DsbSeedInfo *)c->d_sinfo);
 }
 
 extern "C" int dsb_batch_run(dsb_ctx *c)
@@ -799,7 +901,6 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
 	hipLaunchKernelGGL(k_encode_bytes, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, s.d_ascii, c->d_bin);
 	hipLaunchKernelGGL(k_encode_pack, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, c->d_bin, c->d_pk);
-	if (s.n_words_total) hipLaunchKernelGGL(k_build_wd, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, c->d_wd);
 	HIPCHK(hipEventRecord(c->ev[1], c->stream));
 	const bool dbg = getenv("DSB_DEBUG") != NULL && c->dbg_dev;
 	if (dbg) { HIPCHK(hipStreamSynchronize(c->stream)); fprintf(stderr, "[dsb] encode done\n"); }
@@ -819,6 +920,14 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		if (n_heavy > n / 2) n_heavy = (unsigned)(n / 2);
 	}
 	c->n_early = n_heavy;
+	// Seed lookup of the main launch: k_seed_scan (a lane per strand, only the windows the reference's scan consumes, seed
+	// lists written by the kernel) for batches that fill the device, the all-windows probe + in-kernel scan of the hit
+	// bits otherwise (a strand is a serial chain of ~7000 round trips: a small batch would wait for it).  DSB_SEED_SCAN=0/1
+	// forces one or the other.  The early launch of the heaviest reads always takes the hit-bit path.
+	bool use_scan = n >= 2048;
+	if (const char *e = getenv("DSB_SEED_SCAN")) use_scan = atoi(e) != 0;
+	if (dbg) use_scan = false;
+	c->bits_valid = !use_scan; c->seeds_valid = use_scan;
 	uint32_t step_limit = DSB_STEP_LIMIT;
 	if (const char *e = getenv("DSB_STEP_LIMIT_RT")) { long v = atol(e); if (v > 0) step_limit = (uint32_t)v; }   // diagnostics: a small budget forces second runs
 	DsbDevIndex dx1 = c->dx; dx1.sms_cap = c->arena.sms_cap; dx1.step_limit = step_limit;
@@ -828,12 +937,16 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		HIPCHK(hipEventRecord(c->ev_hprobe, c->stream));
 		HIPCHK(hipEventRecord(c->ev_order, c->stream));             // order_ms covers scoring, ordering and these probes
 		HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_hprobe, 0));
-		launch_classify(k_classify_early, c, c->stream2, n_heavy, dx1, s, (uint32_t)n_heavy, nullptr, (const uint32_t *)c->d_order, c->arena, c->d_counters + 4, nullptr, 0u, (uint32_t)c->n_slots, 1);
+		launch_classify(k_classify_early, c, c->stream2, n_heavy, dx1, s, (uint32_t)n_heavy, nullptr, (const uint32_t *)c->d_order, c->arena, c->d_counters + 4, nullptr, 0u, (uint32_t)c->n_slots, 1, false);
 		HIPCHK(hipEventRecord(c->ev_heavy, c->stream2));
 	}
-	if (s.n_words_total) {
+	if (use_scan) {
+		hipLaunchKernelGGL(k_seed_scan, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const uint32_t *)(s.ragged ? s.d_scan_order : nullptr),
+		                   (uint32_t)n, (const uint64_t *)c->d_pk, c->d_seeds, c->d_sinfo, (const uint8_t *)c->staged->d_summ, c->staged->summ_shift, (unsigned long long *)(c->d_counters + 40));
+	} else if (s.n_words_total) {
 		uint64_t waves = (s.n_words_total + DSB_PROBE_UN - 1) / DSB_PROBE_UN; unsigned blocks = (unsigned)((waves + 3) / 4);
 		if (blocks > 256u * 32u) blocks = 256u * 32u;       // >= 8 blocks of 4 waves per CU, grid-stride beyond
+		hipLaunchKernelGGL(k_build_wd, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, c->d_wd);
 		hipLaunchKernelGGL(k_seed_probe, dim3(blocks), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const DsbWordDesc *)c->d_wd, s.n_words_total, c->d_pk, c->d_bits,
 		                   (unsigned long long *)(c->d_counters + 2), c->staged->d_summ, c->staged->summ_shift);
 	}
@@ -843,7 +956,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	{
 		uint32_t *dbgp = dbg ? c->dbg_dev : nullptr;
 		if (dbg) memset(c->dbg_host, 0, 32 * 65536 * sizeof(uint32_t));
-		launch_classify(k_classify, c, c->stream, slots, dx1, s, (uint32_t)n, nullptr, (const uint32_t *)c->d_order, c->arena, c->d_counters, dbgp, (uint32_t)n_heavy, 0u, 0);
+		launch_classify(k_classify, c, c->stream, slots, dx1, s, (uint32_t)n, nullptr, (const uint32_t *)c->d_order, c->arena, c->d_counters, dbgp, (uint32_t)n_heavy, 0u, 0, use_scan);
 		HIPCHK(hipEventRecord(c->ev_cls, c->stream));
 		if (n_heavy) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_heavy, 0));
 		if (dbg) {
@@ -866,7 +979,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	DsbDevIndex dx2 = c->dx; dx2.sms_cap = c->arena_big.sms_cap; dx2.step_limit = step_limit > 0xffffffffu / 16 ? 0xffffffffu : step_limit * 16u;
 	const int retry_mask = DSB_ST_SMS_OVF | DSB_ST_ANC_OVF | DSB_ST_HIT_OVF | DSB_ST_TIMEOUT;
 	hipLaunchKernelGGL(k_collect_retry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const DsbReadOut *)c->d_rout, (uint32_t)n, c->d_score, c->d_counters + 6, retry_mask, 0);
-	launch_classify(k_classify_second, c, c->stream, (unsigned)c->n_slots_big, dx2, s, 0u, (const unsigned int *)(c->d_counters + 6), (const uint32_t *)c->d_score, c->arena_big, c->d_counters + 7, nullptr, 0u, 0u, 2);
+	launch_classify(k_classify_second, c, c->stream, (unsigned)c->n_slots_big, dx2, s, 0u, (const unsigned int *)(c->d_counters + 6), (const uint32_t *)c->d_score, c->arena_big, c->d_counters + 7, nullptr, 0u, 0u, 2, use_scan);
 	HIPCHK(hipEventRecord(c->ev[3], c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	{
@@ -882,7 +995,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 			HIPCHK(hipMemcpy(nh, c->d_hout, c->cap_hout * sizeof(DsbHitOut), hipMemcpyDeviceToDevice));
 			hipFree(c->d_hout); c->d_hout = nh; c->cap_hout = new_cap;
 			hipLaunchKernelGGL(k_collect_retry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const DsbReadOut *)c->d_rout, (uint32_t)n, c->d_score, c->d_counters + 8, DSB_ST_OUT_OVF, 0);
-			launch_classify(k_classify_second, c, c->stream, (unsigned)c->n_slots_big, dx2, s, 0u, (const unsigned int *)(c->d_counters + 8), (const uint32_t *)c->d_score, c->arena_big, c->d_counters + 9, nullptr, 0u, 0u, 2);
+			launch_classify(k_classify_second, c, c->stream, (unsigned)c->n_slots_big, dx2, s, 0u, (const unsigned int *)(c->d_counters + 8), (const uint32_t *)c->d_score, c->arena_big, c->d_counters + 9, nullptr, 0u, 0u, 2, use_scan);
 			HIPCHK(hipStreamSynchronize(c->stream));
 			unsigned int n3 = 0; HIPCHK(hipMemcpy(&n3, c->d_counters + 8, 4, hipMemcpyDeviceToHost));
 			c->timing.n_regrow = n3;
@@ -918,6 +1031,12 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	HIPCHK(hipMemcpy(&c->timing.n_retry, c->d_counters + 6, 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(wk, c->d_counters + 16, 96, hipMemcpyDeviceToHost));
 	c->timing.windows = s.total_windows; c->timing.probes_t1 = c->p1; c->timing.bases = s.total_bases;
+	c->timing.seed_scan = use_scan ? 1 : 0;
+	if (use_scan) {	// probes the scan issued (low-complexity windows excluded), and those that went on to table 1
+		unsigned long long pc[2] = {0, 0};
+		HIPCHK(hipMemcpy(pc, c->d_counters + 40, 16, hipMemcpyDeviceToHost));
+		c->timing.windows = pc[0]; c->timing.probes_t1 = pc[1];
+	}
 	c->timing.n_occ = wk[0] + wk[4] + wk[8]; c->timing.n_mem = wk[1] + wk[5] + wk[9]; c->timing.n_sa = wk[2] + wk[6] + wk[10]; c->timing.ref_bases = wk[3] + wk[7] + wk[11];
 	c->timing.main_occ = wk[0]; c->timing.main_mem = wk[1]; c->timing.main_sa = wk[2]; c->timing.main_ref_bases = wk[3];
 	return DSB_OK;
@@ -968,9 +1087,20 @@ extern "C" int dsb_batch_exist_bits(dsb_ctx *c, size_t read, int strand, uint8_t
 {
 	if (!c || read >= c->in[c->cur].n_reads) return DSB_EINVAL;
 	HIPCHK(hipSetDevice(c->device));
-	const DsbReadDesc &d = c->in[c->cur].h_rd[read];
+	const InSlot &sl = c->in[c->cur];
+	const DsbReadDesc &d = sl.h_rd[read];
 	if (n_out) *n_out = d.n_win;
 	if (cap < d.n_win) return DSB_EINVAL;
+	if (!c->bits_valid && sl.n_words_total) {
+		// the last run looked its seeds up with k_seed_scan, which keeps no hit bits: probe all windows now (stage dump only)
+		uint64_t waves = (sl.n_words_total + DSB_PROBE_UN - 1) / DSB_PROBE_UN; unsigned blocks = (unsigned)((waves + 3) / 4);
+		if (blocks > 256u * 32u) blocks = 256u * 32u;
+		hipLaunchKernelGGL(k_build_wd, dim3((unsigned)sl.n_reads), dim3(256), 0, c->stream, sl.d_rd, c->d_wd);
+		hipLaunchKernelGGL(k_seed_probe, dim3(blocks), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)sl.d_rd, (const DsbWordDesc *)c->d_wd, sl.n_words_total, c->d_pk, c->d_bits,
+		                   (unsigned long long *)nullptr, c->staged->d_summ, c->staged->summ_shift);
+		HIPCHK(hipStreamSynchronize(c->stream));
+		c->bits_valid = true;
+	}
 	std::vector<uint64_t> wv(d.n_words);
 	if (d.n_words) HIPCHK(hipMemcpy(wv.data(), c->d_bits + d.bit_off + (strand ? 0 : d.n_words), d.n_words * 8, hipMemcpyDeviceToHost));
 	for (uint32_t i = 0; i < d.n_win; i++) out[i] = (uint8_t)((wv[i >> 6] >> (i & 63)) & 1);
@@ -985,7 +1115,7 @@ __global__ void __launch_bounds__(64) k_seed_dump(DsbDevIndex x, DsbReadDesc d, 
 	if (threadIdx.x == 0) sx = x;
 	__syncthreads();
 	dsb_g64::WCtx w; w.x = (dsb_g64::DsbXP)&sx; w.lane = threadIdx.x; w.L = d.len; w.status = 0; w.dbg = nullptr; w.anc_cap = 0; w.wtab = nullptr;
-	w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1;
+	w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1; w.pre_seeds = nullptr; w.pre_info = nullptr;
 	dsb_g64::SDir sd;
 	uint32_t n = d.len - x.ek_len + 1;
 	if (strand) dsb_g64::seed_vector(w, bin + d.bin_off + DSB_QPAD_L, bits + d.bit_off, n, out, D_FORWARD, &sd);
@@ -998,6 +1128,17 @@ extern "C" int dsb_batch_seeds(dsb_ctx *c, size_t read, int strand, dsb_seed *ou
 	HIPCHK(hipSetDevice(c->device));
 	const DsbReadDesc &d = c->in[c->cur].h_rd[read];
 	if (d.len < 40) { if (n) *n = 0; if (total_score) *total_score = 0; return DSB_OK; }
+	if (c->seeds_valid) {
+		// the lists k_seed_scan wrote during the last run
+		DsbSeedInfo si; HIPCHK(hipMemcpy(&si, c->d_sinfo + read, sizeof si, hipMemcpyDeviceToHost));
+		const int dir = strand ? 0 : 1; const uint32_t cnt = si.n_seed[dir];
+		std::vector<DsbSeed> hs(cnt ? cnt : 1);
+		if (cnt) HIPCHK(hipMemcpy(hs.data(), c->d_seeds + d.seed_off + (dir ? (d.len >> 2) : 0), cnt * sizeof(DsbSeed), hipMemcpyDeviceToHost));
+		if (n) *n = cnt; if (total_score) *total_score = si.total[dir];
+		if (cap < cnt) return DSB_EINVAL;
+		for (uint32_t i = 0; i < cnt; i++) { out[i].offset = hs[i].offset; out[i].len = hs[i].len; out[i].top = (uint8_t)hs[i].top; out[i].pad[0] = out[i].pad[1] = out[i].pad[2] = 0; }
+		return DSB_OK;
+	}
 	DsbSeed *ds; uint32_t *dn; size_t m = (d.len >> 1) + 64;
 	HIPCHK(hipMalloc((void **)&ds, m * sizeof(DsbSeed))); HIPCHK(hipMalloc((void **)&dn, 8));
 	hipLaunchKernelGGL(k_seed_dump, dim3(1), dim3(64), 0, c->stream, c->dx, d, c->d_bin, c->d_bits, strand, ds, dn);

@@ -1,0 +1,140 @@
+// Seed lookup as the reference does it: probe only the windows its scan consumes.
+//
+// search_exist_kmer_M2 (src/cly.c:1071-1160) probes every third k-mer window of a strand; a hit is extended back by at
+// most two windows and forward while windows hit (a seed holds at most 61 windows), and the scan resumes three windows
+// behind the seed -- at a phase that depends on where the seed ended.  Which windows are consulted is therefore known
+// only while scanning: the scan is sequential per strand, and strands are independent.  Here ONE LANE scans ONE STRAND,
+// 64 strands per wavefront, and asks the two filter tables (get_exist_kmer, src/cly.c:956-972) for exactly the windows the
+// reference would ask for, plus a little speculation: in stride mode the next four stride points go out together (93 %
+// of them miss, so the look-ahead is rarely wasted), around a hit and along a run two windows at a time.  Against probing
+// every window of both strands (k_seed_probe: 2 probes per base) this issues ~0.85 per base -- the kernel is bound by
+// the rate of random 64-B requests, not by latency, so the probes not issued are the time saved -- and the seed lists
+// (with get_seed_vector_M2's top-seed marking, src/cly.c:1174-1234) come out of the same kernel: no hit-bit arrays, no
+// scan stage in the classify kernel.
+//
+// The reverse strand is scanned through the forward strand's windows: window w of the reverse strand is the reverse
+// complement of forward window n-1-w, and the reference's descending scan of the reverse strand (src/cly.c:1122-1157)
+// is the ascending scan over the mirrored index with the same rules; only the emitted offset is mirrored back.
+//
+// This header holds the scan as a state machine over "which windows do you want" / "here are their bits", so that the
+// identical code runs in the kernel (dsb_gpu.hip: k_seed_scan) and, one lane at a time, in the host emulation
+// (tests/emu) where it is compared with the scan over all hit bits (seed_vector_scan) and with the oracle.
+#pragma once
+#include <stdint.h>
+#include "dsb_device.h"
+
+#ifdef DSB_HOST_EMU
+#define DSB_SCAN_FN static inline
+#else
+#define DSB_SCAN_FN __device__ __forceinline__
+#endif
+
+#define DSB_SCAN_STRIDE 0u
+#define DSB_SCAN_BACK1 1u
+#define DSB_SCAN_BACK2 2u
+#define DSB_SCAN_FWD 3u
+#define DSB_SCAN_DONE 4u
+#define DSB_SCAN_NONE 0xffffffffu
+
+struct DsbScan {
+	uint32_t n;                 // windows of the strand
+	uint32_t i;                 // stride position (mirrored coordinates for the reverse strand)
+	uint32_t mode;
+	uint32_t hit_m1, hit_p1;    // BACK1 results kept for BACK2
+	uint32_t off, len, j;       // the seed being extended; next forward window
+	// get_seed_vector_M2's marking of the best seed per 100-window bin (src/cly.c:1200-1234), run on each seed as it is made
+	uint32_t ns, total, max_index, max_length, index_end, cur_top;
+};
+
+DSB_SCAN_FN void dsb_scan_init(DsbScan &s, uint32_t n)
+{
+	s.n = n; s.i = 2; s.mode = n > 2 ? DSB_SCAN_STRIDE : DSB_SCAN_DONE;
+	s.hit_m1 = s.hit_p1 = 0; s.off = s.len = s.j = 0;
+	s.ns = 0; s.total = 0; s.max_index = 0; s.max_length = 0; s.index_end = 100; s.cur_top = 0;
+}
+
+// the windows whose bits the next step needs (DSB_SCAN_NONE = slot unused)
+DSB_SCAN_FN void dsb_scan_want(const DsbScan &s, uint32_t (&want)[4])
+{
+	want[0] = want[1] = want[2] = want[3] = DSB_SCAN_NONE;
+	if (s.mode == DSB_SCAN_STRIDE) {
+#pragma unroll
+		for (int t = 0; t < 4; t++) { const uint32_t p = s.i + 3u * (uint32_t)t; if (p < s.n) want[t] = p; }
+	} else if (s.mode == DSB_SCAN_BACK1) {
+		want[0] = s.i - 1;                                       // i >= 2 at every hit
+		if (s.i + 1 < s.n) want[1] = s.i + 1;
+	} else if (s.mode == DSB_SCAN_BACK2) {
+		if (s.hit_m1) want[0] = s.i - 2;
+		if (s.hit_p1 && s.i + 2 < s.n) want[1] = s.i + 2;
+	} else if (s.mode == DSB_SCAN_FWD) {
+		if (s.j < s.n) want[0] = s.j;
+		if (s.j + 1 < s.n) want[1] = s.j + 1;
+	}
+}
+
+// One finished seed: `store(index, offset, len)` keeps the record (top = 0), `mark(index)` sets top = 1 on a record stored
+// earlier.  offset is in the strand's own coordinates (mirrored back for the reverse strand).
+template <class Store, class Mark>
+DSB_SCAN_FN void dsb_scan_emit(DsbScan &s, bool rc, Store &store, Mark &mark)
+{
+	const uint32_t l = s.len, key = s.off;                           // key: forward n-o-l mirrored == off
+	store(s.ns, rc ? s.n - s.off - l : s.off, l);
+	if (key < s.index_end) {
+		if (s.max_length < l) { if (s.cur_top && s.max_index != s.ns) mark(s.max_index); s.max_length = l; s.max_index = s.ns; }
+		s.cur_top = 0;
+	} else {
+		// the best seed of the bin that just ended is a top seed (when this is the very first seed of the strand that is the
+		// new seed itself, and a later seed of its bin may take the mark away again: cur_top)
+		if (s.max_index != s.ns) { mark(s.max_index); s.cur_top = 0; } else s.cur_top = 1;
+		s.index_end += 100; s.total += s.max_length; s.max_index = s.ns; s.max_length = l;
+	}
+	s.ns++;
+	s.i = s.off + l + 3; s.mode = s.i < s.n ? DSB_SCAN_STRIDE : DSB_SCAN_DONE;
+}
+
+// bits: bit t = window want[t] hit (0 for unused slots)
+template <class Store, class Mark>
+DSB_SCAN_FN void dsb_scan_consume(DsbScan &s, uint32_t bits, bool rc, Store &store, Mark &mark)
+{
+	if (s.mode == DSB_SCAN_STRIDE) {
+		if (bits & 15u) {
+			const uint32_t t = (uint32_t)__builtin_ctz(bits & 15u);
+			s.i += 3u * t; s.mode = DSB_SCAN_BACK1;
+		} else { s.i += 12; if (s.i >= s.n) s.mode = DSB_SCAN_DONE; }
+	} else if (s.mode == DSB_SCAN_BACK1) {
+		s.hit_m1 = bits & 1u; s.hit_p1 = (bits >> 1) & 1u;
+		if (!s.hit_m1 && !s.hit_p1) { s.off = s.i; s.len = 1; dsb_scan_emit(s, rc, store, mark); }
+		else s.mode = DSB_SCAN_BACK2;
+	} else if (s.mode == DSB_SCAN_BACK2) {
+		const uint32_t hit_m2 = s.hit_m1 ? (bits & 1u) : 0u, hit_p2 = s.hit_p1 ? ((bits >> 1) & 1u) : 0u;
+		const uint32_t back = s.hit_m1 ? (hit_m2 ? 2u : 1u) : 0u;
+		s.off = s.i - back; s.len = 1 + back + s.hit_p1 + hit_p2;
+		s.j = s.i + 3;
+		// the run goes on behind i+2 only if both forward windows hit; a seed holds at most 61 windows (src/cly.c:1100)
+		if (s.hit_p1 && hit_p2 && s.j < s.n && s.len < 61) s.mode = DSB_SCAN_FWD; else dsb_scan_emit(s, rc, store, mark);
+	} else if (s.mode == DSB_SCAN_FWD) {
+		bool more = false;
+		if (bits & 1u) {
+			s.len++; s.j++;
+			if (s.len < 61 && s.j < s.n && (bits & 2u)) { s.len++; s.j++; more = s.len < 61 && s.j < s.n; }
+		}
+		if (!more) dsb_scan_emit(s, rc, store, mark);
+	}
+}
+
+// after the last step: the best seed of the last bin
+template <class Mark>
+DSB_SCAN_FN void dsb_scan_finish(DsbScan &s, Mark &mark)
+{
+	if (s.ns) { mark(s.max_index); s.total += s.max_length; }
+}
+
+// reverse complement of a k-mer (2 bits per base, first base in the high bits of the low 2k bits)
+DSB_SCAN_FN uint64_t dsb_revcomp_kmer(uint64_t kmer, int k)
+{
+	uint64_t x = ~kmer;
+	x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+	x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+	x = __builtin_bswap64(x);
+	return x >> (64 - 2 * k);
+}

@@ -80,7 +80,7 @@ typedef struct { uint32_t offset, len; uint8_t top; uint8_t pad[3]; } dsb_seed;
 /* per-batch device timings (HIP events on the ctx's stream), milliseconds */
 typedef struct {
 	float encode_ms, seed_probe_ms, classify_ms, total_ms;   /* classify_ms: the main k_classify launch */
-	uint64_t windows;      /* exist-kmer windows probed in table 0 (= P0 of SURVEY.md 8d) */
+	uint64_t windows;      /* exist-kmer windows probed (= P0 of SURVEY.md 8d): all of both strands, or what k_seed_scan asked for */
 	uint64_t probes_t1;    /* probes that continued to table 1 (= P1) */
 	uint64_t bases;
 	float order_ms;        /* scoring + ordering of the reads (longest first) + the probes of the early launch */
@@ -88,7 +88,7 @@ typedef struct {
 	uint32_t n_early;      /* reads that went through the early launch */
 	uint32_t n_retry;      /* reads run a second time (32x match nodes, 8x anchors, 4x chains, 16x loop budget): theirs ran out */
 	uint32_t n_regrow;     /* reads run again after the hit buffer had to be regrown */
-	uint32_t pad;
+	uint32_t seed_scan;    /* 1: the seed lookup ran as k_seed_scan (one lane per strand, windows = probes it issued); 0: all windows probed */
 	/* work counters of the classify kernels, counted on the device (the terms of the algorithmic bytes) */
 	uint64_t n_occ;        /* occ() evaluations (src/bwt.c:43) */
 	uint64_t n_mem;        /* bwt_MEM_search calls = hash_index pairs read (src/cly.c:1388) */

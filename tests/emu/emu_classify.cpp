@@ -7,6 +7,7 @@
 #include <vector>
 #include "dsb_device.h"
 #include "dsb_probe.h"
+#include "dsb_seed_scan.h"
 #include "dsb_classify_dev.h"
 #include "dsb_host.h"
 using namespace dsb_g64;
@@ -157,6 +158,47 @@ extern "C" uint32_t emu_sms_peak(void *p)
 	size_t n = (size_t)e->dx.sms_cap * 4;
 	while (n && a[n - 1] == 0xCDCDCDCDu) n--;
 	return (uint32_t)((n + 3) / 4);
+}
+// k_seed_scan's per-lane code (dsb_seed_scan.h) on the strands of the last read: the seed list of one strand and the number of
+// windows it asked for ([0] with a k-mer that passes the low-complexity filter, [1] all); same layout as emu_seeds
+extern "C" int emu_scan_seeds(void *p, int strand, DsbSeed *out, int max_out, uint32_t *total, uint32_t *probes)
+{
+	EmuCtx *e = (EmuCtx *)p; const DsbDevIndex &dx = e->dx; const WCtx &w = e->w;
+	const uint32_t L = w.L, n = L >= 40 ? L - dx.ek_len + 1 : 0; const bool rc = strand == 0;
+	const int k = dx.ek_len; const uint64_t kmask = k >= 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+	std::vector<DsbSeed> sv;
+	auto store = [&](uint32_t idx, uint32_t off, uint32_t len) { if (sv.size() <= idx) sv.resize(idx + 1); sv[idx].offset = off; sv[idx].len = (uint16_t)len; sv[idx].top = 0; };
+	auto mark = [&](uint32_t idx) { sv[idx].top = 1; };
+	DsbScan s; dsb_scan_init(s, n);
+	uint32_t np = 0, nall = 0;
+	while (s.mode != DSB_SCAN_DONE) {
+		uint32_t want[4]; dsb_scan_want(s, want); uint32_t bits = 0;
+		uint32_t lo = DSB_SCAN_NONE; for (int t = 0; t < 4; t++) if (want[t] < lo) lo = want[t];
+		for (int t = 0; t < 4; t++) {
+			if (want[t] == DSB_SCAN_NONE) continue;
+			nall++;
+			// the kernel's two-word window: every wanted window lies within the two packed words at lo >> 5
+			const uint32_t base = lo & ~31u, rel = want[t] - base;
+			const uint64_t W0 = e->pk[lo >> 5], W1 = e->pk[(lo >> 5) + 1];
+			const uint64_t a = rel < 32 ? W0 : W1, b = rel < 32 ? W1 : 0ULL; const uint32_t sh = (rel & 31u) * 2;
+			const uint64_t hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
+			uint64_t v = (hi >> (64 - 2 * k)) & kmask;
+			if (rc) v = dsb_revcomp_kmer(v, k);
+			if (!dsb_kmer_ok(v, k, dx.single_base_max)) continue;
+			np++;
+			const uint64_t h1 = dsb_ph1(v) & dx.ek_mask;
+			if (((dx.ek0[h1 >> 3] >> (7 - (h1 & 7))) & 1) == 0) continue;
+			const uint64_t h2 = dsb_ph2(v) & dx.ek_mask;
+			if ((dx.ek1[h2 >> 3] >> (7 - (h2 & 7))) & 1) bits |= 1u << t;
+		}
+		dsb_scan_consume(s, bits, rc, store, mark);
+	}
+	dsb_scan_finish(s, mark);
+	int m = (int)s.ns < max_out ? (int)s.ns : max_out;
+	for (int i = 0; i < m; i++) out[i] = sv[i];
+	if (total) *total = s.total;
+	if (probes) { probes[0] = np; probes[1] = nall; }
+	return (int)s.ns;
 }
 // loop budget of the following reads (DSB_STEP_LIMIT by default); steps the last read charged
 extern "C" void emu_set_step_limit(void *p, uint32_t v) { ((EmuCtx *)p)->w.step_limit = v; ((EmuCtx *)p)->limit_set = v; }

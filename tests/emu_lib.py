@@ -15,7 +15,7 @@ class EmuHit(C.Structure):
 
 
 class EmuSeed(C.Structure):
-    _fields_ = [("offset", C.c_uint32), ("len", C.c_uint32), ("top", C.c_uint32)]
+    _fields_ = [("offset", C.c_uint32), ("len", C.c_uint16), ("top", C.c_uint16)]
 
 
 class Emu:
@@ -28,6 +28,7 @@ class Emu:
         L.emu_sms_peak.argtypes = [C.c_void_p]; L.emu_sms_peak.restype = C.c_uint32
         L.emu_seeds.argtypes = [C.c_void_p, C.c_int, C.POINTER(EmuSeed), C.c_int, C.POINTER(C.c_uint32)]
         L.emu_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        L.emu_scan_seeds.argtypes = [C.c_void_p, C.c_int, C.POINTER(EmuSeed), C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         self.L = L
         self.idx = C.c_void_p()
         rc = L.dsb_index_open(os.fsencode(index_dir), C.byref(self.idx))
@@ -59,3 +60,10 @@ class Emu:
         buf = (EmuSeed * 65536)(); ts = C.c_uint32()
         n = self.L.emu_seeds(self.e, strand, buf, 65536, C.byref(ts))
         return [(buf[i].offset, buf[i].len, buf[i].top) for i in range(n)], ts.value
+
+    def scan_seeds(self, strand):
+        """the seed list of one strand of the last read as k_seed_scan's per-lane state machine makes it (probing only what
+        the scan consumes) -> (seeds, total_score, (probes with a valid k-mer, windows asked for))"""
+        buf = (EmuSeed * 65536)(); ts = C.c_uint32(); pr = (C.c_uint32 * 2)()
+        n = self.L.emu_scan_seeds(self.e, strand, buf, 65536, C.byref(ts), pr)
+        return [(buf[i].offset, buf[i].len, buf[i].top) for i in range(n)], ts.value, (pr[0], pr[1])

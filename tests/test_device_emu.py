@@ -30,6 +30,11 @@ def _cmp(emu, oracle, recs, check_stages=False):
         else:
             got = emu.classify(seq, hist)
         assert got == exp, name
+        if len(seq) >= 40:
+            # k_seed_scan's lane code (probes only what the scan consumes) gives the seed lists of the scan over all hit bits
+            for s in (1, 0):
+                sv, ts, _ = emu.scan_seeds(s)
+                assert (sv, ts) == emu.seeds(s), (name, s)
         assert emu.n_anc() == oracle.n_anc(), name
         # the work counters behind the algorithmic bytes: occ, SA lookups, reference bases, MEM searches
         # (the device walks islands in parallel and commits in order, so an island that the reference skips after a

@@ -395,3 +395,54 @@ def test_device_work_counters_match_the_oracle(gpu, demo, oracle, tmp_path):
     for a, b in zip(got, tot):
         assert b <= a <= 1.01 * b, (got, tot)
     assert t.main_occ <= t.n_occ
+
+
+@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq", "ngs_e14", "overhang"])
+def test_seed_scan_kernel_golden_sam(gpu, name, monkeypatch):
+    """k_seed_scan (one lane per read strand, probing only the windows the reference's scan consumes, seed lists written by
+    the kernel) forced on for small batches too -- by default it serves batches of >= 2048 reads"""
+    D, idx, ctx = gpu
+    monkeypatch.setenv("DSB_SEED_SCAN", "1")
+    hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))
+    assert ctx.timing().seed_scan == 1
+    assert sam == open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read()
+
+
+def test_seed_scan_kernel_stage_parity(gpu, demo, oracle, monkeypatch):
+    """the seed lists k_seed_scan writes (both strands, top marks, total_score) against the oracle's, read for read; the
+    demo set is ragged (reads of 300 .. 4000 bases share wavefronts, longest first) and includes reads shorter than 40"""
+    D, idx, ctx = gpu
+    monkeypatch.setenv("DSB_SEED_SCAN", "1")
+    recs = D.read_fastq(demo["fastq"], 300) + D.read_fastq(os.path.join(GOLDEN, "synth", "ngs150.fq"), 64) + [(b"short", b"ACGT" * 9, None), (b"polyA", b"A" * 300, None)] + \
+        D.read_fastq(os.path.join(GOLDEN, "synth", "ont20k.fq"), 4)
+    reads = D.make_reads(recs)
+    ctx.reset_history(); ctx.classify(reads)
+    t = ctx.timing()
+    assert t.seed_scan == 1 and 0 < t.windows < 1.2 * t.bases and t.probes_t1 < t.windows
+    hist = 0
+    for i, (nm, seq, q) in enumerate(recs):
+        oracle.classify(seq, hist); hist = max(hist, len(seq))
+        for s in (1, 0):
+            assert ctx.seeds(i, s) == oracle.seeds(s), (nm, s)
+    # the hit bits are still available as a stage dump (probed on demand)
+    n = len(recs[0][1]) - 16 + 1
+    assert ctx.exist_bits(0, 1) == bytes(oracle.exist_bits(recs[0][1], 1)[:n])
+
+
+def test_seed_scan_kernel_long_reads_vs_oracle(gpu, demo, oracle, tmp_path, monkeypatch):
+    """a batch large enough for the default choice (>= 2048 reads): 2304 x 50 kbp through k_seed_scan + k_classify, a sample
+    checked hit by hit against the oracle, every read classified to its source reference, device work counters sane"""
+    import random, subprocess
+    D, idx, ctx = gpu
+    monkeypatch.delenv("DSB_SEED_SCAN", raising=False)
+    fq = tmp_path / "scan.fq"
+    subprocess.check_call([os.path.join(ROOT, "tools", "readsim"), demo["index"], str(fq), "2304", "50000", "0.15", "555", "ont"])
+    recs = D.read_fastq(str(fq))
+    hits, _ = classify_all(D, ctx, recs)
+    t = ctx.timing()
+    assert t.seed_scan == 1
+    assert 0.7 * t.bases < t.windows < 0.9 * t.bases           # ~0.79 probes per base (all windows of both strands: 2.0)
+    for i in random.Random(3).sample(range(len(recs)), 64):
+        assert hits[i] == oracle.classify(recs[i][1], 50000), recs[i][0]
+    ok = sum(1 for (nm, s, q), h in zip(recs, hits) if h and h[0][0] == int(nm.split(b"_")[1]))
+    assert ok >= 0.99 * len(recs)
