@@ -221,8 +221,8 @@ __global__ void __launch_bounds__(256) k_seed_probe_reads(DsbDevIndex x, const D
 
 // ---- seed lookup, one lane per read strand (dsb_seed_scan.h): probes what the reference's scan consumes and writes the seed lists
 // Strand g = 2 * (read slot) + (0 forward, 1 reverse); both strands of a read sit in neighbouring lanes and read the same
-// packed words.  A round of a lane: the (at most four) windows its scan wants next lie within 12 windows of each other, so
-// one 16-byte load of the forward strand's packed words holds all their k-mers; then, stage by stage with the loads of a
+// packed words.  A round of a lane: the (at most eight) windows its scan wants next lie within 24 windows of each other, so
+// three packed words of the forward strand hold all their k-mers; then, stage by stage with the loads of a
 // stage issued for all slots before the first is used: low-complexity filter + hash -> summary bit (L2) -> table 0 ->
 // table 1 (get_exist_kmer, src/cly.c:956-972).  `order` (optional) lists the reads longest first, so that the lanes of a
 // wavefront finish together on ragged batches.
@@ -244,48 +244,64 @@ __global__ void __launch_bounds__(256) k_seed_scan(DsbDevIndex x, const DsbReadD
 	const uint64_t kmask = k >= 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
 	DsbScan s; dsb_scan_init(s, active ? d.n_win : 0u);
 	uint32_t p0 = 0, p1 = 0;
+	uint64_t K0 = 0, K1 = 0, K2 = 0; uint32_t wbase = 0xfffffff0u;          // packed words wbase .. wbase + 2 of the strand (none yet)
 	for (;;) {
 		if (!__any(s.mode != DSB_SCAN_DONE)) break;                          // the wavefront leaves together: every lane reaches this
-		uint32_t want[4]; dsb_scan_want(s, want);
-		uint32_t lo = want[0] < want[1] ? want[0] : want[1];
-		{ const uint32_t l2 = want[2] < want[3] ? want[2] : want[3]; lo = l2 < lo ? l2 : lo; }
-		const bool any = lo != DSB_SCAN_NONE;
-		const uint32_t base = lo & ~31u;
-		uint64_t W0 = 0, W1 = 0;
-		if (any) { W0 = P[lo >> 5]; W1 = P[(lo >> 5) + 1]; }
-		uint64_t km[4], h1[4]; bool ok[4];
+		uint32_t want[DSB_SCAN_W]; dsb_scan_want(s, want);
+		uint32_t lo = DSB_SCAN_NONE;
 #pragma unroll
-		for (int t = 0; t < 4; t++) {
+		for (int t = 0; t < DSB_SCAN_W; t++) lo = want[t] < lo ? want[t] : lo;
+		const uint32_t base = lo & ~31u;
+		if (lo != DSB_SCAN_NONE) {
+			// the three packed words that hold the wanted k-mers: a sliding window in registers, a word is loaded only when the
+			// scan has moved past the ones at hand (the texture addresser, not the memory behind it, is what this kernel
+			// saturates: every lane's load is a request of its own).  Reverse-strand lanes keep the words reverse-complemented.
+			const uint32_t wi = lo >> 5;
+			uint64_t n0, n1, n2;
+#define DSB_SCAN_WORD(dst, idx) \
+			if ((idx) == wbase) dst = K0; else if ((idx) == wbase + 1) dst = K1; else if ((idx) == wbase + 2) dst = K2; \
+			else { dst = P[idx]; if (rc) dst = dsb_revcomp_kmer(dst, 32); }
+			DSB_SCAN_WORD(n0, wi) DSB_SCAN_WORD(n1, wi + 1) DSB_SCAN_WORD(n2, wi + 2)
+#undef DSB_SCAN_WORD
+			K0 = n0; K1 = n1; K2 = n2; wbase = wi;
+		}
+		// forward lanes: bases of the block in order K0 K1 K2, window at rel; reverse lanes: the block reverse-complemented is
+		// rc(K2) rc(K1) rc(K0), and the reverse complement of the k-mer at rel is the k-mer at 96 - rel - k of that block
+		const uint64_t B0 = rc ? K2 : K0, B1 = K1, B2 = rc ? K0 : K2;
+		uint64_t km[DSB_SCAN_W], h1[DSB_SCAN_W]; bool ok[DSB_SCAN_W];
+#pragma unroll
+		for (int t = 0; t < DSB_SCAN_W; t++) {
 			ok[t] = want[t] != DSB_SCAN_NONE; km[t] = 0; h1[t] = 0;
 			if (ok[t]) {
-				const uint32_t rel = want[t] - base;                          // < 64; a window that starts in W1 ends in W1
-				const uint64_t a = rel < 32 ? W0 : W1, b = rel < 32 ? W1 : 0ULL; const uint32_t sh = (rel & 31u) * 2;
+				uint32_t rel = want[t] - base;                                // < 64: the window starts in the first or second word
+				if (rc) rel = 96u - rel - (uint32_t)k;                        // 12 .. 80
+				const uint64_t a = rel < 32 ? B0 : rel < 64 ? B1 : B2, b = rel < 32 ? B1 : B2; const uint32_t sh = (rel & 31u) * 2;
 				const uint64_t hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
-				uint64_t v = (hi >> (64 - 2 * k)) & kmask;
-				if (rc) v = dsb_revcomp_kmer(v, k);
+				const uint64_t v = (hi >> (64 - 2 * k)) & kmask;
 				ok[t] = dsb_kmer_ok(v, k, sbm); km[t] = v;
 				if (ok[t]) { p0++; h1[t] = dsb_ph1(v) & x.ek_mask; }
 			}
 		}
 		if (summ) {
-			uint8_t sb[4];
+			uint8_t sb[DSB_SCAN_W];
 #pragma unroll
-			for (int t = 0; t < 4; t++) { sb[t] = 0xff; if (ok[t]) sb[t] = summ[(h1[t] >> summ_shift) >> 3]; }
+			for (int t = 0; t < DSB_SCAN_W; t++) { sb[t] = 0xff; if (ok[t]) sb[t] = summ[(h1[t] >> summ_shift) >> 3]; }
 #pragma unroll
-			for (int t = 0; t < 4; t++) ok[t] = ok[t] && ((sb[t] >> ((h1[t] >> summ_shift) & 7)) & 1);
+			for (int t = 0; t < DSB_SCAN_W; t++) ok[t] = ok[t] && ((sb[t] >> ((h1[t] >> summ_shift) & 7)) & 1);
 		}
-		uint8_t t0[4];
+		uint8_t t0[DSB_SCAN_W];
 #pragma unroll
-		for (int t = 0; t < 4; t++) { t0[t] = 0; if (ok[t]) t0[t] = x.ek0[h1[t] >> 3]; }
+		for (int t = 0; t < DSB_SCAN_W; t++) { t0[t] = 0; if (ok[t]) t0[t] = x.ek0[h1[t] >> 3]; }
+		bool any1 = false;
 #pragma unroll
-		for (int t = 0; t < 4; t++) ok[t] = ok[t] && ((t0[t] >> (7 - (h1[t] & 7))) & 1);
+		for (int t = 0; t < DSB_SCAN_W; t++) { ok[t] = ok[t] && ((t0[t] >> (7 - (h1[t] & 7))) & 1); any1 |= ok[t]; }
 		uint32_t bits = 0;
-		if (__any(ok[0] | ok[1] | ok[2] | ok[3])) {
-			uint8_t t1[4]; uint64_t h2[4];
+		if (__any(any1)) {
+			uint8_t t1[DSB_SCAN_W]; uint64_t h2[DSB_SCAN_W];
 #pragma unroll
-			for (int t = 0; t < 4; t++) { t1[t] = 0; h2[t] = 0; if (ok[t]) { h2[t] = dsb_ph2(km[t]) & x.ek_mask; t1[t] = x.ek1[h2[t] >> 3]; p1++; } }
+			for (int t = 0; t < DSB_SCAN_W; t++) { t1[t] = 0; h2[t] = 0; if (ok[t]) { h2[t] = dsb_ph2(km[t]) & x.ek_mask; t1[t] = x.ek1[h2[t] >> 3]; p1++; } }
 #pragma unroll
-			for (int t = 0; t < 4; t++) if (ok[t] && ((t1[t] >> (7 - (h2[t] & 7))) & 1)) bits |= 1u << t;
+			for (int t = 0; t < DSB_SCAN_W; t++) if (ok[t] && ((t1[t] >> (7 - (h2[t] & 7))) & 1)) bits |= 1u << t;
 		}
 		if (s.mode != DSB_SCAN_DONE) dsb_scan_consume(s, bits, rc, store, mark);
 	}

@@ -5,10 +5,10 @@
 // behind the seed -- at a phase that depends on where the seed ended.  Which windows are consulted is therefore known
 // only while scanning: the scan is sequential per strand, and strands are independent.  Here ONE LANE scans ONE STRAND,
 // 64 strands per wavefront, and asks the two filter tables (get_exist_kmer, src/cly.c:956-972) for exactly the windows the
-// reference would ask for, plus a little speculation: in stride mode the next four stride points go out together (93 %
-// of them miss, so the look-ahead is rarely wasted), around a hit and along a run two windows at a time.  Against probing
-// every window of both strands (k_seed_probe: 2 probes per base) this issues ~0.85 per base -- the kernel is bound by
-// the rate of random 64-B requests, not by latency, so the probes not issued are the time saved -- and the seed lists
+// reference would ask for, plus some look-ahead: in stride mode the next eight stride points go out together (93 % of
+// them miss, so little of it is wasted), around a hit the two windows behind it and the six in front, along a run eight
+// at a time.  Against probing every window of both strands (k_seed_probe: 2 probes per base) this issues about one per
+// base, and the seed lists
 // (with get_seed_vector_M2's top-seed marking, src/cly.c:1174-1234) come out of the same kernel: no hit-bit arrays, no
 // scan stage in the classify kernel.
 //
@@ -30,17 +30,16 @@
 #endif
 
 #define DSB_SCAN_STRIDE 0u
-#define DSB_SCAN_BACK1 1u
-#define DSB_SCAN_BACK2 2u
+#define DSB_SCAN_BACK 1u
 #define DSB_SCAN_FWD 3u
 #define DSB_SCAN_DONE 4u
 #define DSB_SCAN_NONE 0xffffffffu
+#define DSB_SCAN_W 8           /* windows a lane asks for per round */
 
 struct DsbScan {
 	uint32_t n;                 // windows of the strand
 	uint32_t i;                 // stride position (mirrored coordinates for the reverse strand)
 	uint32_t mode;
-	uint32_t hit_m1, hit_p1;    // BACK1 results kept for BACK2
 	uint32_t off, len, j;       // the seed being extended; next forward window
 	// get_seed_vector_M2's marking of the best seed per 100-window bin (src/cly.c:1200-1234), run on each seed as it is made
 	uint32_t ns, total, max_index, max_length, index_end, cur_top;
@@ -49,26 +48,29 @@ struct DsbScan {
 DSB_SCAN_FN void dsb_scan_init(DsbScan &s, uint32_t n)
 {
 	s.n = n; s.i = 2; s.mode = n > 2 ? DSB_SCAN_STRIDE : DSB_SCAN_DONE;
-	s.hit_m1 = s.hit_p1 = 0; s.off = s.len = s.j = 0;
+	s.off = s.len = s.j = 0;
 	s.ns = 0; s.total = 0; s.max_index = 0; s.max_length = 0; s.index_end = 100; s.cur_top = 0;
 }
 
-// the windows whose bits the next step needs (DSB_SCAN_NONE = slot unused)
-DSB_SCAN_FN void dsb_scan_want(const DsbScan &s, uint32_t (&want)[4])
+// the windows whose bits the next step may need (DSB_SCAN_NONE = slot unused).  All of them lie within 24 windows of the
+// smallest, so with k <= 20 their k-mers sit in the two packed words (64 bases) that start at the word of the smallest --
+// unless the smallest sits late in its word: the kernel then loads a third word.
+DSB_SCAN_FN void dsb_scan_want(const DsbScan &s, uint32_t (&want)[DSB_SCAN_W])
 {
-	want[0] = want[1] = want[2] = want[3] = DSB_SCAN_NONE;
-	if (s.mode == DSB_SCAN_STRIDE) {
 #pragma unroll
-		for (int t = 0; t < 4; t++) { const uint32_t p = s.i + 3u * (uint32_t)t; if (p < s.n) want[t] = p; }
-	} else if (s.mode == DSB_SCAN_BACK1) {
-		want[0] = s.i - 1;                                       // i >= 2 at every hit
-		if (s.i + 1 < s.n) want[1] = s.i + 1;
-	} else if (s.mode == DSB_SCAN_BACK2) {
-		if (s.hit_m1) want[0] = s.i - 2;
-		if (s.hit_p1 && s.i + 2 < s.n) want[1] = s.i + 2;
+	for (int t = 0; t < DSB_SCAN_W; t++) want[t] = DSB_SCAN_NONE;
+	if (s.mode == DSB_SCAN_STRIDE) {
+		// the next eight stride points: 93 % of them miss, so little of the look-ahead is wasted
+#pragma unroll
+		for (int t = 0; t < DSB_SCAN_W; t++) { const uint32_t p = s.i + 3u * (uint32_t)t; if (p < s.n) want[t] = p; }
+	} else if (s.mode == DSB_SCAN_BACK) {
+		// around a hit at i: two back (i >= 2 at every hit), and the run forward
+		want[0] = s.i - 1; want[1] = s.i - 2;
+#pragma unroll
+		for (int t = 2; t < DSB_SCAN_W; t++) { const uint32_t p = s.i + (uint32_t)(t - 1); if (p < s.n) want[t] = p; }
 	} else if (s.mode == DSB_SCAN_FWD) {
-		if (s.j < s.n) want[0] = s.j;
-		if (s.j + 1 < s.n) want[1] = s.j + 1;
+#pragma unroll
+		for (int t = 0; t < DSB_SCAN_W; t++) { const uint32_t p = s.j + (uint32_t)t; if (p < s.n) want[t] = p; }
 	}
 }
 
@@ -92,33 +94,29 @@ DSB_SCAN_FN void dsb_scan_emit(DsbScan &s, bool rc, Store &store, Mark &mark)
 	s.i = s.off + l + 3; s.mode = s.i < s.n ? DSB_SCAN_STRIDE : DSB_SCAN_DONE;
 }
 
+// the run of hits in bits[from ..] (bit t = window want[t]): extends the seed, at most to 61 windows (src/cly.c:1100);
+// returns true if the run reached the last slot and may go on
+DSB_SCAN_FN bool dsb_scan_run(DsbScan &s, uint32_t bits, int from)
+{
+	const uint32_t run = (uint32_t)__builtin_ctz(~(bits >> from) | (1u << (DSB_SCAN_W - from)));   // consecutive set bits, <= W - from
+	const uint32_t room = 61u - s.len, take = run < room ? run : room;
+	s.len += take; s.j += take;
+	return take == (uint32_t)(DSB_SCAN_W - from) && s.len < 61 && s.j < s.n;
+}
+
 // bits: bit t = window want[t] hit (0 for unused slots)
 template <class Store, class Mark>
 DSB_SCAN_FN void dsb_scan_consume(DsbScan &s, uint32_t bits, bool rc, Store &store, Mark &mark)
 {
 	if (s.mode == DSB_SCAN_STRIDE) {
-		if (bits & 15u) {
-			const uint32_t t = (uint32_t)__builtin_ctz(bits & 15u);
-			s.i += 3u * t; s.mode = DSB_SCAN_BACK1;
-		} else { s.i += 12; if (s.i >= s.n) s.mode = DSB_SCAN_DONE; }
-	} else if (s.mode == DSB_SCAN_BACK1) {
-		s.hit_m1 = bits & 1u; s.hit_p1 = (bits >> 1) & 1u;
-		if (!s.hit_m1 && !s.hit_p1) { s.off = s.i; s.len = 1; dsb_scan_emit(s, rc, store, mark); }
-		else s.mode = DSB_SCAN_BACK2;
-	} else if (s.mode == DSB_SCAN_BACK2) {
-		const uint32_t hit_m2 = s.hit_m1 ? (bits & 1u) : 0u, hit_p2 = s.hit_p1 ? ((bits >> 1) & 1u) : 0u;
-		const uint32_t back = s.hit_m1 ? (hit_m2 ? 2u : 1u) : 0u;
-		s.off = s.i - back; s.len = 1 + back + s.hit_p1 + hit_p2;
-		s.j = s.i + 3;
-		// the run goes on behind i+2 only if both forward windows hit; a seed holds at most 61 windows (src/cly.c:1100)
-		if (s.hit_p1 && hit_p2 && s.j < s.n && s.len < 61) s.mode = DSB_SCAN_FWD; else dsb_scan_emit(s, rc, store, mark);
+		if (bits) { s.i += 3u * (uint32_t)__builtin_ctz(bits); s.mode = DSB_SCAN_BACK; }
+		else { s.i += 3u * DSB_SCAN_W; if (s.i >= s.n) s.mode = DSB_SCAN_DONE; }
+	} else if (s.mode == DSB_SCAN_BACK) {
+		const uint32_t back = (bits & 1u) ? ((bits & 2u) ? 2u : 1u) : 0u;
+		s.off = s.i - back; s.len = 1 + back; s.j = s.i + 1;
+		if (dsb_scan_run(s, bits, 2)) s.mode = DSB_SCAN_FWD; else dsb_scan_emit(s, rc, store, mark);
 	} else if (s.mode == DSB_SCAN_FWD) {
-		bool more = false;
-		if (bits & 1u) {
-			s.len++; s.j++;
-			if (s.len < 61 && s.j < s.n && (bits & 2u)) { s.len++; s.j++; more = s.len < 61 && s.j < s.n; }
-		}
-		if (!more) dsb_scan_emit(s, rc, store, mark);
+		if (!dsb_scan_run(s, bits, 0)) dsb_scan_emit(s, rc, store, mark);
 	}
 }
 

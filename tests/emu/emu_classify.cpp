@@ -172,15 +172,16 @@ extern "C" int emu_scan_seeds(void *p, int strand, DsbSeed *out, int max_out, ui
 	DsbScan s; dsb_scan_init(s, n);
 	uint32_t np = 0, nall = 0;
 	while (s.mode != DSB_SCAN_DONE) {
-		uint32_t want[4]; dsb_scan_want(s, want); uint32_t bits = 0;
-		uint32_t lo = DSB_SCAN_NONE; for (int t = 0; t < 4; t++) if (want[t] < lo) lo = want[t];
-		for (int t = 0; t < 4; t++) {
+		uint32_t want[DSB_SCAN_W]; dsb_scan_want(s, want); uint32_t bits = 0;
+		uint32_t lo = DSB_SCAN_NONE; for (int t = 0; t < DSB_SCAN_W; t++) if (want[t] < lo) lo = want[t];
+		for (int t = 0; t < DSB_SCAN_W; t++) {
 			if (want[t] == DSB_SCAN_NONE) continue;
 			nall++;
-			// the kernel's two-word window: every wanted window lies within the two packed words at lo >> 5
+			// the kernel's three-word window: every wanted window starts within the two packed words at lo >> 5
 			const uint32_t base = lo & ~31u, rel = want[t] - base;
-			const uint64_t W0 = e->pk[lo >> 5], W1 = e->pk[(lo >> 5) + 1];
-			const uint64_t a = rel < 32 ? W0 : W1, b = rel < 32 ? W1 : 0ULL; const uint32_t sh = (rel & 31u) * 2;
+			if (rel >= 64) abort();
+			const size_t wi = lo >> 5; const uint64_t W0 = e->pk[wi], W1 = e->pk[wi + 1], W2 = wi + 2 < (L + 31) / 32 + 1 ? e->pk[wi + 2] : 0;
+			const uint64_t a = rel < 32 ? W0 : W1, b = rel < 32 ? W1 : W2; const uint32_t sh = (rel & 31u) * 2;
 			const uint64_t hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
 			uint64_t v = (hi >> (64 - 2 * k)) & kmask;
 			if (rc) v = dsb_revcomp_kmer(v, k);

@@ -441,7 +441,7 @@ def test_seed_scan_kernel_long_reads_vs_oracle(gpu, demo, oracle, tmp_path, monk
     hits, _ = classify_all(D, ctx, recs)
     t = ctx.timing()
     assert t.seed_scan == 1
-    assert 0.7 * t.bases < t.windows < 0.9 * t.bases           # ~0.79 probes per base (all windows of both strands: 2.0)
+    assert 0.7 * t.bases < t.windows < 1.05 * t.bases          # ~0.9 probes per base (all windows of both strands: 2.0)
     for i in random.Random(3).sample(range(len(recs)), 64):
         assert hits[i] == oracle.classify(recs[i][1], 50000), recs[i][0]
     ok = sum(1 for (nm, s, q), h in zip(recs, hits) if h and h[0][0] == int(nm.split(b"_")[1]))

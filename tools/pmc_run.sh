@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect rocprofv3 PMC counters for the bench workload, one pass per counter group (PMC only, no tracing).
 #   tools/pmc_run.sh <tag> <reads> "<CTR CTR ...>" ["<CTR ...>" ...]
-# Writes gpurun_out/pmc_<tag>.json: per-kernel sums over all dispatches of every counter.
+# Writes gpurun_out/pmc_<tag>.json: per-kernel, per-launch averages of every counter.
 set -e -o pipefail
 cd "$(dirname "$0")/.."
 ROOT=$PWD
@@ -12,11 +12,12 @@ i=0
 for grp in "$@"; do
 	out=$ROOT/gpurun_out/pmc_${tag}_$i
 	rm -rf "$out"
-	(cd /tmp && timeout -k 10 120 rocprofv3 --pmc $grp -d "$out" -o run --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --steps 1 --warmup 0 --reads-per-gpu "$reads" > "$out.log" 2>&1)
+	(cd /tmp && timeout -k 10 200 rocprofv3 --pmc $grp -d "$out" -o run --output-format csv -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-end-to-end --steps 2 --warmup 0 --batches 1 --reads-per-gpu "$reads" > "$out.log" 2>&1) || { echo "pass $i ($grp) failed"; tail -5 "$out.log"; }
 	i=$((i+1))
 done
-python3 - "$tag" "$reads" <<'EOF'
+python3 - "$tag" "$reads" <<'PYEOF'
 import csv, glob, json, sys, collections
+sys.path.insert(0, ".")
 tag, reads = sys.argv[1], int(sys.argv[2])
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
@@ -28,6 +29,10 @@ for f in glob.glob("gpurun_out/pmc_%s_*/**/*counter_collection.csv" % tag, recur
 for k in acc:                     # per launch: average over the dispatches of the kernel
     for c in acc[k]:
         acc[k][c] /= max(len(disp[k][c]), 1)
-json.dump({"workload": "%d x 50 kbp ONT reads, bench.py --steps 1 --warmup 0; per-launch averages" % reads, "counters": acc}, open("gpurun_out/pmc_%s.json" % tag, "w"), indent=1, sort_keys=True)
-print(json.dumps(acc.get("k_classify", {}), indent=1, sort_keys=True))
-EOF
+import desamba_amd as D
+json.dump({"workload": {"reads_per_gpu": reads, "read_len": 50000, "library": D.lib().dsb_version().decode(),
+                        "what": "%d x 50 kbp ONT reads, bench.py --steps 2 --warmup 0 --batches 1; per-launch averages" % reads}, "counters": acc},
+          open("gpurun_out/pmc_%s.json" % tag, "w"), indent=1, sort_keys=True)
+for k in ("k_seed_scan", "k_classify"):
+    print(k, json.dumps(acc.get(k, {}), sort_keys=True))
+PYEOF
