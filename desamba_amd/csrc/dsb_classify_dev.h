@@ -338,6 +338,22 @@ DV void get_ref_wave(const uint8_t *txt, uint64_t lim, int lane, uint8_t *out, i
 	}
 }
 
+// the same with the raw 4-byte word of this lane's first 8 bases already loaded (sdp_middle_M2 fetches the next gap's
+// window while it works on the current one); positions from 8 * DSB_WAVE on are loaded here
+DV void get_ref_wave_pf(const uint8_t *txt, int lane, uint8_t *out, int64_t off, int32_t length, uint32_t raw0)
+{
+	for (int32_t k = 8 * lane; k < length; k += 8 * DSB_WAVE) {
+		uint64_t p = (uint64_t)off + (uint32_t)k;
+		const uint32_t raw = k < 8 * DSB_WAVE ? raw0 : dsb_g32u(txt + (p >> 2));
+		uint32_t v = __builtin_bswap32(raw), s = (uint32_t)p & 3u;
+		uint64_t o = 0;
+#pragma unroll
+		for (int m = 0; m < 8; m++) o |= (uint64_t)((v >> (30 - 2 * (s + m))) & 3u) << (8 * m);
+		if (k + 8 <= length) *reinterpret_cast<uint64_t *>(out + k) = o;
+		else for (int m = 0; k + m < length; m++) out[k + m] = (uint8_t)(o >> (8 * m));
+	}
+}
+
 // get_uni (src/cly.c:471-496)
 DV int64_t get_uni(DsbXP x, const Cnt &k, uint64_t bwt_pos, int search_l, uint64_t *global_offset, uint32_t *uni_offset_)
 {
@@ -1081,9 +1097,11 @@ DN void chain_sort_M3(WCtx &w)
 	wave_sync();
 	w.anc = T; w.anc_tmp = A;
 }
-// ... and its serial part (one lane).  LDSMODE: the fields the DP touches were staged in LDS by chain_stage_M3
-// (q, t, mtch_len, then the score and predecessor arrays), n <= DSB_CHAINDP_LDS.
-#define DSB_CHAINDP_LDS (DSB_WTAB_SLOTS / 5 / 64 * 64)   /* five 4-byte arrays in the window table's LDS */
+// ... and the DP.  The usual size (n <= DSB_CHAINDP_LDS anchors) runs on the whole wavefront from six 4-byte arrays
+// staged in the window table's LDS -- q, t, mtch_len | score << 16, key (ref_ID << 3 | direction << 2 | useless << 1 |
+// duplicate), then the DP's score and predecessor -- with the lanes over the predecessors of one anchor at a time
+// (chain_dp_M3_wave); larger sets take the serial form on lane 0 from global memory (chain_dp_M3<false>).
+#define DSB_CHAINDP_LDS (DSB_WTAB_SLOTS / 6)              /* 512 */
 #ifdef DSB_HOST_EMU
 typedef uint32_t lds_w32;
 #else
@@ -1093,15 +1111,81 @@ DN void chain_stage_M3(WCtx &w)
 {
 	const DsbAnchor *A = w.anc; const int32_t n = w.n_anc; const int lane = w.lane;
 	lds_w32 *L = (lds_w32 *)w.wtab;
-	for (int32_t i = lane; i < n; i += DSB_WAVE) { L[i] = A[i].index_in_read; L[DSB_CHAINDP_LDS + i] = A[i].ref_offset; L[2 * DSB_CHAINDP_LDS + i] = A[i].mtch_len; }
+	for (int32_t i = lane; i < n; i += DSB_WAVE) {
+		const DsbAnchor a = A[i];
+		L[i] = a.index_in_read; L[DSB_CHAINDP_LDS + i] = a.ref_offset; L[2 * DSB_CHAINDP_LDS + i] = (uint32_t)a.mtch_len | ((uint32_t)(uint16_t)a.score << 16);
+		L[3 * DSB_CHAINDP_LDS + i] = (a.ref_ID << 3) | ((uint32_t)a.direction << 2) | ((uint32_t)(a.useless ? 1 : 0) << 1) | (uint32_t)(a.duplicate ? 1 : 0);
+	}
 	wave_sync();
 }
 DN void chain_unstage_M3(WCtx &w)
 {
 	DsbAnchor *A = w.anc; const int32_t n = w.n_anc; const int lane = w.lane;
-	const lds_w32 *P = (const lds_w32 *)w.wtab + 4 * DSB_CHAINDP_LDS;
+	const lds_w32 *P = (const lds_w32 *)w.wtab + 5 * DSB_CHAINDP_LDS;
 	wave_sync();
 	for (int32_t i = lane; i < n; i += DSB_WAVE) A[i].pre = (int32_t)P[i];
+	wave_sync();
+}
+// chain_insert_M3's DP (src/cly.c:252-323) on the wavefront.  The reference scans the predecessors of an anchor from the
+// nearest one backwards, skips those that overlap it, stops at the first one more than 1000 bases away, and keeps the
+// first predecessor that strictly improves the running best: lane l takes predecessor hi - l of a chunk of 64, a ballot
+// finds the stop, a wave maximum the best score, and among equal scores the nearest predecessor (lowest lane) wins.
+DN void chain_dp_M3_wave(WCtx &w)
+{
+	const int32_t n = w.n_anc; const int lane = w.lane;
+	lds_w32 *LQ = (lds_w32 *)w.wtab, *LT = LQ + DSB_CHAINDP_LDS, *LMS = LQ + 2 * DSB_CHAINDP_LDS, *LK = LQ + 3 * DSB_CHAINDP_LDS,
+	        *LS = LQ + 4 * DSB_CHAINDP_LDS, *LP = LQ + 5 * DSB_CHAINDP_LDS;
+	for (int32_t st = 0; st < n;) {
+		int32_t ed = st + 1;
+		const uint32_t key = (uint32_t)LK[st] >> 2;
+		for (; ed < n && ((uint32_t)LK[ed] >> 2) == key && (uint32_t)LT[ed] - (uint32_t)LT[ed - 1] < 2000; ed++);
+		if (ed - st > 1024) ed = st + 1024;
+		int32_t max_anchor = -1; int max_score = 0;
+		for (int32_t ca = st; ca < ed; ca++) {
+			const uint32_t ms = LMS[ca]; int ams = (int)(int16_t)(ms >> 16); const uint32_t ca_ml = ms & 0xffffu;
+			const uint32_t max_t = (uint32_t)LT[ca] + 3, max_q = (uint32_t)LQ[ca] + 3;
+			int32_t best_pre = -1;
+			for (int32_t hi = ca - 1; hi >= st; hi -= DSB_WAVE) {
+				const int32_t p = hi - lane; const bool valid = p >= st;
+				uint32_t p_q = 0, p_t = 0, p_ml = 0; int p_s = 0;
+				if (valid) { p_q = LQ[p]; p_t = LT[p]; p_ml = (uint32_t)LMS[p] & 0xffffu; p_s = (int)LS[p]; }
+				const bool skip = (p_q + p_ml > max_q) || (p_t + p_ml > max_t);
+				const bool brk = valid && !skip && ((p_q + 1000 < max_q) || (p_t + 1000 < max_t));
+				const int first_brk = grp_first(w.red, lane, brk);
+				const int indel = (int)(p_q - p_t - (max_q - max_t)); const int ai = ABSV(indel);
+				const bool ok = valid && !skip && !brk && ai <= 200 && lane < first_brk;
+				const int ns = ok ? (int)(p_s + (int)ca_ml - (ai >> 4) - (int)((max_q - p_q) >> 8)) : (-2147483647 - 1);
+				const int m = grp_max_i(w.red, lane, ns);
+				if (m > ams) { ams = m; best_pre = hi - grp_first(w.red, lane, ok && ns == m); }
+				if (first_brk < DSB_WAVE) break;
+			}
+			if (lane == 0) { LP[ca] = (uint32_t)best_pre; LS[ca] = (uint32_t)ams; }
+			wave_sync();
+			if (max_score < ams) { max_score = ams; max_anchor = ca; }
+		}
+		int sum_INDEL = 0, anchor_number = 1; int32_t pre = max_anchor;
+		uint32_t fl = LK[max_anchor];
+		int sum_score = (fl & 1u) ? 1 : (int)(int16_t)((uint32_t)LMS[max_anchor] >> 16);
+		bool with_top = !(fl & 2u);
+		for (; (int32_t)LP[pre] != -1; anchor_number++) {
+			const int32_t pre_ = (int32_t)LP[pre];
+			sum_INDEL += (int)(((uint32_t)LQ[pre] - (uint32_t)LQ[pre_]) - ((uint32_t)LT[pre] - (uint32_t)LT[pre_]));
+			fl = LK[pre];
+			with_top |= !(fl & 2u);
+			sum_score += (fl & 1u) ? 1 : (int)(int16_t)((uint32_t)LMS[pre] >> 16);
+			pre = pre_;
+		}
+		DsbChain *nc = push_hit(w);
+		if (lane == 0) {
+			nc->chain_id = w.n_hit - 1; nc->ref_ID = key >> 1; nc->direction = (uint8_t)(key & 1u);
+			nc->q_t_dis = (int32_t)((uint32_t)LT[max_anchor] - (uint32_t)LQ[max_anchor]);
+			nc->t_st = LT[pre]; nc->t_ed = (uint32_t)LT[max_anchor] + ((uint32_t)LMS[max_anchor] & 0xffffu);
+			nc->q_st = LQ[pre]; nc->q_ed = (uint32_t)LQ[max_anchor] + ((uint32_t)LMS[max_anchor] & 0xffffu);
+			nc->with_top_anchor = with_top; nc->anchor_number = anchor_number; nc->sum_score = sum_score;
+			nc->indel = sum_INDEL; nc->cur = max_anchor; nc->primary = 0; nc->pri_index = 0;
+		}
+		st = ed;
+	}
 	wave_sync();
 }
 template <bool LDSMODE>
@@ -1226,18 +1310,16 @@ DN void resolve_tree(WCtx &w)
 	w.n_hit = 0;
 	const bool lds_dp = w.n_anc >= 50 && w.n_anc <= DSB_CHAINDP_LDS && w.wtab;
 	if (w.n_anc >= 50) chain_sort_M3(w);
-	if (lds_dp) chain_stage_M3(w);
+	if (lds_dp) { chain_stage_M3(w); chain_dp_M3_wave(w); chain_unstage_M3(w); }
 	DSB_SERIAL(w) {
 		if (w.n_anc < 50) for (uint32_t i = 0; i < w.n_anc; i++) chain_insert_M2(w, i);
-		else if (lds_dp) chain_dp_M3<true>(w);
-		else chain_dp_M3<false>(w);
+		else if (!lds_dp) chain_dp_M3<false>(w);
 		if (w.n_hit > 1) glibc_sort_chains<0>(w, w.n_hit);
 		int rst_num = MINV(5, w.n_hit);
 		while (rst_num < w.n_hit && w.hit[rst_num].with_top_anchor == 1) rst_num++;
 		w.n_hit = rst_num;
 	}
 	serial_end(w);
-	if (lds_dp) chain_unstage_M3(w);
 }
 
 // ---- sc_hash_idx / combine_chain (src/cly.c:1691-1710,1763-1808) -------------------------------
@@ -1850,10 +1932,32 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 	const uint64_t t_offset = x->refinfo[ca.ref_ID].seq_offset;
 	// the chain is a linked list: the anchor after next is loaded one gap ahead, off the critical path
 	DsbAnchor pa = A[ca.pre != -1 ? ca.pre : c_a];
+	DsbAnchor nxt = A[(ca.pre != -1 && pa.pre != -1) ? pa.pre : c_a];
+	// The window of the NEXT gap (read stretch and packed reference words, the first 8 * 64 bytes / bases of each, which is
+	// all of a usual gap) is requested while this gap is worked on: pf_* hold what was asked for during the previous gap.
+	uint64_t pf_q = 0; uint32_t pf_t = 0; int32_t pf_qlo = 0; uint64_t pf_toff = ~0ULL; bool pf_has_q = false, pf_has_t = false;
 	for (;;) {
 		const int32_t pre_a = ca.pre;
 		if (pre_a == -1) { score += ca.mtch_len - 9 + 1; break; }
-		const DsbAnchor nxt = A[pa.pre != -1 ? pa.pre : pre_a];
+		// (the anchor after next is loaded one gap ahead as well: the addresses of the next window come from `nxt`)
+		const DsbAnchor nx2 = A[(pa.pre != -1 && nxt.pre != -1) ? nxt.pre : c_a];
+		const uint64_t cur_q = pf_q; const uint32_t cur_t = pf_t; const int32_t cur_qlo = pf_qlo; const uint64_t cur_toff = pf_toff; const bool cur_has_q = pf_has_q, cur_has_t = pf_has_t;
+		pf_has_q = pf_has_t = false;
+#ifndef DSB_HOST_EMU
+		if (pa.pre != -1) {
+			const int n_mch = nxt.mtch_len, n_tlen = (int)(pa.ref_offset - ((nxt.ref_offset - 3) + n_mch) + 3);
+			if (n_tlen > 12 && n_tlen < 2000) {
+				const uint64_t n_toff = (uint64_t)(int64_t)(int)(nxt.ref_offset - 3) + t_offset + (uint64_t)(int64_t)n_mch;
+				const int32_t n_qlo = (int32_t)(nxt.index_in_read + n_mch - 8) - 16, n_qhi = (int32_t)(pa.index_in_read - 1) + 80;
+				if ((int64_t)n_toff >= 0 && n_toff < x->ref_bases && 8 * lane < n_tlen) pf_t = dsb_g32u(x->refbin + ((n_toff + (uint32_t)(8 * lane)) >> 2));
+				pf_toff = n_toff; pf_has_t = (int64_t)n_toff >= 0 && n_toff < x->ref_bases;
+				if (n_qhi > n_qlo && n_qlo >= -(int32_t)DSB_QPAD_L + 8) {
+					if (8 * lane < ((n_qhi - n_qlo + 7) & ~7)) pf_q = ld_u64(q_str + n_qlo + 8 * lane);
+					pf_qlo = n_qlo; pf_has_q = true;
+				}
+			}
+		}
+#endif
 		const int pre_mch = pa.mtch_len;
 		const int pre_refoffset = pa.ref_offset - 3;
 		const int total_ref_len = ca.ref_offset - (pre_refoffset + pre_mch) + 3;
@@ -1877,10 +1981,13 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 			if (n_q > 0 && q_bytes && q_lo >= -(int32_t)DSB_QPAD_L + 8 && 4 * slots + q_bytes + 8 + t_bytes + 8 + 1024 <= 4 * DSB_WTAB_SLOTS) {
 				uint8_t *lq = reinterpret_cast<uint8_t *>(wtab + slots), *lt = lq + q_bytes + 8;
 				lnodes = reinterpret_cast<uint4 *>(lt + t_bytes + (((4 * slots + q_bytes + t_bytes) & 8u) ? 0 : 8));   // 16-byte aligned: the table starts 16-aligned
-				for (uint32_t k = 8 * lane; k < q_bytes; k += 8 * DSB_WAVE) *reinterpret_cast<uint64_t *>(lq + k) = ld_u64(q_str + q_lo + (int32_t)k);
+				const bool use_pf = cur_has_q && cur_qlo == q_lo;
+				for (uint32_t k = 8 * lane; k < q_bytes; k += 8 * DSB_WAVE) *reinterpret_cast<uint64_t *>(lq + k) = (use_pf && k < 8 * DSB_WAVE) ? cur_q : ld_u64(q_str + q_lo + (int32_t)k);
 				ref = lt; qs = nullptr; lq_st = lq;
 			}
-			get_ref_wave(x->refbin, x->ref_bases, lane, ref, ref_offset, total_ref_len); cnt_add(Cnt{w.k.c, 1u}, 3, (uint32_t)total_ref_len);
+			if (cur_has_t && cur_toff == ref_offset) get_ref_wave_pf(x->refbin, lane, ref, (int64_t)ref_offset, total_ref_len, cur_t);
+			else get_ref_wave(x->refbin, x->ref_bases, lane, ref, ref_offset, total_ref_len);
+			cnt_add(Cnt{w.k.c, 1u}, 3, (uint32_t)total_ref_len);
 			for (int k = total_ref_len + lane; k < total_ref_len + 64; k += DSB_WAVE) ref[k] = DSB_TPAD_VAL;   // reads reach <= 58 past the window
 			wave_sync();
 			n_sms = lq_st ? sdp_match_lds(w, n_sms, q_bg, q_ed, lq_st, q_lo, ref, total_ref_len, pre_refoffset + pre_mch, lnodes)
@@ -1932,7 +2039,7 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 				}
 			}
 		}
-		ca = pa; pa = nxt;
+		ca = pa; pa = nxt; nxt = nx2;
 	}
 	w.n_sms = 0;
 	return score - 10000;

@@ -942,7 +942,6 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	// forces one or the other.  The early launch of the heaviest reads always takes the hit-bit path.
 	bool use_scan = n >= 2048;
 	if (const char *e = getenv("DSB_SEED_SCAN")) use_scan = atoi(e) != 0;
-	if (dbg) use_scan = false;
 	c->bits_valid = !use_scan; c->seeds_valid = use_scan;
 	uint32_t step_limit = DSB_STEP_LIMIT;
 	if (const char *e = getenv("DSB_STEP_LIMIT_RT")) { long v = atol(e); if (v > 0) step_limit = (uint32_t)v; }   // diagnostics: a small budget forces second runs
