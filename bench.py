@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-seed-hbm", action="store_true", help="skip the seed-lookup measurement on synthetic multi-GiB filter tables")
+    ap.add_argument("--seed-hbm-mib", type=int, default=2048, help="size of each synthetic filter table (MiB, power of two 128 .. 16384)")
     ap.add_argument("--slots", type=int, default=0, help="reads in flight per GPU (0 = library default)")
     a = ap.parse_args()
 
@@ -234,6 +236,7 @@ def main():
         ctx.select_slot(i % B); ctx.run()
     sync_all()
     t0 = time.perf_counter()
+    seed_scan_used = False
     acc = {"probe": 0.0, "cls": 0.0, "enc": 0.0, "order": 0.0, "tail": 0.0, "windows": 0, "p1": 0, "bases": 0, "occ": 0, "mem": 0, "sa": 0, "rb": 0,
            "m_occ": 0, "m_mem": 0, "m_sa": 0, "m_rb": 0, "early": 0, "retry": 0}
     for i in range(a.steps):
@@ -244,7 +247,7 @@ def main():
         acc["windows"] += tm.windows; acc["p1"] += tm.probes_t1; acc["bases"] += tm.bases
         acc["occ"] += tm.n_occ; acc["mem"] += tm.n_mem; acc["sa"] += tm.n_sa; acc["rb"] += tm.ref_bases
         acc["m_occ"] += tm.main_occ; acc["m_mem"] += tm.main_mem; acc["m_sa"] += tm.main_sa; acc["m_rb"] += tm.main_ref_bases
-        acc["early"] += tm.n_early; acc["retry"] += tm.n_retry
+        acc["early"] += tm.n_early; acc["retry"] += tm.n_retry; seed_scan_used = bool(tm.seed_scan)
     sync_all()
     dt = time.perf_counter() - t0
     if dist:
@@ -305,6 +308,32 @@ def main():
                "what": "per batch: H2D of the raw FASTQ text (sequence + quality lines, %.1f GB) from pinned memory, all kernels, D2H of per-read results and hits; two contexts on the GPU share the staged index and overlap each other" % (bufs[0][1] / 1e9)}
         ctx2.close()
 
+    # ---- the seed-lookup kernel in the HBM regime: 2 x 2 GiB synthetic filter tables, 20 % full (no index of that size exists here;
+    # SURVEY.md 8d asks for the roofline claim on multi-GiB tables).  Only the seed lookup runs; answers on such tables are
+    # checked against a host recomputation in tests/test_gpu_parity.py::test_seed_lookup_on_synthetic_multi_gib_tables.
+    seed_hbm = None
+    if rank == 0 and not a.no_seed_hbm:
+        ctx3 = D.Ctx(idx, local, max_read_len=0, max_batch_reads=0, input_slots=1)
+        ctx3.use_synthetic_filter(a.seed_hbm_mib << 20, 0.2)
+        ctx3.upload_text(bufs[0][0], bufs[0][1], bufs[0][2], bufs[0][3], R)
+        ms = []; tm3 = None
+        for _ in range(4):
+            ctx3.run(); tm3 = ctx3.timing(); ms.append(tm3.seed_probe_ms)
+        ms = sorted(ms[1:])[len(ms[1:]) // 2]
+        by = tm3.bases + 64.0 * (tm3.windows + tm3.probes_t1)
+        seed_hbm = {"kernel": "k_seed_scan" if tm3.seed_scan else "k_seed_probe", "bound": "hbm", "tables": "2 x %d MiB synthetic, 20 %% of the bits set (k = 18)" % a.seed_hbm_mib,
+                    "ms": ms, "algorithmic_bytes": by, "achieved": by / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
+                    "probes_per_base": tm3.windows / max(tm3.bases, 1), "table1_probes_per_base": tm3.probes_t1 / max(tm3.bases, 1), "traffic": None}
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_seed_hbm.json")))
+            wl = prof.get("workload", {})
+            if wl.get("reads_per_gpu") == R and wl.get("read_len") == Lr and wl.get("library") == D.lib().dsb_version().decode() and wl.get("table_mib") == a.seed_hbm_mib:
+                cn = prof["counters"][seed_hbm["kernel"]]
+                seed_hbm["traffic"] = (cn["FETCH_SIZE"] + cn["WRITE_SIZE"]) * 1024.0
+        except Exception:
+            pass
+        ctx3.close()
+
     if rank == 0:
         steps = max(a.steps, 1)
         value = R * world * a.steps / dt
@@ -317,7 +346,7 @@ def main():
         main_reads_frac = 1.0 - acc["early"] / float(R * steps)
         cls_bytes = (64.0 * acc["m_occ"] + 16.0 * acc["m_mem"] + 24.0 * acc["m_sa"] + acc["m_rb"] / 4.0 + 2.0 * acc["bases"] * main_reads_frac) / steps
         dom_is_cls = classify_s >= probe_s
-        roof_seed = {"kernel": "k_seed_probe", "bound": "hbm", "achieved": seed_bytes / probe_s / 1e9 if probe_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
+        roof_seed = {"kernel": "k_seed_scan" if seed_scan_used else "k_seed_probe", "bound": "hbm", "achieved": seed_bytes / probe_s / 1e9 if probe_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "traffic": None, "ms": probe_s * 1e3, "algorithmic_bytes": seed_bytes}
         roof_seed["frac"] = roof_seed["achieved"] / HBM_PEAK_GBS
         roof_cls = {"kernel": "k_classify", "bound": "hbm", "achieved": cls_bytes / classify_s / 1e9 if classify_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
@@ -333,7 +362,7 @@ def main():
             wl = prof.get("workload", {})
             if wl.get("reads_per_gpu") == R and wl.get("read_len") == Lr and wl.get("library") == D.lib().dsb_version().decode():
                 cn = prof["counters"]
-                roof_seed["traffic"] = (cn["k_seed_probe"]["FETCH_SIZE"] + cn["k_seed_probe"]["WRITE_SIZE"]) * 1024.0
+                roof_seed["traffic"] = (cn[roof_seed["kernel"]]["FETCH_SIZE"] + cn[roof_seed["kernel"]]["WRITE_SIZE"]) * 1024.0
                 roof_cls["traffic"] = (cn["k_classify"]["FETCH_SIZE"] + cn["k_classify"]["WRITE_SIZE"]) * 1024.0
         except Exception:
             pass
@@ -343,12 +372,13 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64 integer", "data": "synthetic",
             "config": {"workload": "demo viral-gs index (463 genomes, k=16 filter, 828 MB) + %d distinct batches of %d synthetic %d bp ONT-15%%-error reads per GPU (BASELINE configs[1] shape; %d reads per GPU)" % (B, R, Lr, B * R),
                        "reads_per_gpu": R, "read_len": Lr, "batches_per_gpu": B, "parallelism": "reads sharded x%d, index replicated" % world},
-            "kernel_ms_per_step": {"k_encode": acc["enc"] / steps, "order+early_probe": acc["order"] / steps, "k_seed_probe": acc["probe"] / steps,
+            "kernel_ms_per_step": {"k_encode": acc["enc"] / steps, "order+early_probe": acc["order"] / steps, ("k_seed_scan" if seed_scan_used else "k_seed_probe"): acc["probe"] / steps,
                                    "k_classify": acc["cls"] / steps, "wait_for_k_classify_early": acc["tail"] / steps},
             "reads_in_early_launch": acc["early"] / steps,
             "reads_in_second_run": acc["retry"] / steps,    # an arena or the loop budget outgrown; their time is part of the wait term
             "roofline": roof_cls if dom_is_cls else roof_seed,
             "roofline_seed_lookup": roof_seed,
+            "roofline_seed_lookup_hbm": seed_hbm,
             "end_to_end": e2e,
             "reads_mapped_frac": n_mapped / max(R, 1), "reads_with_device_status": n_bad,
             "per_read_wave_us": {"mean": sum(dev_us) / max(len(dev_us), 1), "median": dev_us[len(dev_us) // 2] if dev_us else 0,

@@ -61,7 +61,7 @@ EXPORTS = ["dsb_index_open", "dsb_index_close", "dsb_index_n_ref", "dsb_index_re
            "dsb_batch_upload", "dsb_batch_upload_fastq", "dsb_batch_upload_text", "dsb_ctx_set_history", "dsb_host_alloc", "dsb_host_free", "dsb_batch_run", "dsb_batch_fetch", "dsb_batch_timing", "dsb_batch_seeds", "dsb_batch_exist_bits",
            "dsb_format_sam", "dsb_format_des", "dsb_strerror", "dsb_version",
            "dsb_device_count", "dsb_ctx_select_slot", "dsb_ctx_create_multi", "dsb_multi_destroy", "dsb_multi_n", "dsb_multi_ctx",
-           "dsb_multi_reset_history", "dsb_multi_classify_batch", "dsb_shard_plan"]
+           "dsb_multi_reset_history", "dsb_multi_classify_batch", "dsb_shard_plan", "dsb_ctx_use_synthetic_filter", "dsb_synthetic_filter_bit"]
 
 _lib = None
 
@@ -109,6 +109,8 @@ def lib():
     L.dsb_multi_reset_history.argtypes = [C.c_void_p]; L.dsb_multi_reset_history.restype = None
     L.dsb_multi_classify_batch.argtypes = [C.c_void_p, C.POINTER(DsbRead), C.c_size_t, C.POINTER(DsbResult)]
     L.dsb_shard_plan.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.c_uint64, C.c_uint32, C.POINTER(DsbChunk), C.c_size_t, C.POINTER(C.c_size_t)]
+    L.dsb_ctx_use_synthetic_filter.argtypes = [C.c_void_p, C.c_uint64, C.c_double]
+    L.dsb_synthetic_filter_bit.argtypes = [C.c_int, C.c_uint64, C.c_double]
     L.dsb_index_close.restype = None; L.dsb_ctx_destroy.restype = None; L.dsb_ctx_reset_history.restype = None
     L.dsb_strerror.argtypes = [C.c_int]; L.dsb_strerror.restype = C.c_char_p
     L.dsb_version.restype = C.c_char_p
@@ -189,6 +191,13 @@ class Ctx:
 
     def set_history(self, max_len_before):
         lib().dsb_ctx_set_history(self.h, max_len_before)
+
+    def use_synthetic_filter(self, table_bytes, fill):
+        """measurement hook: synthetic exist-kmer tables for this ctx (seed lookup only); upload the batch afterwards"""
+        rc = lib().dsb_ctx_use_synthetic_filter(self.h, table_bytes, fill)
+        if rc != 0:
+            raise DsbError(rc, "dsb_ctx_use_synthetic_filter")
+        self.synthetic = (table_bytes, fill)
 
     def select_slot(self, slot):
         rc = lib().dsb_ctx_select_slot(self.h, slot)

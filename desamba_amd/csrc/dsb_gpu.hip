@@ -314,6 +314,24 @@ __global__ void __launch_bounds__(256) k_seed_scan(DsbDevIndex x, const DsbReadD
 	}
 }
 
+// ---- synthetic filter tables (measurement hook, dsb_ctx_use_synthetic_filter): bit b of table `which` is set iff a 24-bit
+// mix of (b, which) is below a threshold -- any bit can be recomputed on the host without keeping the table
+__host__ __device__ inline uint32_t dsb_synth_mix(uint64_t b, uint32_t which)
+{
+	uint64_t z = b * 0x9E3779B97F4A7C15ULL + ((uint64_t)which + 1) * 0xD1342543DE82EF95ULL;
+	z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+	return (uint32_t)((z ^ (z >> 31)) >> 40);
+}
+__global__ void __launch_bounds__(256) k_synth_table(uint8_t *tab, uint64_t n_bytes, uint32_t which, uint32_t thresh)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_bytes; i += (uint64_t)gridDim.x * 256) {
+		uint32_t v = 0;
+#pragma unroll
+		for (int j = 0; j < 8; j++) if (dsb_synth_mix(i * 8 + j, which) < thresh) v |= 1u << (7 - j);   // bit h of the table = bit 7 - (h & 7) of byte h >> 3 (src/cly.c:956-972)
+		tab[i] = (uint8_t)v;
+	}
+}
+
 // ---- work order: longest-processing-time-first -----------------------------------------------------
 // The batch ends when its slowest read ends, and the slow reads are the ones whose sparse DP explodes:
 // tandem-repeat-like reads, where every reference 9-mer matches many read positions.  k_repeat_score
@@ -589,6 +607,8 @@ struct dsb_ctx {
 	DsbSlotArena arena_big; int n_slots_big = 0;  // second run of reads that outgrew an arena or their loop budget
 	uint32_t *d_score = nullptr, *d_order = nullptr; size_t cap_score = 0, cap_order = 0;
 	DsbSeed *d_seeds = nullptr; DsbSeedInfo *d_sinfo = nullptr; size_t cap_seeds = 0, cap_sinfo = 0;   // seed lists of the batch (k_seed_scan)
+	uint8_t *d_summ = nullptr; int summ_shift = 0;   // summary of exist table 0 in use (the staged index's, or none with synthetic tables)
+	uint8_t *syn0 = nullptr, *syn1 = nullptr; bool seed_only = false;   // dsb_ctx_use_synthetic_filter
 	bool bits_valid = false, seeds_valid = false;   // what the last run left on the device (stage dumps)
 	unsigned n_early = 0;                          // reads of the last run that went through the early launch
 	std::vector<DsbReadOut> h_rout; std::vector<DsbHitOut> h_hout;
@@ -617,7 +637,7 @@ extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 	if (c->stream2) hipStreamSynchronize(c->stream2);
 	for (InSlot &s : c->in) { hipFree(s.d_rd); hipFree(s.d_ascii); hipFree(s.d_scan_order); }
 	hipFree(c->d_wd); hipFree(c->d_bin); hipFree(c->d_pk); hipFree(c->d_bits);
-	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->arena_big.base); hipFree(c->d_score); hipFree(c->d_order); hipFree(c->d_seeds); hipFree(c->d_sinfo);
+	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->arena_big.base); hipFree(c->d_score); hipFree(c->d_order); hipFree(c->d_seeds); hipFree(c->d_sinfo); hipFree(c->syn0); hipFree(c->syn1);
 	if (c->dbg_host) hipHostFree(c->dbg_host);
 	for (int i = 0; i < 4; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	if (c->ev_order) hipEventDestroy(c->ev_order);
@@ -652,7 +672,7 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	CK(hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&c->ev_hprobe, hipEventDisableTiming));
 	if (rc == DSB_OK) rc = stage_acquire(idx, device_id, &c->staged);           // the index goes to HBM once per (index, device)
 	if (rc == DSB_OK) {
-		c->dx = c->staged->dx;
+		c->dx = c->staged->dx; c->d_summ = c->staged->d_summ; c->summ_shift = c->staged->summ_shift;
 		c->dx.filter_min_length = c->opts.L_min_matching; c->dx.filter_min_score = c->opts.min_score; c->dx.filter_min_score_LV3 = c->opts.min_score + 10;
 		if (hipMalloc((void **)&c->d_counters, 256) != hipSuccess) rc = DSB_ENOMEM;
 	}
@@ -672,6 +692,38 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	}
 	if (rc != DSB_OK) { dsb_ctx_destroy(c); return rc; }
 	*out = c;
+	return DSB_OK;
+}
+
+// Measurement hook for the seed-lookup kernels in the HBM regime (SURVEY.md 8d asks for it on multi-GiB tables, which no
+// index in this environment has): the two exist-kmer tables of THIS ctx become synthetic ones of table_bytes each
+// (2^27 .. 2^34, with the mask width and k-mer length set_ekmer_par gives that size, src/idx.c:966-982), every bit set
+// with probability `fill`; dsb_batch_run then stops behind the seed lookup (classifying reads against random seeds
+// would measure nothing).  dsb_synthetic_filter_bit recomputes any bit on the host.
+extern "C" int dsb_synthetic_filter_bit(int which, uint64_t bit, double fill)
+{
+	return dsb_synth_mix(bit, (uint32_t)which) < (uint32_t)(fill * 16777216.0);
+}
+extern "C" int dsb_ctx_use_synthetic_filter(dsb_ctx *c, uint64_t table_bytes, double fill)
+{
+	if (!c || fill <= 0 || fill >= 1) return DSB_EINVAL;
+	int bits, k;
+	switch (table_bytes) {
+	case 1ULL << 27: bits = 30; k = 16; break; case 1ULL << 28: bits = 31; k = 17; break; case 1ULL << 29: bits = 32; k = 17; break;
+	case 1ULL << 30: bits = 33; k = 18; break; case 1ULL << 31: bits = 34; k = 18; break; case 1ULL << 32: bits = 35; k = 19; break;
+	case 1ULL << 33: bits = 36; k = 19; break; case 1ULL << 34: bits = 37; k = 20; break;
+	default: return DSB_EINVAL;
+	}
+	HIPCHK(hipSetDevice(c->device));
+	hipFree(c->syn0); hipFree(c->syn1); c->syn0 = c->syn1 = nullptr;
+	if (hipMalloc((void **)&c->syn0, table_bytes + 256) != hipSuccess || hipMalloc((void **)&c->syn1, table_bytes + 256) != hipSuccess) return DSB_ENOMEM;
+	const uint32_t thresh = (uint32_t)(fill * 16777216.0);
+	hipLaunchKernelGGL(k_synth_table, dim3(256 * 16), dim3(256), 0, c->stream, c->syn0, table_bytes, 0u, thresh);
+	hipLaunchKernelGGL(k_synth_table, dim3(256 * 16), dim3(256), 0, c->stream, c->syn1, table_bytes, 1u, thresh);
+	HIPCHK(hipStreamSynchronize(c->stream));
+	c->dx.ek0 = c->syn0; c->dx.ek1 = c->syn1; c->dx.ek_mask = (1ULL << bits) - 1; c->dx.ek_len = k; c->dx.single_base_max = (int)(0.8 * k);
+	c->d_summ = nullptr; c->summ_shift = 0;             // (tables this full answer nothing from a summary)
+	c->seed_only = true;
 	return DSB_OK;
 }
 
@@ -948,7 +1000,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	DsbDevIndex dx1 = c->dx; dx1.sms_cap = c->arena.sms_cap; dx1.step_limit = step_limit;
 	if (n_heavy) {
 		// their probes first, alone on the device (about a millisecond), then their classify launch on the second stream
-		hipLaunchKernelGGL(k_seed_probe_reads, dim3(n_heavy * DSB_HPROBE_SPLIT), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const uint32_t *)c->d_order, c->d_pk, c->d_bits, c->staged->d_summ, c->staged->summ_shift);
+		hipLaunchKernelGGL(k_seed_probe_reads, dim3(n_heavy * DSB_HPROBE_SPLIT), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const uint32_t *)c->d_order, c->d_pk, c->d_bits, c->d_summ, c->summ_shift);
 		HIPCHK(hipEventRecord(c->ev_hprobe, c->stream));
 		HIPCHK(hipEventRecord(c->ev_order, c->stream));             // order_ms covers scoring, ordering and these probes
 		HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_hprobe, 0));
@@ -957,15 +1009,27 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	}
 	if (use_scan) {
 		hipLaunchKernelGGL(k_seed_scan, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const uint32_t *)(s.ragged ? s.d_scan_order : nullptr),
-		                   (uint32_t)n, (const uint64_t *)c->d_pk, c->d_seeds, c->d_sinfo, (const uint8_t *)c->staged->d_summ, c->staged->summ_shift, (unsigned long long *)(c->d_counters + 40));
+		                   (uint32_t)n, (const uint64_t *)c->d_pk, c->d_seeds, c->d_sinfo, (const uint8_t *)c->d_summ, c->summ_shift, (unsigned long long *)(c->d_counters + 40));
 	} else if (s.n_words_total) {
 		uint64_t waves = (s.n_words_total + DSB_PROBE_UN - 1) / DSB_PROBE_UN; unsigned blocks = (unsigned)((waves + 3) / 4);
 		if (blocks > 256u * 32u) blocks = 256u * 32u;       // >= 8 blocks of 4 waves per CU, grid-stride beyond
 		hipLaunchKernelGGL(k_build_wd, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, c->d_wd);
 		hipLaunchKernelGGL(k_seed_probe, dim3(blocks), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const DsbWordDesc *)c->d_wd, s.n_words_total, c->d_pk, c->d_bits,
-		                   (unsigned long long *)(c->d_counters + 2), c->staged->d_summ, c->staged->summ_shift);
+		                   (unsigned long long *)(c->d_counters + 2), c->d_summ, c->summ_shift);
 	}
 	HIPCHK(hipEventRecord(c->ev[2], c->stream));
+	if (c->seed_only) {
+		// synthetic filter tables (dsb_ctx_use_synthetic_filter): the measurement ends here
+		HIPCHK(hipStreamSynchronize(c->stream));
+		hipEventElapsedTime(&c->timing.encode_ms, c->ev[0], c->ev[1]);
+		hipEventElapsedTime(&c->timing.order_ms, c->ev[1], c->ev_order);
+		hipEventElapsedTime(&c->timing.seed_probe_ms, c->ev_order, c->ev[2]);
+		unsigned long long pc[2] = {0, 0};
+		HIPCHK(hipMemcpy(pc, use_scan ? c->d_counters + 40 : c->d_counters + 2, use_scan ? 16 : 8, hipMemcpyDeviceToHost));
+		c->timing.windows = use_scan ? pc[0] : s.total_windows; c->timing.probes_t1 = use_scan ? pc[1] : pc[0]; c->timing.bases = s.total_bases;
+		c->timing.seed_scan = use_scan ? 1 : 0; c->timing.total_ms = c->timing.encode_ms + c->timing.order_ms + c->timing.seed_probe_ms;
+		return DSB_OK;
+	}
 	if (dbg) { HIPCHK(hipStreamSynchronize(c->stream)); fprintf(stderr, "[dsb] seed probe done\n"); }
 	unsigned slots = (unsigned)c->n_slots; if (slots > n - n_heavy) slots = (unsigned)(n - n_heavy);
 	{
@@ -1112,7 +1176,7 @@ extern "C" int dsb_batch_exist_bits(dsb_ctx *c, size_t read, int strand, uint8_t
 		if (blocks > 256u * 32u) blocks = 256u * 32u;
 		hipLaunchKernelGGL(k_build_wd, dim3((unsigned)sl.n_reads), dim3(256), 0, c->stream, sl.d_rd, c->d_wd);
 		hipLaunchKernelGGL(k_seed_probe, dim3(blocks), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)sl.d_rd, (const DsbWordDesc *)c->d_wd, sl.n_words_total, c->d_pk, c->d_bits,
-		                   (unsigned long long *)nullptr, c->staged->d_summ, c->staged->summ_shift);
+		                   (unsigned long long *)nullptr, c->d_summ, c->summ_shift);
 		HIPCHK(hipStreamSynchronize(c->stream));
 		c->bits_valid = true;
 	}

@@ -120,6 +120,12 @@ void dsb_ctx_reset_history(dsb_ctx *ctx);
 /* set it explicitly: the longest read of the run before the next batch (for callers that deal batches to several
  * contexts and therefore carry the prefix maximum themselves) */
 void dsb_ctx_set_history(dsb_ctx *ctx, uint32_t max_len_before);
+/* measurement hook for the seed-lookup kernels on tables far larger than the caches: the two exist-kmer tables
+ * of this ctx become synthetic ones of table_bytes each (2^27 .. 2^34; k-mer length and mask as set_ekmer_par,
+ * src/idx.c:966-982), each bit set with probability fill; dsb_batch_run then ends behind the seed lookup.  Upload the
+ * batch AFTER this call (the window count of a read depends on k).  dsb_synthetic_filter_bit recomputes a table bit. */
+int  dsb_ctx_use_synthetic_filter(dsb_ctx *ctx, uint64_t table_bytes, double fill);
+int  dsb_synthetic_filter_bit(int which, uint64_t bit, double fill);
 /* input slots (dsb_opts.input_slots > 1): the upload / run / fetch / timing calls below work on the selected slot, so a
  * ctx can keep several batches staged in HBM and run them in any order */
 int  dsb_ctx_select_slot(dsb_ctx *ctx, int slot);

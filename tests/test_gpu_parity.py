@@ -446,3 +446,65 @@ def test_seed_scan_kernel_long_reads_vs_oracle(gpu, demo, oracle, tmp_path, monk
         assert hits[i] == oracle.classify(recs[i][1], 50000), recs[i][0]
     ok = sum(1 for (nm, s, q), h in zip(recs, hits) if h and h[0][0] == int(nm.split(b"_")[1]))
     assert ok >= 0.99 * len(recs)
+
+
+def _hash64_1(key):
+    M = (1 << 64) - 1
+    key = (~key + (key << 21)) & M; key ^= key >> 24; key = (key + (key << 3) + (key << 8)) & M
+    key ^= key >> 14; key = (key + (key << 2) + (key << 4)) & M; key ^= key >> 28; key = (key + (key << 31)) & M
+    return key
+
+
+def _hash64_2(key):
+    M = (1 << 64) - 1
+    key = (key + (~(key << 32) & M)) & M; key ^= key >> 22; key = (key + (~(key << 13) & M)) & M; key ^= key >> 8
+    key = (key + (key << 3)) & M; key ^= key >> 15; key = (key + (~(key << 27) & M)) & M; key ^= key >> 31
+    return key
+
+
+def test_seed_lookup_on_synthetic_multi_gib_tables(demo, tmp_path, monkeypatch):
+    """the measurement hook for the HBM regime of the seed lookup: 2 x 2 GiB synthetic exist-kmer tables
+    (k = 18, 34-bit mask, 20 % of the bits set; dsb_ctx_use_synthetic_filter).  Both seed-lookup kernels must answer what
+    a host recomputation of get_exist_kmer (src/cly.c:956-972: hash64_1 / hash64_2, low-complexity filter of store_kmers)
+    answers on those tables: every window of a sample of reads (all-windows probe), and the seed lists of k_seed_scan equal
+    the scan of those bits"""
+    import subprocess
+    import desamba_amd as D
+    idx = D.Index(demo["index"]); ctx = D.Ctx(idx, 0)
+    try:
+        fill = 0.2; table_bytes = 1 << 31; k = 18; mask = (1 << 34) - 1; sbm = int(0.8 * k)
+        ctx.use_synthetic_filter(table_bytes, fill)
+        fq = tmp_path / "syn.fq"
+        subprocess.check_call([os.path.join(ROOT, "tools", "readsim"), demo["index"], str(fq), "96", "3000", "0.15", "77", "ont"])
+        recs = D.read_fastq(str(fq)) + [(b"polyA", b"A" * 200, None), (b"short", b"ACGT" * 9, None)]
+        reads = D.make_reads(recs)
+        got = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("DSB_SEED_SCAN", mode)
+            ctx.reset_history(); ctx.upload(reads); ctx.run()
+            t = ctx.timing()
+            assert t.seed_scan == int(mode) and t.classify_ms == 0
+            got[mode] = [(ctx.seeds(i, 1), ctx.seeds(i, 0)) for i in range(len(recs))]
+        assert got["0"] == got["1"]
+        assert sum(len(a[0]) + len(b[0]) for a, b in got["1"]) > 1000
+        L = D.lib()
+        code = {65: 0, 97: 0, 71: 2, 103: 2, 84: 3, 116: 3}
+        for i in (0, 17, 96):
+            seq = recs[i][1]; n = len(seq) - k + 1
+            b = [code.get(c, 1) for c in seq]
+            for strand in (1, 0):
+                st = b if strand else [3 - x for x in reversed(b)]
+                exp = bytearray(n)
+                for w in range(n):
+                    km = 0; cnt = [0, 0, 0, 0]
+                    for x in st[w:w + k]:
+                        km = (km << 2) | x; cnt[x] += 1
+                    if km == 0 or max(cnt) >= sbm:
+                        continue
+                    h1 = _hash64_1(km) & mask
+                    if not L.dsb_synthetic_filter_bit(0, h1, fill):
+                        continue
+                    exp[w] = 1 if L.dsb_synthetic_filter_bit(1, _hash64_2(km) & mask, fill) else 0
+                assert ctx.exist_bits(i, strand) == bytes(exp), (i, strand)
+    finally:
+        ctx.close(); idx.close()
