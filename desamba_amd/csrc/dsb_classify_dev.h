@@ -178,6 +178,7 @@ struct WCtx {
 	int lane;
 	uint8_t *bin; uint32_t L;
 	DsbSeed *seeds;
+	const uint64_t *pk[2];     // packed strands (32 bases per word, first base in the top bits): [0] forward, [1] reverse; null: not available
 	DsbSeed *pre_seeds; const DsbSeedInfo *pre_info;   // seed lists made by k_seed_scan (null: scan the hit bits here)
 	DsbAnchor *anc, *anc_tmp; uint32_t n_anc, anc_cap;
 	uint32_t anc_cap_main, hit_cap, step_limit;   // capacities of this launch's arena (anchors, chains) and its loop budget
@@ -1921,6 +1922,139 @@ DV void fill_window(const WCtx &w, uint8_t *win, int n)
 }
 
 // sdp_middle_M2 (src/cly.c:2444-2530)
+// ---- sdp_middle_M2, one gap per lane -----------------------------------------------------------------------------------
+// A chain of a 50-kbp read has ~300 gaps between consecutive anchors, median 75 bases with 4 match nodes; the
+// wave-cooperative form below spends six synchronised phases (window fetch, table build, lookups, scan, node DP) of a few
+// thousand cycles each on one of them at a time.  The gaps of a chain are independent: the running score enters a gap
+// only as the score of its first node, every other node either descends from that node (score = first + delta) or starts
+// afresh with its own length (< 2000, far below the 10000 the running score starts from), so a gap adds
+// max(0, best delta) whatever the score before it.  gap_lane() therefore scores ONE GAP PER LANE, 64 gaps at a time:
+// sdp_match (src/cly.c:2335-2440, forward form) as a bit-parallel search of each probed reference 9-mer in the packed
+// query window (32 query positions per step: nine shifted XORs accumulate the mismatches of all alignments), the two
+// exact-match extensions on packed words (XOR + count leading zeros), the node DP of src/cly.c:2495-2517 over <= 14 nodes.
+// Per lane in LDS (the window table's 12 KB): 12 packed query words and 12 match nodes.  Gaps that do not fit (window
+// > ~220 query positions or > 320 reference bases, > 12 match nodes, windows touching the ends of the read or of the
+// reference text: 10-20 % of the gaps) are left to the cooperative form.
+#define DSB_GL_QW 12
+#define DSB_GL_NODES 12
+#define DSB_GL_MAXT 320
+#define DSB_GL_NONE (-2147483647 - 1)
+#define DSB_GL_K 10000
+struct DsbGap { uint32_t pq, pt, pl, cq, ct, cl; int32_t gain; uint32_t pad; };   // previous / current anchor: index_in_read, ref_offset, mtch_len
+
+#ifdef DSB_HOST_EMU
+typedef uint64_t lds_u64;
+#else
+typedef __attribute__((address_space(3))) uint64_t lds_u64;
+#endif
+DV uint64_t gl_funnel(uint64_t a, uint64_t b, uint32_t s) { return s ? ((a << s) | (b >> (64 - s))) : a; }
+// 29 bases of the 2-bit reference text from base p on, first base in the top bits (the low 6 bits are not to be used)
+DV uint64_t gl_tload(const uint8_t *txt, uint64_t p) { return __builtin_bswap64(dsb_g64u(txt + (p >> 2))) << (((uint32_t)p & 3u) * 2); }
+// 32 bases of the packed query from position p on (staged words start at word w0)
+#define GL_Q32(p_) gl_funnel(lq[(((p_) >> 5) - w0) * DSB_WAVE], lq[(((p_) >> 5) - w0 + 1) * DSB_WAVE], ((p_) & 31u) * 2)
+
+DN int gap_lane(WCtx &w, const DsbGap g, const uint64_t *qpk, uint64_t t_offset)
+{
+	DsbXP x = w.x;
+	const uint32_t L = w.L; const int lane = w.lane;
+	lds_u64 *lq = (lds_u64 *)w.wtab + lane, *ln = (lds_u64 *)w.wtab + DSB_GL_QW * DSB_WAVE + lane;
+	const int pre_mch = (int)g.pl, pre_refoffset = (int)(g.pt - 3);
+	const int total_ref_len = (int)(g.ct - (uint32_t)(pre_refoffset + pre_mch) + 3);
+	if (total_ref_len >= DSB_GL_MAXT) return DSB_GL_NONE;
+	// node 0 = the previous anchor, the last node = this anchor (registers); match nodes in between (LDS)
+	const uint32_t f_q = g.pq, f_t = g.pt, f_l = g.pl - 9 + 1, l_q = g.cq, l_t = g.ct, l_l = g.cl - 9 + 1;
+	uint32_t nn = 0;                                                    // match nodes
+	const uint32_t q_bg = g.pq + (uint32_t)pre_mch - 8, q_ed = g.cq - 1, t_st = (uint32_t)(pre_refoffset + pre_mch);
+	const uint32_t q_base = q_bg - 8, t_base = t_st - 8;
+	if (total_ref_len > 12) {
+		const uint32_t n_q = sdp_nq(L, q_bg, q_ed);
+		const uint64_t ref_offset = (uint64_t)(int64_t)pre_refoffset + t_offset + (uint64_t)(int64_t)pre_mch;
+		const uint32_t t_len = (uint32_t)total_ref_len, t_kmer_num = t_len - 9 + 1;
+		if (n_q > 0 && t_kmer_num > 4) {
+			// the window must lie inside the strand and inside the reference text, and fit the staged words
+			if ((int32_t)q_bg < 8 || q_ed < q_bg || (uint64_t)q_ed + 58 >= L || (int64_t)ref_offset < 0 || ref_offset + t_len + 64 >= x->ref_bases) return DSB_GL_NONE;
+			const uint32_t w0 = (q_bg - 8) >> 5, w1 = ((q_ed + 58) >> 5) + 1;
+			if (w1 - w0 + 1 > DSB_GL_QW) return DSB_GL_NONE;
+			for (uint32_t j = 0; j <= w1 - w0; j++) lq[j * DSB_WAVE] = DSB_G64(qpk, w0 + j);
+			const uint8_t *txt = x->refbin;
+			const uint32_t hi = q_ed < L - 9 ? q_ed : L - 9;                // last query position with a 9-mer inside the window
+			for (uint32_t i = 4; i < t_kmer_num; i += 4) {
+				const uint64_t tw = gl_tload(txt, ref_offset + i);
+				uint64_t rep[9];
+#pragma unroll
+				for (int b = 0; b < 9; b++) rep[b] = ((tw >> (62 - 2 * b)) & 3ULL) * 0x5555555555555555ULL;
+				for (uint32_t j = q_bg >> 5; j <= (hi >> 5); j++) {
+					const uint64_t a = lq[(j - w0) * DSB_WAVE], c = lq[(j - w0 + 1) * DSB_WAVE];
+					uint64_t acc = a ^ rep[0];
+#pragma unroll
+					for (int b = 1; b < 9; b++) acc |= ((a << (2 * b)) | (c >> (64 - 2 * b))) ^ rep[b];
+					uint64_t m = ~(acc | (acc << 1)) & 0xAAAAAAAAAAAAAAAAULL;    // high bit of every pair whose nine bases all agree
+					// positions of this word inside [q_bg, hi]
+					const uint32_t pw = j << 5;
+					if (pw < q_bg) m &= ~0ULL >> (2 * (q_bg - pw));
+					if (pw + 31 > hi) m &= ~0ULL << (2 * (pw + 31 - hi));
+					while (m) {
+						const uint32_t r = (uint32_t)__builtin_clzll(m) >> 1; m &= ~(0x8000000000000000ULL >> (2 * r));
+						const uint32_t q_pos = pw + r;
+						// sdp_emit, forward form (src/cly.c:2390-2414): left-maximal within 4, exact extension to the right
+						const uint64_t qb = GL_Q32(q_pos - 4), tb = gl_tload(txt, ref_offset + i - 4);
+						const uint32_t xb = (uint32_t)((qb ^ tb) >> 56);                 // the four bases in front, the nearest in the low pair
+						const int back_len = (int)((uint32_t)__builtin_ctz(xb | 0x100u) >> 1);
+						if (back_len < 4 || i == 4) {
+							uint32_t max_search = q_ed - q_pos - 1;
+							max_search = MINV(max_search, t_len - i - 1) + 50;
+							// bases of the window beyond t_len never match (oracle U2)
+							const uint32_t t_room = t_len > i + 9 ? t_len - (i + 9) : 0u;
+							const uint32_t lim = max_search < t_room ? max_search : t_room;
+							uint32_t fwd = 0;
+							while (fwd < lim) {
+								const uint64_t xq = GL_Q32(q_pos + 9 + fwd), xt = gl_tload(txt, ref_offset + i + 9 + fwd);
+								const uint64_t d = (xq ^ xt) >> 6;                          // 29 bases
+								if (d) { fwd += ((uint32_t)__builtin_clzll(d) - 6) >> 1; break; }
+								fwd += 29;
+							}
+							if (fwd > lim) fwd = lim;
+							const int total = back_len + (int)fwd + 1;
+							if (total >= 4) {
+								if (nn >= DSB_GL_NODES) return DSB_GL_NONE;
+								const uint32_t nq = q_pos - (uint32_t)back_len - q_base, nt = i - (uint32_t)back_len + t_st - t_base;
+								ln[nn * DSB_WAVE] = (uint64_t)nt | ((uint64_t)nq << 11) | ((uint64_t)(uint32_t)total << 22);
+								nn++;
+							}
+						}
+					}
+				}
+			}
+		}
+	}
+	// node DP (src/cly.c:2495-2517; sdp_best_pred<0>): nodes 0 .. nn + 1
+	int best = DSB_GL_K;
+	for (uint32_t ci = 1; ci <= nn + 1; ci++) {
+		uint32_t c_q, c_t, c_l;
+		if (ci == nn + 1) { c_q = l_q; c_t = l_t; c_l = l_l; }
+		else { const uint64_t v = ln[(ci - 1) * DSB_WAVE]; c_t = (uint32_t)(v & 0x7ffu) + t_base; c_q = (uint32_t)((v >> 11) & 0x7ffu) + q_base; c_l = (uint32_t)((v >> 22) & 0x3ffu); }
+		const uint32_t lim_q = c_q + 6, lim_t = c_t + 6;
+		int cand = (int)c_l;
+		for (uint32_t pi = 0; pi < ci; pi++) {
+			uint32_t p_q, p_t, p_l; int p_s;
+			if (pi == 0) { p_q = f_q; p_t = f_t; p_l = f_l; p_s = DSB_GL_K; }
+			else { const uint64_t v = ln[(pi - 1) * DSB_WAVE]; p_t = (uint32_t)(v & 0x7ffu) + t_base; p_q = (uint32_t)((v >> 11) & 0x7ffu) + q_base; p_l = (uint32_t)((v >> 22) & 0x3ffu); p_s = (int)(uint32_t)(v >> 32); }
+			const int pre_q_ed = (int)(p_q + p_l + 9 - 1), pre_t_ed = (int)(p_t + p_l + 9 - 1);
+			if ((uint32_t)pre_q_ed > lim_q || (uint32_t)pre_t_ed > lim_t) continue;
+			const int indel = (int)(p_q - p_t - (lim_q - lim_t)); const int ai = ABSV(indel);
+			if (ai > 200) continue;
+			int ns = p_s + (int)c_l - (ai >> 3);
+			if ((uint32_t)pre_q_ed > c_q || (uint32_t)pre_t_ed > c_t) { const int oq = pre_q_ed - (int)c_q, ot = pre_t_ed - (int)c_t; ns -= MAXV(oq, ot); }
+			cand = MAXV(cand, ns);
+		}
+		if (ci <= nn) ln[(ci - 1) * DSB_WAVE] = (ln[(ci - 1) * DSB_WAVE] & 0xffffffffULL) | ((uint64_t)(uint32_t)cand << 32);
+		best = MAXV(best, cand);
+	}
+	if (total_ref_len > 12) cnt_add(Cnt{w.k.c, 0u}, 3, (uint32_t)total_ref_len);   // the window get_ref would have fetched (work counter)
+	return best - DSB_GL_K;
+}
+#undef GL_Q32
+
 DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int key_len)
 {
 	DsbXP x = w.x;
@@ -1928,27 +2062,43 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 	// the context lives in memory: work on copies (see sdp_match_t)
 	const DsbAnchor *A = w.anc; DsbSms *const S = w.sms; uint32_t *const wtab = w.wtab; uint8_t *const win = w.win_mid;
 	const int lane = w.lane; const uint32_t L = w.L;
-	DsbAnchor ca = A[c_a];
-	const uint64_t t_offset = x->refinfo[ca.ref_ID].seq_offset;
-	// the chain is a linked list: the anchor after next is loaded one gap ahead, off the critical path
-	DsbAnchor pa = A[ca.pre != -1 ? ca.pre : c_a];
-	DsbAnchor nxt = A[(ca.pre != -1 && pa.pre != -1) ? pa.pre : c_a];
-	// The window of the NEXT gap (read stretch and packed reference words, the first 8 * 64 bytes / bases of each, which is
-	// all of a usual gap) is requested while this gap is worked on: pf_* hold what was asked for during the previous gap.
+	DsbGap *const G = reinterpret_cast<DsbGap *>(w.anc_tmp);            // the unsorted anchor copy is idle from the chaining on
+	const uint64_t t_offset = x->refinfo[A[c_a].ref_ID].seq_offset;
+	// 1. the gaps of the chain (a linked list through Anchor.pre), from its last anchor backwards
+	uint32_t n_gap = 0; int tail_len = 0;
+	DSB_SERIAL(w) {
+		DsbAnchor ca = A[c_a];
+		while (ca.pre != -1) {
+			const DsbAnchor pa = A[ca.pre];
+			DsbGap g; g.pq = pa.index_in_read; g.pt = pa.ref_offset; g.pl = pa.mtch_len; g.cq = ca.index_in_read; g.ct = ca.ref_offset; g.cl = ca.mtch_len; g.gain = DSB_GL_NONE; g.pad = 0;
+			G[n_gap++] = g;
+			ca = pa;
+		}
+		tail_len = (int)ca.mtch_len - 9 + 1;
+	}
+	n_gap = dsb_shfl(n_gap, 0); tail_len = dsb_shfl(tail_len, 0);
+	wave_sync();
+	// 2. one gap per lane (gap_lane): most gaps are scored here, 64 at a time
+	if (w.pk[tbl] && wtab) {
+		for (uint32_t gi = (uint32_t)lane; gi < n_gap; gi += DSB_WAVE) G[gi].gain = gap_lane(w, G[gi], w.pk[tbl], t_offset);
+		wave_sync();
+	}
+	// 3. what is left, one gap at a time on the whole wavefront
 	uint64_t pf_q = 0; uint32_t pf_t = 0; int32_t pf_qlo = 0; uint64_t pf_toff = ~0ULL; bool pf_has_q = false, pf_has_t = false;
-	for (;;) {
-		const int32_t pre_a = ca.pre;
-		if (pre_a == -1) { score += ca.mtch_len - 9 + 1; break; }
-		// (the anchor after next is loaded one gap ahead as well: the addresses of the next window come from `nxt`)
-		const DsbAnchor nx2 = A[(pa.pre != -1 && nxt.pre != -1) ? nxt.pre : c_a];
+	for (uint32_t gi = 0; gi < n_gap; gi++) {
+		const DsbGap g = G[gi];
+		if (g.gain != DSB_GL_NONE) { score += g.gain; continue; }
+		// The window of the NEXT gap (read stretch and packed reference words, the first 8 * 64 bytes / bases of each, which is
+		// all of a usual gap) is requested while this gap is worked on: pf_* hold what was asked for during the previous gap.
 		const uint64_t cur_q = pf_q; const uint32_t cur_t = pf_t; const int32_t cur_qlo = pf_qlo; const uint64_t cur_toff = pf_toff; const bool cur_has_q = pf_has_q, cur_has_t = pf_has_t;
 		pf_has_q = pf_has_t = false;
 #ifndef DSB_HOST_EMU
-		if (pa.pre != -1) {
-			const int n_mch = nxt.mtch_len, n_tlen = (int)(pa.ref_offset - ((nxt.ref_offset - 3) + n_mch) + 3);
-			if (n_tlen > 12 && n_tlen < 2000) {
-				const uint64_t n_toff = (uint64_t)(int64_t)(int)(nxt.ref_offset - 3) + t_offset + (uint64_t)(int64_t)n_mch;
-				const int32_t n_qlo = (int32_t)(nxt.index_in_read + n_mch - 8) - 16, n_qhi = (int32_t)(pa.index_in_read - 1) + 80;
+		if (gi + 1 < n_gap) {
+			const DsbGap n = G[gi + 1];
+			const int n_mch = (int)n.pl, n_tlen = (int)(n.ct - ((n.pt - 3) + (uint32_t)n_mch) + 3);
+			if (n.gain == DSB_GL_NONE && n_tlen > 12 && n_tlen < 2000) {
+				const uint64_t n_toff = (uint64_t)(int64_t)(int)(n.pt - 3) + t_offset + (uint64_t)(int64_t)n_mch;
+				const int32_t n_qlo = (int32_t)(n.pq + (uint32_t)n_mch - 8) - 16, n_qhi = (int32_t)(n.cq - 1) + 80;
 				if ((int64_t)n_toff >= 0 && n_toff < x->ref_bases && 8 * lane < n_tlen) pf_t = dsb_g32u(x->refbin + ((n_toff + (uint32_t)(8 * lane)) >> 2));
 				pf_toff = n_toff; pf_has_t = (int64_t)n_toff >= 0 && n_toff < x->ref_bases;
 				if (n_qhi > n_qlo && n_qlo >= -(int32_t)DSB_QPAD_L + 8) {
@@ -1958,19 +2108,19 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 			}
 		}
 #endif
-		const int pre_mch = pa.mtch_len;
-		const int pre_refoffset = pa.ref_offset - 3;
-		const int total_ref_len = ca.ref_offset - (pre_refoffset + pre_mch) + 3;
+		const int pre_mch = (int)g.pl;
+		const int pre_refoffset = g.pt - 3;
+		const int total_ref_len = g.ct - (pre_refoffset + pre_mch) + 3;
 		// node 0 = the previous anchor, the last node = this anchor; both stay in registers unless the list
 		// has to go through the general path
-		DsbSms first; first.score = score; first.q_pos = pa.index_in_read; first.t_pos = pa.ref_offset; first.len = pa.mtch_len - 9 + 1;
-		DsbSms last; last.score = 0; last.q_pos = ca.index_in_read; last.t_pos = ca.ref_offset; last.len = ca.mtch_len - 9 + 1;
+		DsbSms first; first.score = score; first.q_pos = g.pq; first.t_pos = g.pt; first.len = (int)g.pl - 9 + 1;
+		DsbSms last; last.score = 0; last.q_pos = g.cq; last.t_pos = g.ct; last.len = g.cl - 9 + 1;
 		uint32_t n_sms = 1; uint4 *lnodes = nullptr; bool mirror = false;
 		if (total_ref_len > 12) {
 			uint8_t *ref = win;
 			if (total_ref_len >= 2000) { w.status |= DSB_ST_TIMEOUT; w.n_sms = 0; return 0; }   // the reference aborts here (xassert, src/cly.c:2473)
 			uint64_t ref_offset = pre_refoffset + t_offset + pre_mch;
-			const uint32_t q_bg = pa.index_in_read + pre_mch - 8, q_ed = ca.index_in_read - 1;
+			const uint32_t q_bg = g.pq + pre_mch - 8, q_ed = g.cq - 1;
 			const uint8_t *qs = q_str; const uint8_t *lq_st = nullptr;
 			// Small gap (the usual case): the reference window and the stretch of the read the match can touch live
 			// in LDS behind the window's hash table, so the k-mer builds and exact-match extensions of sdp_match
@@ -2039,8 +2189,8 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 				}
 			}
 		}
-		ca = pa; pa = nxt; nxt = nx2;
 	}
+	score += tail_len;
 	w.n_sms = 0;
 	return score - 10000;
 }
