@@ -1982,12 +1982,15 @@ DN int gap_lane(WCtx &w, const DsbGap g, const uint64_t *qpk, uint64_t t_offset)
 				const uint64_t tw = gl_tload(txt, ref_offset + i);
 				uint64_t rep[9];
 #pragma unroll
-				for (int b = 0; b < 9; b++) rep[b] = ((tw >> (62 - 2 * b)) & 3ULL) * 0x5555555555555555ULL;
+				for (int b = 0; b < 9; b++) { const uint32_t v = (uint32_t)(tw >> (62 - 2 * b)); rep[b] = ((v & 1u) ? 0x5555555555555555ULL : 0ULL) | ((v & 2u) ? 0xAAAAAAAAAAAAAAAAULL : 0ULL); }
 				for (uint32_t j = q_bg >> 5; j <= (hi >> 5); j++) {
 					const uint64_t a = lq[(j - w0) * DSB_WAVE], c = lq[(j - w0 + 1) * DSB_WAVE];
 					uint64_t acc = a ^ rep[0];
 #pragma unroll
-					for (int b = 1; b < 9; b++) acc |= ((a << (2 * b)) | (c >> (64 - 2 * b))) ^ rep[b];
+					for (int b = 1; b < 5; b++) acc |= ((a << (2 * b)) | (c >> (64 - 2 * b))) ^ rep[b];
+					if ((~(acc | (acc << 1)) & 0xAAAAAAAAAAAAAAAAULL) == 0) continue;          // no alignment of this word agrees in the first five bases (31 of 32 words)
+#pragma unroll
+					for (int b = 5; b < 9; b++) acc |= ((a << (2 * b)) | (c >> (64 - 2 * b))) ^ rep[b];
 					uint64_t m = ~(acc | (acc << 1)) & 0xAAAAAAAAAAAAAAAAULL;    // high bit of every pair whose nine bases all agree
 					// positions of this word inside [q_bg, hi]
 					const uint32_t pw = j << 5;
@@ -2078,9 +2081,40 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 	}
 	n_gap = dsb_shfl(n_gap, 0); tail_len = dsb_shfl(tail_len, 0);
 	wave_sync();
-	// 2. one gap per lane (gap_lane): most gaps are scored here, 64 at a time
+	// 2. one gap per lane (gap_lane): most gaps are scored here, 64 at a time.  The lanes of a wavefront finish together, so
+	// gaps of similar cost (probed reference positions x query words) share a round: counting sort by log2 of the cost,
+	// heaviest first (the order changes no result: every gap's gain is its own).
 	if (w.pk[tbl] && wtab) {
-		for (uint32_t gi = (uint32_t)lane; gi < n_gap; gi += DSB_WAVE) G[gi].gain = gap_lane(w, G[gi], w.pk[tbl], t_offset);
+		uint32_t *const perm = w.sortidx;
+		lds_u32 *hist = (lds_u32 *)w.ring;                                  // 32 words: counts, then start offsets (the DP ring is idle here)
+		for (int i = lane; i < 32; i += DSB_WAVE) hist[i] = 0;
+		wave_sync();
+		for (uint32_t gi = (uint32_t)lane; gi < n_gap; gi += DSB_WAVE) {
+			const DsbGap g = G[gi];
+			const int tl = (int)(g.ct - ((g.pt - 3) + g.pl) + 3);
+			uint32_t cost = 0;
+			if (tl > 12) { const uint32_t nq = g.cq - (g.pq + g.pl - 8); cost = ((uint32_t)tl >> 2) * ((nq >> 5) + 1); }
+			const uint32_t bk = cost ? 32u - (uint32_t)__builtin_clz(cost) : 0u;   // 0 .. 15 for the gaps the lane form takes
+			G[gi].pad = bk > 15 ? 15u : bk;
+#ifdef DSB_HOST_EMU
+			hist[G[gi].pad]++;
+#else
+			__hip_atomic_fetch_add(hist + (bk > 15 ? 15u : bk), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+		}
+		wave_sync();
+		if (lane == 0) { uint32_t acc = 0; for (int b = 15; b >= 0; b--) { hist[16 + b] = acc; acc += hist[b]; } }
+		wave_sync();
+		for (uint32_t gi = (uint32_t)lane; gi < n_gap; gi += DSB_WAVE) {
+#ifdef DSB_HOST_EMU
+			const uint32_t pos = hist[16 + G[gi].pad]++;
+#else
+			const uint32_t pos = __hip_atomic_fetch_add(hist + 16 + G[gi].pad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+			perm[pos] = gi;
+		}
+		wave_sync();
+		for (uint32_t k = (uint32_t)lane; k < n_gap; k += DSB_WAVE) { const uint32_t gi = perm[k]; G[gi].gain = gap_lane(w, G[gi], w.pk[tbl], t_offset); }
 		wave_sync();
 	}
 	// 3. what is left, one gap at a time on the whole wavefront
