@@ -171,6 +171,20 @@ typedef const DsbDevIndex *DsbXP;
 typedef const __attribute__((address_space(3))) DsbDevIndex *DsbXP;
 #endif
 
+// Several wavefronts on one read (k_classify_heavy): wave 0 runs the read, the other waves of its workgroup sleep at a
+// barrier and are woken for the old-predecessor pass of the batched sparse DP (sdp_batch_old_mw), the one piece of a
+// tandem-repeat read that costs tens of milliseconds.  One of these per workgroup, in LDS.
+#define DSB_MW_MAXW 8
+#define DSB_MW_MIN_PREDS 2048      /* shorter predecessor lists stay on wave 0 alone */
+struct DsbMw {
+	uint32_t cmd;                  // 1 / 2: DP pass of a right / left extension batch; 3: the read is done
+	uint32_t n0, K;
+	const DsbSms *sms;
+	uint32_t nd_t[8], nd_q[8], nd_l[8];
+	uint32_t cut[2][DSB_MW_MAXW];  // per round parity and wave: bit j = that wave's chunk holds the distance cut of node j
+	int32_t best[DSB_MW_MAXW][8];
+};
+
 struct SDir { DsbSeed *seed_v; uint32_t l_seed_v; uint8_t *bin_read; const uint64_t *bits; uint32_t direction, total_score; };
 
 struct WCtx {
@@ -178,6 +192,7 @@ struct WCtx {
 	int lane;
 	uint8_t *bin; uint32_t L;
 	DsbSeed *seeds;
+	DsbMw *mw; int n_waves;    // k_classify_heavy: the workgroup's shared block and its number of wavefronts (null / 1 otherwise)
 	const uint64_t *pk[2];     // packed strands (32 bases per word, first base in the top bits): [0] forward, [1] reverse; null: not available
 	DsbSeed *pre_seeds; const DsbSeedInfo *pre_info;   // seed lists made by k_seed_scan (null: scan the hit bits here)
 	DsbAnchor *anc, *anc_tmp; uint32_t n_anc, anc_cap;
@@ -894,6 +909,7 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 	// Phase 2: commit in island order, 64 islands at a time.  A seed is skipped iff it directly follows (index + 1)
 	// a committed seed whose island raised the skip flag (src/cly.c:1530-1531) -- a bit recurrence over the
 	// islands -- and every lane then copies one island's anchors to their place in the list.
+	SUB0(w);
 	uint32_t skip_seed = 0xffffffffu;
 	for (uint32_t base = 0; base < n_top; base += DSB_WAVE) {
 		const uint32_t t = base + lane; const bool valid = t < n_top;
@@ -942,6 +958,7 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 		}
 		wave_sync();
 	}
+	SUB1(w, 13);
 }
 
 // stable sort of the slow-path MEMs by match_len, descending (qsort at src/cly.c:1595 with a
@@ -1893,6 +1910,131 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 	for (int j = 0; j < DSB_DPB; j++) b.old_best[j] = ((uint32_t)j < b.K) ? grp_max_i(w.red, w.lane, best[j]) : 0;
 }
 
+#ifndef DSB_HOST_EMU
+// The old-predecessor pass of sdp_batch_old on W wavefronts.  Round r: wave v takes the chunk of 4 x 64 predecessors
+// number r * W + v (newest first).  Every wave works out, for each node of the batch, the best score among the predecessors
+// of its chunk that the reference's newest-first scan would reach if it entered the chunk, and whether the scan stops inside
+// the chunk (distance cut); the cut flags of a round are exchanged through LDS: a chunk counts if no newer chunk of the round
+// holds the cut of that node, and the node is finished once any chunk does.  Same maxima as the serial scan.
+template <int MODE>
+DN void sdp_batch_old_mw(DsbMw *mw, uint4 *ring, uint32_t *red, const int lane, const int wv, const int W, uint32_t *preds_out)
+{
+	uint32_t lq[DSB_DPB], lt[DSB_DPB], dl[DSB_DPB], nq[DSB_DPB], nt[DSB_DPB], nl[DSB_DPB]; int best[DSB_DPB];
+	uint32_t stopm = 0, wnm = 0, preds = 0;
+	const uint32_t K = mw->K; const DsbSms *const sms = mw->sms;
+#pragma unroll
+	for (int j = 0; j < DSB_DPB; j++) {
+		DsbSms nd; nd.t_pos = mw->nd_t[j]; nd.q_pos = mw->nd_q[j]; nd.len = mw->nd_l[j]; nd.score = 0;
+		uint32_t q_, t_; sdp_limits<MODE>(nd, q_, t_);
+		lq[j] = DSB_RFL(q_); lt[j] = DSB_RFL(t_);
+		dl[j] = lq[j] - lt[j]; nl[j] = DSB_RFL(nd.len);
+		if (MODE == 2) { nq[j] = lq[j] + 6; nt[j] = lt[j] + 6; } else { nq[j] = DSB_RFL(nd.q_pos); nt[j] = DSB_RFL(nd.t_pos); }
+		best[j] = -2147483647 - 1;
+		if ((uint32_t)j >= K) stopm |= 1u << j;
+		if ((int)(lq[j] | lt[j] | nq[j] | nt[j] | (lt[j] + 600)) < 0) wnm |= 1u << j;
+	}
+	stopm = DSB_RFL(stopm); wnm = DSB_RFL(wnm);
+	const int32_t n0 = (int32_t)mw->n0;
+	const int32_t step = DSB_DP_UNROLL * DSB_WAVE;
+	DsbSms nx[DSB_DP_UNROLL];
+#define DSB_FETCH_PREDS_MW(dst, hi_)                                                                            \
+	_Pragma("unroll") for (int u = 0; u < DSB_DP_UNROLL; u++) {                                                 \
+		int32_t pi = (hi_) - u * DSB_WAVE - lane;                                                                \
+		if (pi < 0) { dst[u].t_pos = 0; dst[u].q_pos = (MODE == 2) ? 0u : 0xfffffff0u; dst[u].len = 0; dst[u].score = 0; } \
+		else if (pi > n0 - DSB_RING) { uint4 r = ring_ld(ring, pi & (DSB_RING - 1)); dst[u].t_pos = r.x; dst[u].q_pos = r.y; dst[u].len = r.z; dst[u].score = r.w; } \
+		else dst[u] = sms[pi];                                                                                   \
+	}
+	int32_t hi = n0 - 1 - wv * step;
+	if (hi >= 0) { DSB_FETCH_PREDS_MW(nx, hi) }
+	for (uint32_t round = 0;; round++, hi -= W * step) {
+		int v[DSB_DPB]; uint32_t cutm = 0;
+#pragma unroll
+		for (int j = 0; j < DSB_DPB; j++) v[j] = -2147483647 - 1;
+		if (hi >= 0) {
+			uint32_t A[DSB_DP_UNROLL], B[DSB_DP_UNROLL], C[DSB_DP_UNROLL], D[DSB_DP_UNROLL], S[DSB_DP_UNROLL]; bool wrapped[DSB_DP_UNROLL];
+#pragma unroll
+			for (int u = 0; u < DSB_DP_UNROLL; u++) {
+				int32_t pi = hi - u * DSB_WAVE - lane;
+				DsbSms ps = nx[u];
+				if (MODE == 2) { A[u] = ps.q_pos; B[u] = ps.t_pos; C[u] = ps.t_pos; }
+				else { A[u] = ps.q_pos + ps.len + 8; B[u] = ps.t_pos + ps.len + 8; C[u] = ps.t_pos + 600; }
+				D[u] = ps.q_pos - ps.t_pos; S[u] = ps.score;
+				if (pi < 0 && MODE != 2) A[u] = 0x7fffffffu;
+				wrapped[u] = dsb_ballot64((int)(A[u] | B[u] | C[u]) < 0) != 0;
+			}
+			if (hi - W * step >= 0) { DSB_FETCH_PREDS_MW(nx, hi - W * step) }
+			const bool plain = wnm == 0 && !(wrapped[0] | wrapped[1] | wrapped[2] | wrapped[3]);
+			uint32_t redo = ~stopm & ((1u << DSB_DPB) - 1u);
+			if (plain) {
+#pragma unroll
+				for (int j = 0; j < DSB_DPB; j++) {
+					if ((stopm >> j) & 1u) continue;
+					int tb = -2147483647 - 1; bool anyb = false;
+#pragma unroll
+					for (int u = 0; u < DSB_DP_UNROLL; u++) {
+						const int oq = (MODE == 2) ? (int)(nq[j] - A[u]) : (int)(A[u] - nq[j]);
+						const int ot = (MODE == 2) ? (int)(nt[j] - B[u]) : (int)(B[u] - nt[j]);
+						const int indel = (int)(D[u] - dl[j]); const int ai = ABSV(indel);
+						int ovl = MAXV(oq, ot); ovl = MAXV(ovl, 0);
+						const bool skip = ovl > 6;
+						const bool brk = !skip & ((MODE == 2) ? (lt[j] + 600 < C[u]) : (C[u] < lt[j]));
+						const int ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3)) - ovl;
+						anyb |= brk;
+						if (!skip & !brk & (ai <= 200) & (ns > tb)) tb = ns;
+					}
+					if (dsb_ballot64(anyb) == 0) { v[j] = tb; redo &= ~(1u << j); }
+				}
+			}
+			preds += DSB_DP_UNROLL * DSB_WAVE * (uint32_t)__builtin_popcount(~stopm & ((1u << DSB_DPB) - 1u));
+			if (redo)
+#pragma unroll
+			for (int j = 0; j < DSB_DPB; j++) {
+				if (!((redo >> j) & 1u)) continue;
+#pragma unroll
+				for (int u = 0; u < DSB_DP_UNROLL; u++) {
+					if ((cutm >> j) & 1u) break;
+					const int oq = (MODE == 2) ? (int)(nq[j] - A[u]) : (int)(A[u] - nq[j]);
+					const int ot = (MODE == 2) ? (int)(nt[j] - B[u]) : (int)(B[u] - nt[j]);
+					const int indel = (int)(D[u] - dl[j]); const int ai = ABSV(indel);
+					bool skip, brk; int ns;
+					if (wrapped[u] || ((wnm >> j) & 1u)) {
+						bool ov;
+						if (MODE == 2) { skip = (A[u] < lq[j]) | (B[u] < lt[j]); brk = !skip & (lt[j] + 600 < C[u]); ov = (nq[j] > A[u]) | (nt[j] > B[u]); }
+						else { skip = (A[u] > lq[j]) | (B[u] > lt[j]); brk = !skip & (C[u] < lt[j]); ov = (A[u] > nq[j]) | (B[u] > nt[j]); }
+						ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3));
+						if (ov) ns -= MAXV(oq, ot);
+					} else {
+						int ovl = MAXV(oq, ot); ovl = MAXV(ovl, 0);
+						skip = ovl > 6;
+						brk = !skip & ((MODE == 2) ? (lt[j] + 600 < C[u]) : (C[u] < lt[j]));
+						ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3)) - ovl;
+					}
+					bool ok = !skip & !brk & (ai <= 200);
+					if (dsb_ballot64(brk)) { const int first_brk = grp_first(red, lane, brk); ok = ok & (lane < first_brk); cutm |= 1u << j; }
+					if (ok && ns > v[j]) v[j] = ns;
+				}
+			}
+		}
+		// exchange the cut flags of this round
+		const uint32_t par = round & 1u;
+		if (lane == 0) mw->cut[par][wv] = cutm;
+		__syncthreads();
+		uint32_t newer = 0, all = 0;
+		for (int u = 0; u < W; u++) { const uint32_t c = mw->cut[par][u]; if (u < wv) newer |= c; all |= c; }
+#pragma unroll
+		for (int j = 0; j < DSB_DPB; j++) if (!(((stopm | newer) >> j) & 1u) && v[j] > best[j]) best[j] = v[j];
+		stopm |= all;
+		if (stopm == (1u << DSB_DPB) - 1u) break;
+		if (n0 - 1 - (int32_t)(round + 1) * W * step < 0) break;           // no chunk left for any wave
+	}
+#undef DSB_FETCH_PREDS_MW
+#pragma unroll
+	for (int j = 0; j < DSB_DPB; j++) { const int m = grp_max_i(red, lane, best[j]); if (lane == 0) mw->best[wv][j] = m; }
+	__syncthreads();
+	if (preds_out) *preds_out = preds;
+}
+
+#endif
 // best predecessor score of node `cur` (right/left extension), through the batch
 template <int MODE>
 DV int sdp_best_pred_b(WCtx &w, DpBatch &b, const DsbSms &cs, int32_t cur)
@@ -1900,6 +2042,19 @@ DV int sdp_best_pred_b(WCtx &w, DpBatch &b, const DsbSms &cs, int32_t cur)
 	if ((uint32_t)cur < b.n0 || (uint32_t)cur >= b.n0 + b.K) {
 		b.n0 = (uint32_t)cur; b.K = MINV((uint32_t)DSB_DPB, w.n_sms - (uint32_t)cur);
 		for (uint32_t j = 0; j < b.K; j++) { b.nd[j] = w.sms[cur + j]; b.nd[j].score = 0; }
+#ifndef DSB_HOST_EMU
+		if (w.mw && b.n0 >= DSB_MW_MIN_PREDS) {
+			// several wavefronts on this read: wake the helpers for the pass over the old predecessors
+			DsbMw *mw = w.mw;
+			if (w.lane < DSB_DPB) { const DsbSms nd = (uint32_t)w.lane < b.K ? b.nd[w.lane] : b.nd[0]; mw->nd_t[w.lane] = nd.t_pos; mw->nd_q[w.lane] = nd.q_pos; mw->nd_l[w.lane] = nd.len; }
+			if (w.lane == 0) { mw->cmd = (uint32_t)MODE; mw->n0 = b.n0; mw->K = b.K; mw->sms = w.sms; }
+			__syncthreads();
+			uint32_t preds = 0;
+			sdp_batch_old_mw<MODE>(mw, w.ring, w.red, w.lane, 0, w.n_waves, &preds);
+			w.dp_preds += preds;
+			for (uint32_t j = 0; j < DSB_DPB; j++) { int m = -2147483647 - 1; for (int u = 0; u < w.n_waves; u++) m = MAXV(m, mw->best[u][j]); b.old_best[j] = j < b.K ? m : 0; }
+		} else
+#endif
 		sdp_batch_old<MODE>(w, b);
 	}
 	int best = (int)cs.len; bool cut = false;

@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	w.win_mid = slot + ar.off_win; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;         \
 	w.lane_anc = (DsbAnchor *)(slot + ar.off_lane_anc); w.lane_spset = (uint64_t *)(slot + ar.off_lane_sp);             \
 	w.top_idx = (uint32_t *)(slot + ar.off_top); w.round_info = (uint32_t *)(slot + ar.off_round);                      \
-	w.anc_cap = ar.anc_cap; w.anc_cap_main = ar.anc_cap; w.hit_cap = ar.hit_cap; w.step_limit = x.step_limit; w.sp_gen = 0;                                                                            \
+	w.anc_cap = ar.anc_cap; w.anc_cap_main = ar.anc_cap; w.hit_cap = ar.hit_cap; w.step_limit = x.step_limit; w.sp_gen = 0; w.mw = nullptr; w.n_waves = 1;                                                                            \
 	/* visited-row sets are generation-tagged: clear them once per launch */                                          \
 	for (uint32_t i = lane; i < (uint32_t)THREADS * DSB_SPHASH; i += THREADS) w.lane_spset[i] = 0;                       \
 	for (uint32_t i = lane; i < DSB_SPHASH; i += THREADS) w.spset[i] = 0;                                                \
@@ -476,6 +476,96 @@ DSB_DEFINE_CLASSIFY(k_classify, dsb_g64, 64)
 DSB_DEFINE_CLASSIFY(k_classify_early, dsb_g64, 64)
 // ... and a third one for the second run of reads whose match-node arena overflowed (usually an empty launch)
 DSB_DEFINE_CLASSIFY(k_classify_second, dsb_g64, 64)
+
+
+// Several wavefronts per read, for the handful of reads whose sparse DP is the batch's tail (tandem repeats: tens of
+// thousands of match nodes, a quadratic predecessor scan).  A workgroup of DSB_MW_WAVES wavefronts takes one read: wave 0
+// runs classify_read as everywhere else, the other waves sleep at the workgroup barrier and are woken for the pass over
+// the old predecessors of a batch of DP nodes (sdp_batch_old_mw), which they split chunk by chunk.  Work items as in
+// k_classify (atomic counter over the LPT order); every wave reaches every barrier, so the grid drains.
+#define DSB_MW_WAVES 4
+__global__ void __launch_bounds__(64 * DSB_MW_WAVES, DSB_WAVES_PER_EU) k_classify_heavy(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed,
+        const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout,
+        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t slot_base, unsigned long long *work_cnt, const uint64_t *pk)
+{
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const uint32_t slot_id = slot_base + blockIdx.x;
+	uint8_t *slot = ar.base + (size_t)slot_id * ar.stride;
+	__shared__ DsbDevIndex sx;
+	__shared__ uint4 lds_ring[DSB_RING];
+	__shared__ __attribute__((aligned(16))) uint32_t lds_wtab[DSB_WTAB_SLOTS];
+	__shared__ uint32_t lds_red[DSB_MW_WAVES + 1];
+	__shared__ unsigned int s_word;
+	__shared__ uint32_t lds_cnt[4];
+	__shared__ dsb_g64::DsbMw mw;
+	if (threadIdx.x < 4) lds_cnt[threadIdx.x] = 0;
+	if (threadIdx.x == 0) { sx = x; mw.cmd = 0; }
+	__syncthreads();
+	dsb_g64::WCtx w;
+	if (wv == 0) {
+		w.ring = lds_ring; w.red = lds_red; w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1;
+		w.x = (dsb_g64::DsbXP)&sx; w.lane = lane; w.dbg = nullptr;
+		for (int i = 0; i < 14; i++) w.tacc[i] = 0;
+		w.seeds = (DsbSeed *)(slot + ar.off_seeds);
+		w.anc = (DsbAnchor *)(slot + ar.off_anc); w.anc_tmp = (DsbAnchor *)(slot + ar.off_anc_tmp);
+		w.hit = (DsbChain *)(slot + ar.off_hit); w.hit_tmp = (DsbChain *)(slot + ar.off_hit_tmp);
+		w.sms = (DsbSms *)(slot + ar.off_sms);
+		w.sc = (DsbScHash *)(slot + ar.off_sc); w.wtab = lds_wtab;
+		w.mem_slow = (DsbMem *)(slot + ar.off_mem);
+		w.spset = (uint64_t *)(slot + ar.off_spset);
+		w.score_v = (int *)(slot + ar.off_scorev);
+		w.sortkey = (uint64_t *)(slot + ar.off_sortkey); w.sortidx = (uint32_t *)(slot + ar.off_sortidx);
+		w.win_mid = slot + ar.off_win; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
+		w.lane_anc = (DsbAnchor *)(slot + ar.off_lane_anc); w.lane_spset = (uint64_t *)(slot + ar.off_lane_sp);
+		w.top_idx = (uint32_t *)(slot + ar.off_top); w.round_info = (uint32_t *)(slot + ar.off_round);
+		w.anc_cap = ar.anc_cap; w.anc_cap_main = ar.anc_cap; w.hit_cap = ar.hit_cap; w.step_limit = x.step_limit; w.sp_gen = 0;
+		w.mw = &mw; w.n_waves = DSB_MW_WAVES;
+		for (uint32_t i = lane; i < 64u * DSB_SPHASH; i += 64) w.lane_spset[i] = 0;
+		for (uint32_t i = lane; i < DSB_SPHASH; i += 64) w.spset[i] = 0;
+	}
+	__syncthreads();
+	for (;;) {
+		if (threadIdx.x == 0) s_word = atomicAdd(work_counter, 1u);
+		__syncthreads();
+		const unsigned int k = s_word;
+		__syncthreads();
+		if (k >= n_fixed) {
+			if (threadIdx.x < 4 && lds_cnt[threadIdx.x]) atomicAdd(work_cnt + threadIdx.x, (unsigned long long)lds_cnt[threadIdx.x]);
+			break;
+		}
+		const unsigned int r = list ? list[k] : k;
+		if (wv == 0) {
+			DsbReadDesc d = rd[r];
+			const uint64_t t_start = wall_clock64();
+			w.bin = bin + d.bin_off + DSB_QPAD_L; w.L = d.len; w.status = 0; w.max_read_l = d.hist_max;
+			w.pre_seeds = nullptr; w.pre_info = nullptr;
+			w.pk[0] = pk + d.pk_off; w.pk[1] = w.pk[0] + ((d.len + 31) / 32 + 1);
+			const uint32_t fast = dsb_g64::classify_read(w, bits + d.bit_off, bits + d.bit_off + d.n_words);
+			if (w.boosted) __builtin_amdgcn_s_setprio(0);
+			if (lane == 0) { mw.cmd = 3; s_word = w.n_hit ? atomicAdd(hout_counter, w.n_hit) : 0u; }
+			__syncthreads();                                                // releases the helper waves from this read
+			const unsigned int first = s_word;
+			uint32_t n_out = w.n_hit;
+			if (first + n_out > hout_cap) { w.status |= DSB_ST_OUT_OVF; n_out = 0; }
+			for (uint32_t i = lane; i < n_out; i += 64) {
+				DsbChain h = w.hit[i]; DsbHitOut o;
+				o.ref_ID = h.ref_ID; o.t_st = h.t_st; o.t_ed = h.t_ed; o.q_st = h.q_st; o.q_ed = h.q_ed; o.sum_score = h.sum_score; o.indel = h.indel;
+				o.direction = h.direction; o.primary = h.primary; o.pri_index = h.pri_index; o.pad = 0;
+				hout[first + i] = o;
+			}
+			if (lane == 0) { DsbReadOut ro; ro.first = first; ro.n = n_out; ro.status = w.status | (w.status ? (w.stage << 8) : 0);
+				ro.fast = fast | ((uint32_t)((wall_clock64() - t_start) / 100) << 1); ro.n_anc = w.n_anc; ro.pad = 0; rout[r] = ro; }
+		} else {
+			for (;;) {
+				__syncthreads();                                            // wave 0 posted a command
+				const uint32_t cmd = mw.cmd;
+				if (cmd == 3) break;
+				if (cmd == 1) dsb_g64::sdp_batch_old_mw<1>(&mw, lds_ring, lds_red, lane, wv, DSB_MW_WAVES, nullptr);
+				else dsb_g64::sdp_batch_old_mw<2>(&mw, lds_ring, lds_red, lane, wv, DSB_MW_WAVES, nullptr);
+			}
+		}
+	}
+}
 
 // reads of a finished launch whose status has one of the `mask` bits are listed for another run
 __global__ void k_collect_retry(const DsbReadOut *rout, uint32_t n, uint32_t *list, unsigned int *count, int mask, int clear_n)
@@ -616,6 +706,7 @@ struct dsb_ctx {
 	std::vector<dsb_read_result> res_reads;
 	int hist_max = 0;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; dsb_timing timing; unsigned long long p1 = 0;
+	hipStream_t stream3 = nullptr; hipEvent_t ev_heavy3 = nullptr;    // k_classify_heavy: several wavefronts on each of the very heaviest reads
 	hipStream_t stream2 = nullptr; hipEvent_t ev_order = nullptr, ev_heavy = nullptr, ev_hprobe = nullptr, ev_cls = nullptr;   // the heaviest reads run beside the seed probe
 	uint32_t *dbg_host = nullptr, *dbg_dev = nullptr;
 	dsb_opts opts;
@@ -646,6 +737,8 @@ extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 	if (c->ev_heavy) hipEventDestroy(c->ev_heavy);
 	if (c->ev_hprobe) hipEventDestroy(c->ev_hprobe);
 	if (c->stream2) hipStreamDestroy(c->stream2);
+	if (c->stream3) { hipStreamSynchronize(c->stream3); hipStreamDestroy(c->stream3); }
+	if (c->ev_heavy3) hipEventDestroy(c->ev_heavy3);
 	if (c->stream) hipStreamDestroy(c->stream);
 	if (c->staged) stage_release(c->staged);
 	delete c;
@@ -671,6 +764,7 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	for (int i = 0; i < 4; i++) CK(hipEventCreate(&c->ev[i]));
 	CK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)); CK(hipEventCreate(&c->ev_order)); CK(hipEventCreate(&c->ev_cls));
 	CK(hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&c->ev_hprobe, hipEventDisableTiming));
+	CK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)); CK(hipEventCreateWithFlags(&c->ev_heavy3, hipEventDisableTiming));
 	if (rc == DSB_OK) rc = stage_acquire(idx, device_id, &c->staged);           // the index goes to HBM once per (index, device)
 	if (rc == DSB_OK) {
 		c->dx = c->staged->dx; c->d_summ = c->staged->d_summ; c->summ_shift = c->staged->summ_shift;
@@ -1004,8 +1098,21 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		hipLaunchKernelGGL(k_seed_probe_reads, dim3(n_heavy * DSB_HPROBE_SPLIT), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const uint32_t *)c->d_order, c->d_pk, c->d_bits, c->d_summ, c->summ_shift);
 		HIPCHK(hipEventRecord(c->ev_hprobe, c->stream));
 		HIPCHK(hipEventRecord(c->ev_order, c->stream));             // order_ms covers scoring, ordering and these probes
+		// the very heaviest of them (DSB_HEAVY_MW, default 32) get several wavefronts each (k_classify_heavy) on a third stream
+		unsigned n_mw = 32;
+		if (const char *e = getenv("DSB_HEAVY_MW")) n_mw = (unsigned)atoi(e);
+		if (n_mw > n_heavy) n_mw = n_heavy;
+		c->timing.n_heavy_mw = n_mw;
+		if (n_mw) {
+			HIPCHK(hipStreamWaitEvent(c->stream3, c->ev_hprobe, 0));
+			hipLaunchKernelGGL(k_classify_heavy, dim3(n_mw), dim3(64 * DSB_MW_WAVES), 0, c->stream3, dx1, (const DsbReadDesc *)s.d_rd, (uint32_t)n_mw, (const uint32_t *)c->d_order, c->d_bin,
+			                   (const uint64_t *)c->d_bits, c->arena, c->d_counters + 10, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, (uint32_t)c->n_slots,
+			                   (unsigned long long *)(c->d_counters + 16 + 8), (const uint64_t *)c->d_pk);
+			HIPCHK(hipEventRecord(c->ev_heavy3, c->stream3));
+		}
 		HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_hprobe, 0));
-		launch_classify(k_classify_early, c, c->stream2, n_heavy, dx1, s, (uint32_t)n_heavy, nullptr, (const uint32_t *)c->d_order, c->arena, c->d_counters + 4, nullptr, 0u, (uint32_t)c->n_slots, 1, false);
+		if (n_heavy > n_mw)
+			launch_classify(k_classify_early, c, c->stream2, n_heavy - n_mw, dx1, s, (uint32_t)n_heavy, nullptr, (const uint32_t *)c->d_order, c->arena, c->d_counters + 4, nullptr, n_mw, (uint32_t)c->n_slots + n_mw, 1, false);
 		HIPCHK(hipEventRecord(c->ev_heavy, c->stream2));
 	}
 	if (use_scan) {
@@ -1038,7 +1145,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		if (dbg) memset(c->dbg_host, 0, 32 * 65536 * sizeof(uint32_t));
 		launch_classify(k_classify, c, c->stream, slots, dx1, s, (uint32_t)n, nullptr, (const uint32_t *)c->d_order, c->arena, c->d_counters, dbgp, (uint32_t)n_heavy, 0u, 0, use_scan);
 		HIPCHK(hipEventRecord(c->ev_cls, c->stream));
-		if (n_heavy) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_heavy, 0));
+		if (n_heavy) { HIPCHK(hipStreamWaitEvent(c->stream, c->ev_heavy, 0)); if (c->timing.n_heavy_mw) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_heavy3, 0)); }
 		if (dbg) {
 			// watchdog: poll the stream; dump the progress words of every slot if the kernel runs long
 			for (int sec = 0; sec < 60; sec++) {
@@ -1086,7 +1193,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		double tot[10] = {0}, all = 0; unsigned sl = (unsigned)c->n_slots; if (sl > n) sl = (unsigned)n;
 		double sub[4] = {0};
 		for (unsigned sI = 0; sI < sl; sI++) { for (int i = 0; i < 10; i++) { tot[i] += c->dbg_host[4 * 65536 + 14 * sI + i]; all += c->dbg_host[4 * 65536 + 14 * sI + i]; } for (int i = 0; i < 4; i++) sub[i] += c->dbg_host[4 * 65536 + 14 * sI + 10 + i]; }
-		fprintf(stderr, "[dsb] inside sdp_right/left (ms): sdp_match %.1f  dp %.1f  combine %.1f  [3] %.1f\n", sub[0] / 1e3, sub[1] / 1e3, sub[2] / 1e3, sub[3] / 1e3);
+		fprintf(stderr, "[dsb] inside sdp_right/left (ms): sdp_match %.1f  dp %.1f  combine %.1f | fast_classify commit phase %.1f\n", sub[0] / 1e3, sub[1] / 1e3, sub[2] / 1e3, sub[3] / 1e3);
 		{	// stage split of the slowest read of the batch (as it ran, i.e. under load)
 			size_t worst = 0; uint64_t wsum = 0;
 			for (size_t r = 0; r < n && r < 65536; r++) { uint64_t sm = 0; for (int i = 0; i < 10; i++) sm += c->dbg_host[16 * 65536 + 14 * r + i]; if (sm > wsum) { wsum = sm; worst = r; } }
@@ -1195,7 +1302,7 @@ __global__ void __launch_bounds__(64) k_seed_dump(DsbDevIndex x, DsbReadDesc d, 
 	if (threadIdx.x == 0) sx = x;
 	__syncthreads();
 	dsb_g64::WCtx w; w.x = (dsb_g64::DsbXP)&sx; w.lane = threadIdx.x; w.L = d.len; w.status = 0; w.dbg = nullptr; w.anc_cap = 0; w.wtab = nullptr;
-	w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1; w.pre_seeds = nullptr; w.pre_info = nullptr; w.pk[0] = w.pk[1] = nullptr;
+	w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1; w.pre_seeds = nullptr; w.pre_info = nullptr; w.pk[0] = w.pk[1] = nullptr; w.mw = nullptr; w.n_waves = 1;
 	dsb_g64::SDir sd;
 	uint32_t n = d.len - x.ek_len + 1;
 	if (strand) dsb_g64::seed_vector(w, bin + d.bin_off + DSB_QPAD_L, bits + d.bit_off, n, out, D_FORWARD, &sd);

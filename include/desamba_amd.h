@@ -95,6 +95,8 @@ typedef struct {
 	uint64_t n_sa;         /* get_uni calls = SA sample + unitig + ref-position lookups (src/cly.c:471) */
 	uint64_t ref_bases;    /* reference bases fetched by get_ref (src/cly.c:435) */
 	uint64_t main_occ, main_mem, main_sa, main_ref_bases;   /* the same for the main k_classify launch alone (what classify_ms times) */
+	uint32_t n_heavy_mw;   /* reads of the early launch that ran on several wavefronts each (k_classify_heavy) */
+	uint32_t pad2;
 } dsb_timing;
 
 /* load_idx (src/idx.c:1103-1160, src/bwt.c:68-104): read <dir>/deSAMBA.* into host memory */

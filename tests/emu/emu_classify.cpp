@@ -106,6 +106,7 @@ extern "C" int emu_classify(void *p, const char *seq, uint32_t L, int hist_max, 
 	if (e->limit_set) w.step_limit = e->limit_set;
 	memset(e->cnt, 0, sizeof e->cnt); w.k.c = e->cnt; w.k.uni = 1;
 	w.bin = F; w.L = L; w.status = 0; w.max_read_l = hist_max;
+	w.mw = nullptr; w.n_waves = 1;
 	w.pre_seeds = nullptr; w.pre_info = nullptr; w.pk[0] = getenv("DSB_EMU_NO_GAP_LANE") ? nullptr : e->pk.data(); w.pk[1] = w.pk[0] ? w.pk[0] + nw : nullptr;
 	classify_read(w, e->bits.data(), e->bits.data() + n_words);
 	if (w.status) return -(w.status | (w.stage << 8));

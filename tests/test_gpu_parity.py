@@ -508,3 +508,28 @@ def test_seed_lookup_on_synthetic_multi_gib_tables(demo, tmp_path, monkeypatch):
                 assert ctx.exist_bits(i, strand) == bytes(exp), (i, strand)
     finally:
         ctx.close(); idx.close()
+
+
+@pytest.mark.parametrize("name", ["heavy", "wrapq", "ont20k", "ont5k_e25"])
+def test_heavy_reads_on_several_wavefronts(gpu, name, monkeypatch):
+    """k_classify_heavy: the very heaviest reads of a batch run on a workgroup of four wavefronts each (wave 0 runs the read,
+    the others split the old-predecessor pass of the batched sparse DP); forced onto small golden sets"""
+    D, idx, ctx = gpu
+    monkeypatch.setenv("DSB_HEAVY_FIRST", "16"); monkeypatch.setenv("DSB_HEAVY_MW", "16")
+    hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))
+    assert ctx.timing().n_heavy_mw > 0
+    assert sam == open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read()
+
+
+def test_heavy_reads_on_several_wavefronts_second_index(strain, monkeypatch):
+    """the same on the strain index, whose reads have match-node lists of tens of thousands of nodes (the multi-wave DP pass
+    does run there)"""
+    import desamba_amd as D
+    monkeypatch.setenv("DSB_HEAVY_FIRST", "48"); monkeypatch.setenv("DSB_HEAVY_MW", "48")
+    idx = D.Index(strain["index"]); ctx = D.Ctx(idx, 0)
+    try:
+        hits, sam = classify_all(D, ctx, D.read_fastq(strain["fastq"]))
+        assert ctx.timing().n_heavy_mw == 48
+        assert sam == open(strain["sam"], "rb").read()
+    finally:
+        ctx.close(); idx.close()
