@@ -1125,34 +1125,36 @@ typedef uint32_t lds_w32;
 #else
 typedef __attribute__((address_space(3))) uint32_t lds_w32;
 #endif
-DN void chain_stage_M3(WCtx &w)
+// (P32: lds_w32 * for the arrays in LDS, uint32_t * for larger anchor sets whose arrays lie in the idle half of the
+// anchor arena -- global memory, same code, the loads of a chunk of predecessors are coalesced; C = array stride)
+template <class P32>
+DN void chain_stage_M3(WCtx &w, P32 L, const uint32_t C)
 {
 	const DsbAnchor *A = w.anc; const int32_t n = w.n_anc; const int lane = w.lane;
-	lds_w32 *L = (lds_w32 *)w.wtab;
 	for (int32_t i = lane; i < n; i += DSB_WAVE) {
 		const DsbAnchor a = A[i];
-		L[i] = a.index_in_read; L[DSB_CHAINDP_LDS + i] = a.ref_offset; L[2 * DSB_CHAINDP_LDS + i] = (uint32_t)a.mtch_len | ((uint32_t)(uint16_t)a.score << 16);
-		L[3 * DSB_CHAINDP_LDS + i] = (a.ref_ID << 3) | ((uint32_t)a.direction << 2) | ((uint32_t)(a.useless ? 1 : 0) << 1) | (uint32_t)(a.duplicate ? 1 : 0);
+		L[i] = a.index_in_read; L[C + i] = a.ref_offset; L[2 * C + i] = (uint32_t)a.mtch_len | ((uint32_t)(uint16_t)a.score << 16);
+		L[3 * C + i] = (a.ref_ID << 3) | ((uint32_t)a.direction << 2) | ((uint32_t)(a.useless ? 1 : 0) << 1) | (uint32_t)(a.duplicate ? 1 : 0);
 	}
 	wave_sync();
 }
-DN void chain_unstage_M3(WCtx &w)
+template <class P32>
+DN void chain_unstage_M3(WCtx &w, P32 L, const uint32_t C)
 {
 	DsbAnchor *A = w.anc; const int32_t n = w.n_anc; const int lane = w.lane;
-	const lds_w32 *P = (const lds_w32 *)w.wtab + 5 * DSB_CHAINDP_LDS;
 	wave_sync();
-	for (int32_t i = lane; i < n; i += DSB_WAVE) A[i].pre = (int32_t)P[i];
+	for (int32_t i = lane; i < n; i += DSB_WAVE) A[i].pre = (int32_t)L[5 * C + i];
 	wave_sync();
 }
 // chain_insert_M3's DP (src/cly.c:252-323) on the wavefront.  The reference scans the predecessors of an anchor from the
 // nearest one backwards, skips those that overlap it, stops at the first one more than 1000 bases away, and keeps the
 // first predecessor that strictly improves the running best: lane l takes predecessor hi - l of a chunk of 64, a ballot
 // finds the stop, a wave maximum the best score, and among equal scores the nearest predecessor (lowest lane) wins.
-DN void chain_dp_M3_wave(WCtx &w)
+template <class P32>
+DN void chain_dp_M3_wave(WCtx &w, P32 LQ, const uint32_t C)
 {
 	const int32_t n = w.n_anc; const int lane = w.lane;
-	lds_w32 *LQ = (lds_w32 *)w.wtab, *LT = LQ + DSB_CHAINDP_LDS, *LMS = LQ + 2 * DSB_CHAINDP_LDS, *LK = LQ + 3 * DSB_CHAINDP_LDS,
-	        *LS = LQ + 4 * DSB_CHAINDP_LDS, *LP = LQ + 5 * DSB_CHAINDP_LDS;
+	P32 LT = LQ + C, LMS = LQ + 2 * C, LK = LQ + 3 * C, LS = LQ + 4 * C, LP = LQ + 5 * C;
 	for (int32_t st = 0; st < n;) {
 		int32_t ed = st + 1;
 		const uint32_t key = (uint32_t)LK[st] >> 2;
@@ -1328,10 +1330,17 @@ DN void resolve_tree(WCtx &w)
 	w.n_hit = 0;
 	const bool lds_dp = w.n_anc >= 50 && w.n_anc <= DSB_CHAINDP_LDS && w.wtab;
 	if (w.n_anc >= 50) chain_sort_M3(w);
-	if (lds_dp) { chain_stage_M3(w); chain_dp_M3_wave(w); chain_unstage_M3(w); }
+	const bool wave_dp = w.n_anc >= 50 && w.wtab != nullptr;
+	if (lds_dp) { lds_w32 *L = (lds_w32 *)w.wtab; chain_stage_M3(w, L, DSB_CHAINDP_LDS); chain_dp_M3_wave(w, L, DSB_CHAINDP_LDS); chain_unstage_M3(w, L, DSB_CHAINDP_LDS); }
+	else if (wave_dp) {
+		// more anchors than the LDS arrays hold (reads from repeat-rich regions): the same DP with its arrays in the idle half of
+		// the anchor arena (6 x 4 bytes per anchor <= 40: the unsorted copy chain_sort_M3 left behind)
+		uint32_t *L = reinterpret_cast<uint32_t *>(w.anc_tmp); const uint32_t C = w.n_anc;
+		chain_stage_M3(w, L, C); chain_dp_M3_wave(w, L, C); chain_unstage_M3(w, L, C);
+	}
 	DSB_SERIAL(w) {
 		if (w.n_anc < 50) for (uint32_t i = 0; i < w.n_anc; i++) chain_insert_M2(w, i);
-		else if (!lds_dp) chain_dp_M3<false>(w);
+		else if (!wave_dp) chain_dp_M3<false>(w);
 		if (w.n_hit > 1) glibc_sort_chains<0>(w, w.n_hit);
 		int rst_num = MINV(5, w.n_hit);
 		while (rst_num < w.n_hit && w.hit[rst_num].with_top_anchor == 1) rst_num++;

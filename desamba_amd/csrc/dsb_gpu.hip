@@ -556,6 +556,8 @@ __global__ void __launch_bounds__(64 * DSB_MW_WAVES, DSB_WAVES_PER_EU) k_classif
 			if (lane == 0) { DsbReadOut ro; ro.first = first; ro.n = n_out; ro.status = w.status | (w.status ? (w.stage << 8) : 0);
 				ro.fast = fast | ((uint32_t)((wall_clock64() - t_start) / 100) << 1); ro.n_anc = w.n_anc; ro.pad = 0; rout[r] = ro; }
 		} else {
+			// a helper runs only inside the DP pass of a heavy read, which is ALU-bound: same issue priority as the boosted wave 0
+			__builtin_amdgcn_s_setprio(3);
 			for (;;) {
 				__syncthreads();                                            // wave 0 posted a command
 				const uint32_t cmd = mw.cmd;
@@ -1076,7 +1078,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	// sparse DP on the CPU, ~0.2 s here).  The first n_heavy reads of the LPT order get their probes and their own
 	// k_classify launch on the second stream right away, beside the main seed probe, instead of after it.
 	unsigned n_heavy = 0;
-	if (!dbg && s.n_words_total) {
+	if (!dbg && s.n_words_total && !c->seed_only) {
 		const char *hv = getenv("DSB_HEAVY_FIRST");
 		n_heavy = hv ? (unsigned)atoi(hv) : (n >= 4096 ? (unsigned)(n / 64) : 0u);
 		if (n_heavy > DSB_HEAVY_SLOTS) n_heavy = DSB_HEAVY_SLOTS;

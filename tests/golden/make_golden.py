@@ -88,6 +88,12 @@ def main():
     if os.path.exists(wrapq):
         run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx, wrapq, "-o", os.path.join(OUT, "wrapq.ubfree.sam")])
         run([os.path.join(REF, "deSAMBA"), "classify", "-t", "1", idx, wrapq, "-o", os.path.join(OUT, "wrapq.stock.sam")])
+    # read 21607 of tools/readgen.c's first benchmark batch: 1202 anchors (more than the chain DP's LDS arrays hold), the slowest
+    # read of that batch
+    many = os.path.join(OUT, "manyanchors.fq")
+    if os.path.exists(many):
+        run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx, many, "-o", os.path.join(OUT, "manyanchors.ubfree.sam")])
+        run([os.path.join(REF, "deSAMBA"), "classify", "-t", "1", idx, many, "-o", os.path.join(OUT, "manyanchors.stock.sam")])
     # read 4346 of tools/readgen.c's first benchmark batch before that generator stopped running reads over the end of a
     # reference: the read wraps from the end of NC_003513.1 to its start, a hit hangs over the start of the reference, the
     # reference's unsigned window arithmetic (src/cly.c:2727) wraps and the STOCK binary dies with a segmentation fault;

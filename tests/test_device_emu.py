@@ -52,7 +52,7 @@ def test_demo_reads(emu, oracle, demo):
     _cmp(emu, oracle, D.read_fastq(demo["fastq"], 400), check_stages=True)
 
 
-@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq", "ngs_e14", "overhang"])
+@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq", "ngs_e14", "overhang", "manyanchors"])
 def test_synthetic(emu, oracle, name):
     import desamba_amd as D
     _cmp(emu, oracle, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")), check_stages=(name in ("ngs150", "appc")))

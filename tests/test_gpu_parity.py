@@ -43,7 +43,7 @@ def test_demo_sam_md5(gpu, demo, golden_md5):
     assert hashlib.md5(sam).hexdigest() == golden_md5
 
 
-@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq", "ngs_e14", "overhang"])
+@pytest.mark.parametrize("name", ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq", "ngs_e14", "overhang", "manyanchors"])
 def test_synthetic_golden_sam(gpu, name):
     D, idx, ctx = gpu
     hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))
@@ -510,7 +510,7 @@ def test_seed_lookup_on_synthetic_multi_gib_tables(demo, tmp_path, monkeypatch):
         ctx.close(); idx.close()
 
 
-@pytest.mark.parametrize("name", ["heavy", "wrapq", "ont20k", "ont5k_e25"])
+@pytest.mark.parametrize("name", ["heavy", "wrapq", "ont20k", "ont5k_e25", "manyanchors"])
 def test_heavy_reads_on_several_wavefronts(gpu, name, monkeypatch):
     """k_classify_heavy: the very heaviest reads of a batch run on a workgroup of four wavefronts each (wave 0 runs the read,
     the others split the old-predecessor pass of the batched sparse DP); forced onto small golden sets"""

@@ -8,7 +8,7 @@ import pytest
 
 from conftest import GOLDEN, ROOT, md5_file, sam_lines
 
-SETS = ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq", "ngs_e14", "overhang"]
+SETS = ["ont20k", "ngs150", "pb", "ont5k_e25", "appc", "heavy", "wrapq", "ngs_e14", "overhang", "manyanchors"]
 
 
 def test_demo_md5(demo, oracle, golden_md5, tmp_path):
