@@ -62,7 +62,7 @@ EXPORTS = ["dsb_index_open", "dsb_index_close", "dsb_index_n_ref", "dsb_index_re
            "dsb_batch_upload", "dsb_batch_upload_fastq", "dsb_batch_upload_text", "dsb_ctx_set_history", "dsb_host_alloc", "dsb_host_free", "dsb_batch_run", "dsb_batch_fetch", "dsb_batch_timing", "dsb_batch_seeds", "dsb_batch_exist_bits",
            "dsb_format_sam", "dsb_format_des", "dsb_strerror", "dsb_version",
            "dsb_device_count", "dsb_ctx_select_slot", "dsb_ctx_create_multi", "dsb_multi_destroy", "dsb_multi_n", "dsb_multi_ctx",
-           "dsb_multi_reset_history", "dsb_multi_classify_batch", "dsb_shard_plan", "dsb_ctx_use_synthetic_filter", "dsb_synthetic_filter_bit"]
+           "dsb_multi_reset_history", "dsb_multi_classify_batch", "dsb_shard_plan", "dsb_ctx_use_synthetic_filter", "dsb_synthetic_filter_bit", "dsb_index_prefix_interval"]
 
 _lib = None
 
@@ -112,6 +112,7 @@ def lib():
     L.dsb_shard_plan.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.c_uint64, C.c_uint32, C.POINTER(DsbChunk), C.c_size_t, C.POINTER(C.c_size_t)]
     L.dsb_ctx_use_synthetic_filter.argtypes = [C.c_void_p, C.c_uint64, C.c_double]
     L.dsb_synthetic_filter_bit.argtypes = [C.c_int, C.c_uint64, C.c_double]
+    L.dsb_index_prefix_interval.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.dsb_index_close.restype = None; L.dsb_ctx_destroy.restype = None; L.dsb_ctx_reset_history.restype = None
     L.dsb_strerror.argtypes = [C.c_int]; L.dsb_strerror.restype = C.c_char_p
     L.dsb_version.restype = C.c_char_p

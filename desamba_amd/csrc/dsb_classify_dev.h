@@ -473,7 +473,15 @@ DV int bwt_MEM_search(DsbXP x, const Cnt &k, const uint8_t *string, uint64_t pre
 {
 	int n_rst = 0; uint32_t n_occ = 0;
 	cnt_add(k, 1, 1u);
-	uint64_t sp = DSB_G64(x->hash_index, pre_v), ep = DSB_G64(x->hash_index, pre_v + 1), new_sp, new_ep;
+	uint64_t sp, ep, new_sp, new_ep;
+	if (x->hash_c) {	// both ends of the prefix interval from one 64-byte line
+		const uint32_t ln = DSB_HI_DIV29(pre_v), sl = (uint32_t)pre_v - ln * DSB_HI_PER_LINE;
+		const DsbHiLine *hl = x->hash_c + ln;
+		const uint32_t base = DSB_G32(hl, 0);
+		// off[sl], off[sl + 1]: two unaligned 16-bit values = one 32-bit load at byte 4 + 2 sl
+		const uint32_t two = dsb_g32u(reinterpret_cast<const uint8_t *>(hl) + 4 + 2 * sl);
+		sp = (uint64_t)base + (two & 0xffffu); ep = (uint64_t)base + (two >> 16);
+	} else { sp = DSB_G64(x->hash_index, pre_v); ep = DSB_G64(x->hash_index, pre_v + 1); }
 	string -= 13; int match_len = 13; uint32_t ch;
 	while (1) {
 		ch = *string; string--;

@@ -5,7 +5,7 @@
 //   fm           rank structure re-laid-out for one 64-B line per occ(): per 128 BWT symbols
 //                {u32 cnt[A,C,G,T]; u64 p0[2]; u64 p1[2]; u64 sp[2]}  (reference: 168 B per 256
 //                symbols, src/bwt.c:43-65; answers are identical, tests/test_fm_layout.py)
-//   hash_index   (4^13+1) x u64, as on disk (src/bwt.c:84-85)
+//   hash_index   (4^13+1) x u64, as on disk (src/bwt.c:84-85), or compressed to one 64-B line per 29 prefixes (DsbHiLine)
 //   sa           {unitig_ID, offset} per 8 BWT rows (src/bwt.h:10-13)
 //   uni          {ref_list, length} + sentinel (src/idx.c:1123-1129)
 //   refpos       u64 bit-field {global_offset:40, ref_ID:23, direction:1} (src/idx.h:33-39)
@@ -29,11 +29,21 @@ struct DsbFmBlock {            // 64 bytes, 128 symbols
 
 struct DsbRefInfo { uint64_t seq_l, seq_offset; };
 
+// hash_index compressed.  The table maps a 13-base prefix p to the BWT interval [h[p], h[p + 1]) and is
+// non-decreasing, most of its 2^26 entries repeating their neighbour (src/idx.c:940-960 fills absent prefixes with the
+// previous end).  A 64-byte line holds the 30 values h[29 b] .. h[29 b + 29] as a 32-bit base plus 16-bit offsets, so
+// that both ends of every interval come from ONE line (the last value of a line is the first of the next).  Built at
+// index open when every line spans < 65536 rows and the BWT has < 2^32 rows; otherwise the raw table is staged.
+struct DsbHiLine { uint32_t base; uint16_t off[30]; };
+#define DSB_HI_PER_LINE 29u
+#define DSB_HI_DIV29(p) ((uint32_t)(((uint64_t)(p) * 2369637129ULL) >> 36))      /* p / 29 for p <= 2^26 + 1 */
+
 struct DsbDevIndex {
 	const uint8_t *ek0, *ek1; uint64_t ek_mask; int ek_len, single_base_max;
 	const DsbFmBlock *fm; uint64_t bwt_len; uint64_t rank[6]; uint64_t dollar_pos; uint64_t dollar_row;
 	const uint64_t *fm_sb;     // BWT of >= 2^32 symbols: 5 u64 per superblock (2^22 symbols), block counts are relative to them; else null
-	const uint64_t *hash_index;
+	const uint64_t *hash_index;    // (4^13 + 1) x u64 as on disk -- or null when the compressed form below is staged instead
+	const DsbHiLine *hash_c;       // compressed: one 64-B line per 29 prefixes (DsbHiLine), 148 MB instead of 512 MiB
 	const uint2 *sa; const uint2 *uni; const uint64_t *refpos; const uint8_t *refbin; const DsbRefInfo *refinfo;
 	uint64_t ref_bases;        // bases of the 2-bit reference text (windows that start beyond it read as 0, oracle U6)
 	const int *qmem;           // [2000]

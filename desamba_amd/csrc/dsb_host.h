@@ -13,6 +13,7 @@ struct DsbHostIndex {
 	DsbFmBlock *fm; uint64_t n_fm, bwt_len, rank[6], dollar_pos, dollar_row;
 	uint64_t *fm_sb; uint64_t n_fm_sb;     // 64-bit rank: per superblock of 2^15 blocks {A, C, G, T, sum} before it; null = block counts are absolute
 	uint64_t *hash_index;
+	DsbHiLine *hash_c; uint64_t n_hash_c;      // compressed hash_index (null: does not fit the 16-bit offsets, raw table in use)
 	DsbHostSa *sa; uint64_t sa_size;
 	DsbHostUni *uni; uint64_t n_uni;
 	uint64_t *refpos; uint64_t n_refpos;

@@ -42,6 +42,25 @@ extern "C" int dsb_index_open(const char *dir, dsb_index **out)
 	h.hash_index = (uint64_t *)malloc(nh * 8);
 	if (!h.hash_index || !rd(h.hash_index, 8, nh, f)) { free(raw); FAIL(DSB_EIO); }
 	fclose(f); f = NULL;
+	// compressed hash_index (dsb_device.h: DsbHiLine): 29 prefixes per 64-byte line when every line spans < 65536 rows
+	h.hash_c = NULL; h.n_hash_c = 0;
+	if (!getenv("DSB_RAW_HASH_INDEX")) {
+		const uint64_t n_line = (nh - 1 + DSB_HI_PER_LINE - 1) / DSB_HI_PER_LINE + 1;
+		DsbHiLine *hc = (DsbHiLine *)calloc(n_line, sizeof(DsbHiLine));
+		bool ok = hc != NULL;
+		for (uint64_t b = 0; ok && b < n_line; b++) {
+			const uint64_t p0 = b * DSB_HI_PER_LINE;
+			const uint64_t v0 = h.hash_index[p0 < nh ? p0 : nh - 1];
+			if (v0 > 0xffffffffULL) { ok = false; break; }
+			hc[b].base = (uint32_t)v0;
+			for (uint32_t i = 0; i < 30; i++) {
+				const uint64_t p = p0 + i, v = h.hash_index[p < nh ? p : nh - 1];
+				if (v < v0 || v - v0 > 0xffffULL) { ok = false; break; }
+				hc[b].off[i] = (uint16_t)(v - v0);
+			}
+		}
+		if (ok) { h.hash_c = hc; h.n_hash_c = n_line; } else free(hc);
+	}
 	// re-layout: reference block = 256 symbols: 5 x u64 counts + 256 nibbles (low nibble first), src/bwt.c:43-65
 	uint64_t n_blk256 = byteLen / 168;
 	h.bwt_len = n_blk256 * 256;
@@ -161,13 +180,26 @@ extern "C" void dsb_index_close(dsb_index *x)
 {
 	if (!x) return;
 	DsbHostIndex &h = x->h;
-	free(h.ek0); free(h.ek1); free(h.fm); free(h.fm_sb); free(h.hash_index); free(h.sa); free(h.uni); free(h.refpos); free(h.refbin); free(h.refdisk); free(h.refinfo);
+	free(h.ek0); free(h.ek1); free(h.fm); free(h.fm_sb); free(h.hash_index); free(h.hash_c); free(h.sa); free(h.uni); free(h.refpos); free(h.refbin); free(h.refdisk); free(h.refinfo);
 	free(x);
 }
 extern "C" uint64_t dsb_index_n_ref(const dsb_index *x) { return x ? x->h.n_ref : 0; }
 extern "C" const char *dsb_index_ref_name(const dsb_index *x, uint32_t id) { return (x && id < x->h.n_ref) ? x->h.refdisk[id].name : "*"; }
 extern "C" uint64_t dsb_index_ref_len(const dsb_index *x, uint32_t id) { return (x && id < x->h.n_ref) ? x->h.refdisk[id].seq_l : 0; }
 extern "C" int dsb_index_ek_len(const dsb_index *x) { return x ? x->h.ek_len : 0; }
+
+// host mirror of the prefix-interval lookup of bwt_MEM_search (hash_index[p], hash_index[p + 1]; src/cly.c:1396-1399): from the
+// compressed lines (form = 1; returns -1 if the index has none) or from the table as on disk (form = 0)
+extern "C" int dsb_index_prefix_interval(const dsb_index *x, uint32_t p, int form, uint64_t *sp, uint64_t *ep)
+{
+	const DsbHostIndex &h = x->h;
+	if (p >= (1u << 26)) return DSB_EINVAL;
+	if (form == 0) { *sp = h.hash_index[p]; *ep = h.hash_index[p + 1]; return 0; }
+	if (!h.hash_c) return -1;
+	const uint32_t ln = DSB_HI_DIV29(p), sl = p - ln * DSB_HI_PER_LINE;
+	*sp = (uint64_t)h.hash_c[ln].base + h.hash_c[ln].off[sl]; *ep = (uint64_t)h.hash_c[ln].base + h.hash_c[ln].off[sl + 1];
+	return 0;
+}
 
 // host mirror of fm_occ (dsb_classify_dev.h) over the same blocks, for layout tests without a GPU
 extern "C" uint64_t dsb_index_occ_host(const dsb_index *x, uint64_t r, uint8_t *cp)

@@ -107,6 +107,9 @@ uint64_t    dsb_index_n_ref(const dsb_index *idx);
 const char *dsb_index_ref_name(const dsb_index *idx, uint32_t ref_ID);
 uint64_t    dsb_index_ref_len(const dsb_index *idx, uint32_t ref_ID);
 int         dsb_index_ek_len(const dsb_index *idx);
+/* host mirror of the device's prefix-interval lookup (hash_index[p], hash_index[p+1] of bwt_MEM_search, src/cly.c:1396-1399):
+ * form 1 = from the compressed 64-byte lines staged on the device (returns -1 if this index keeps the raw table), 0 = raw */
+int dsb_index_prefix_interval(const dsb_index *idx, uint32_t prefix, int form, uint64_t *sp, uint64_t *ep);
 /* host mirror of the device rank structure, for layout tests without a GPU (occ, src/bwt.c:43-65) */
 uint64_t dsb_index_occ_host(const dsb_index *idx, uint64_t r, uint8_t *c);
 

@@ -29,7 +29,7 @@ extern "C" void *emu_new(dsb_index *idx, int min_len, int min_score)
 	DsbDevIndex &dx = e->dx; memset(&dx, 0, sizeof dx);
 	dx.ek0 = h->ek0; dx.ek1 = h->ek1; dx.ek_mask = h->ek_mask; dx.ek_len = h->ek_len; dx.single_base_max = h->single_base_max;
 	dx.fm = h->fm; dx.fm_sb = h->fm_sb; dx.bwt_len = h->bwt_len; memcpy(dx.rank, h->rank, sizeof dx.rank); dx.dollar_pos = h->dollar_pos; dx.dollar_row = h->dollar_row;
-	dx.hash_index = h->hash_index; dx.sa = (const uint2 *)h->sa; dx.uni = (const uint2 *)h->uni; dx.refpos = h->refpos; dx.refbin = h->refbin; dx.ref_bases = h->n_refbin * 4;
+	dx.hash_index = h->hash_c ? nullptr : h->hash_index; dx.hash_c = h->hash_c; dx.sa = (const uint2 *)h->sa; dx.uni = (const uint2 *)h->uni; dx.refpos = h->refpos; dx.refbin = h->refbin; dx.ref_bases = h->n_refbin * 4;
 	dx.refinfo = h->refinfo; dx.qmem = h->Q_MEM; dx.qlv = &h->Q_LV[0][0];
 	dx.filter_min_length = min_len; dx.filter_min_score = min_score; dx.filter_min_score_LV3 = min_score + 10;
 	e->max_len = 0;

@@ -46,6 +46,25 @@ def test_index_loader_and_rank_layout(demo, oracle, monkeypatch, rank64):
     idx.close()
 
 
+def test_compressed_hash_index_gives_the_same_intervals(demo):
+    """the prefix table staged on the device as 64-byte lines of 29 prefixes (32-bit base + 16-bit offsets, 148 MB instead
+    of 512 MiB) answers every lookup like hash_index[p], hash_index[p+1] of the on-disk table"""
+    import ctypes as C
+    import desamba_amd as D
+    idx = D.Index(demo["index"]); L = D.lib()
+    rng = random.Random(9)
+    ps = [rng.randrange(1 << 26) for _ in range(200000)] + [0, 1, 28, 29, 30, 57, 58, (1 << 26) - 1, (1 << 26) - 29, (1 << 26) - 30]
+    a0, a1, b0, b1 = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    nonempty = 0
+    for p in ps:
+        assert L.dsb_index_prefix_interval(idx.h, p, 0, C.byref(a0), C.byref(a1)) == 0
+        assert L.dsb_index_prefix_interval(idx.h, p, 1, C.byref(b0), C.byref(b1)) == 0      # the demo index fits the compressed form
+        assert (a0.value, a1.value) == (b0.value, b1.value), p
+        nonempty += a1.value > a0.value
+    assert nonempty > 1000
+    idx.close()
+
+
 def test_missing_index_is_an_error(built, tmp_path):
     import desamba_amd as D
     with pytest.raises(D.DsbError) as e:

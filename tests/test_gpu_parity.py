@@ -516,9 +516,13 @@ def test_heavy_reads_on_several_wavefronts(gpu, name, monkeypatch):
     the others split the old-predecessor pass of the batched sparse DP); forced onto small golden sets"""
     D, idx, ctx = gpu
     monkeypatch.setenv("DSB_HEAVY_FIRST", "16"); monkeypatch.setenv("DSB_HEAVY_MW", "16")
-    hits, sam = classify_all(D, ctx, D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq")))
+    recs = D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq"))
+    exp = open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read()
+    if len(recs) < 4:           # (the early launch takes at most half of a batch: feed the set three times)
+        recs = recs * 3; exp = exp * 3
+    hits, sam = classify_all(D, ctx, recs)
     assert ctx.timing().n_heavy_mw > 0
-    assert sam == open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read()
+    assert sam == exp
 
 
 def test_heavy_reads_on_several_wavefronts_second_index(strain, monkeypatch):
