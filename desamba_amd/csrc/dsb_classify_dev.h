@@ -2680,10 +2680,45 @@ DN void detect_primary(WCtx &w, uint32_t read_len)
 }
 
 // classify_seq (src/cly.c:3064-3132) for one read; returns cly_r.fast_classify
-DN uint32_t classify_read(WCtx &w, const uint64_t *bitsF, const uint64_t *bitsR)
+// Short reads, 64 at a time (k_classify in group mode): the anchor stage of ONE READ PER LANE.  A 150-bp read has one or two
+// top islands whose walk is a chain of ~100 dependent rank queries (its exact matches run through most of the read), so a
+// wavefront that takes one such read leaves 62 lanes idle for a quarter of a millisecond.  Here every lane runs the
+// reference's own sequential loop over the top islands of its read (src/cly.c:1478-1546, skip-next rule as written) into
+// its lane scratch; the wavefront then finishes the reads one after the other from those anchors (classify_read with
+// have_anchors).  Needs the seed lists of k_seed_scan.  *n_anc_out: anchors of the lane's read, *ovf_out: they did not fit
+// the lane scratch (the read then takes the usual path).
+DN void fast_classify_lane(WCtx &w, bool valid, uint8_t *bin, uint32_t read_len, DsbSeed *seeds, const DsbSeedInfo *info, uint32_t *n_anc_out, uint32_t *ovf_out)
+{
+	DsbAnchor *const main_anc = w.anc; uint64_t *const main_sp = w.spset; const int st0 = w.status;
+	w.k.uni = 0;
+	w.anc = w.lane_anc + (size_t)w.lane * DSB_LANE_ANC_CAP; w.n_anc = 0; w.anc_cap = DSB_LANE_ANC_CAP;
+	w.spset = w.lane_spset + (size_t)w.lane * DSB_SPHASH; w.status = 0; w.lsteps = 0;
+	if (valid && read_len >= 40) {
+		const DsbSeedInfo si = *info;
+		SDir sd[2];
+		sd[0].seed_v = seeds; sd[0].l_seed_v = si.n_seed[0]; sd[0].bin_read = bin; sd[0].bits = nullptr; sd[0].direction = D_FORWARD; sd[0].total_score = si.total[0];
+		sd[1].seed_v = seeds + (read_len >> 2); sd[1].l_seed_v = si.n_seed[1]; sd[1].bin_read = bin + read_len; sd[1].bits = nullptr; sd[1].direction = D_REVERSE; sd[1].total_score = si.total[1];
+		if (sd[0].total_score < sd[1].total_score) { SDir t = sd[0]; sd[0] = sd[1]; sd[1] = t; }
+		const bool both_direction = ((sd[0].total_score - sd[1].total_score) <= (sd[0].total_score >> 3));
+		for (int s = 0; s < (both_direction ? 2 : 1); s++) {
+			uint32_t skip_seed = 0xffffffffu;
+			for (uint32_t i = 0; i < sd[s].l_seed_v; i++) {
+				if (!sd[s].seed_v[i].top || i == skip_seed) continue;
+				if (fast_island(w, &sd[s], read_len, i)) skip_seed = i + 1;
+			}
+		}
+	}
+	*n_anc_out = w.n_anc; *ovf_out = (w.status & (DSB_ST_ANC_OVF | DSB_ST_TIMEOUT)) ? 1u : 0u;
+	w.anc = main_anc; w.n_anc = 0; w.anc_cap = w.anc_cap_main; w.spset = main_sp; w.status = st0; w.k.uni = 1;
+	w.sp_gen = (uint32_t)grp_max_i(w.red, w.lane, (int)w.sp_gen);
+	wave_sync();
+}
+
+DN uint32_t classify_read(WCtx &w, const uint64_t *bitsF, const uint64_t *bitsR, const bool have_anchors = false)
 {
 	uint32_t read_len = w.L;
-	w.n_anc = 0; w.n_hit = 0; w.n_sms = 0; w.steps = 0; w.lsteps = 0; w.dp_preds = 0; w.boosted = 0; w.k.uni = 1;
+	if (!have_anchors) w.n_anc = 0;
+	w.n_hit = 0; w.n_sms = 0; w.steps = 0; w.lsteps = 0; w.dp_preds = 0; w.boosted = 0; w.k.uni = 1;
 	uint32_t fast = 1;
 	if (read_len < 40) return fast;
 	SDir *sd = w.sd;
@@ -2703,8 +2738,10 @@ DN uint32_t classify_read(WCtx &w, const uint64_t *bitsF, const uint64_t *bitsR)
 	bool both_direction = ((sd[0].total_score - sd[1].total_score) <= (sd[0].total_score >> 3));
 	int super_repeat = 0;
 	w.stage = 2; MARK(w, 2);
-	fast_classify(w, sd, read_len);
-	if (both_direction) fast_classify(w, sd + 1, read_len);
+	if (!have_anchors) {
+		fast_classify(w, sd, read_len);
+		if (both_direction) fast_classify(w, sd + 1, read_len);
+	}
 	TICK(w, 1);
 	w.stage = 3; MARK(w, 3);
 	resolve_tree(w);

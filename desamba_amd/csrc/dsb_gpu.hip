@@ -393,7 +393,7 @@ struct DsbSlotArena {
 #define DSB_DEFINE_CLASSIFY(KNAME, NS, THREADS)                                                                         \
 __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,   \
         const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout,  \
-        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg, uint32_t item_base, uint32_t slot_base, unsigned long long *work_cnt, DsbSeed *seed_blob, const DsbSeedInfo *sinfo, const uint64_t *pk)  \
+        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg, uint32_t item_base, uint32_t slot_base, unsigned long long *work_cnt, DsbSeed *seed_blob, const DsbSeedInfo *sinfo, const uint64_t *pk, uint32_t group_mode)  \
 {                                                                                                                       \
 	const int lane = threadIdx.x;                                                                                       \
 	const uint32_t slot_id = slot_base + blockIdx.x;            /* arena slot (and debug row) of this wave */          \
@@ -432,8 +432,12 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	__syncthreads();                                                                                                    \
 	const unsigned int n_items = n_ptr ? *n_ptr : n_fixed;                                                              \
 	if (w.dbg && lane == 0) w.dbg[0] = 300;                                                                             \
+	/* group_mode (short reads with seed lists from k_seed_scan): a work item is 64 reads -- the anchor stage of one read per  \
+	   lane (fast_classify_lane), then the reads one after the other on the whole wavefront from those anchors; a read     \
+	   whose anchors outgrew its lane scratch is done afterwards the usual way (pass 1) */                                  \
+	const unsigned int n_grp = (group_mode && seed_blob) ? 64u : 1u;                                                    \
 	for (;;) {                                                                                                          \
-		if (lane == 0) s_word = atomicAdd(work_counter, 1u);                                                            \
+		if (lane == 0) s_word = atomicAdd(work_counter, n_grp);                                                         \
 		__syncthreads();                                                                                                \
 		unsigned int k = s_word + item_base;                                                                            \
 		__syncthreads();                                                                                                \
@@ -442,7 +446,25 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 			if (w.dbg && lane == 0) { w.dbg[0] = 999; for (int i = 0; i < 14; i++) dbg[4 * 65536 + 14 * slot_id + i] += (uint32_t)(w.tacc[i] / 100); } \
 			break;                                                                                                      \
 		}                                                                                                               \
-		unsigned int r = list ? list[k] : k;                                                                            \
+		uint32_t g_nanc = 0, g_ovf = 0;                                                                                 \
+		if (n_grp > 1) {                                                                                                \
+			const bool valid = k + lane < n_items;                                                                      \
+			const unsigned int rl = valid ? (list ? list[k + lane] : k + lane) : 0u;                                    \
+			const DsbReadDesc dl = rd[rl];                                                                              \
+			uint64_t tg = w.dbg ? wall_clock64() : 0;                                                                   \
+			NS::fast_classify_lane(w, valid, bin + dl.bin_off + DSB_QPAD_L, dl.len, seed_blob + dl.seed_off, sinfo + rl, &g_nanc, &g_ovf); \
+			if (w.dbg) w.tacc[1] += wall_clock64() - tg;                                                                \
+		}                                                                                                               \
+		for (unsigned int pass = 0; pass < (n_grp > 1 ? 2u : 1u); pass++)                                               \
+		for (unsigned int gl = 0; gl < n_grp; gl++) {                                                                   \
+			if (k + gl >= n_items) break;                                                                               \
+			bool have_anc = false;                                                                                      \
+			if (n_grp > 1) {                                                                                            \
+				const uint32_t ovf_l = NS::dsb_shfl(g_ovf, (int)gl);                                                    \
+				if ((ovf_l != 0) != (pass == 1)) continue;                                                              \
+				have_anc = !ovf_l;                                                                                      \
+			}                                                                                                           \
+		unsigned int r = list ? list[k + gl] : k + gl;                                                                  \
 		DsbReadDesc d = rd[r];                                                                                          \
 		uint64_t t_start = wall_clock64();                                                                              \
 		uint64_t tacc0[14]; if (w.dbg) for (int i = 0; i < 14; i++) tacc0[i] = w.tacc[i];                               \
@@ -450,7 +472,14 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 		w.bin = bin + d.bin_off + DSB_QPAD_L; w.L = d.len; w.status = 0; w.max_read_l = d.hist_max;                     \
 		w.pre_seeds = seed_blob ? seed_blob + d.seed_off : nullptr; w.pre_info = sinfo + r;                             \
 		w.pk[0] = pk + d.pk_off; w.pk[1] = w.pk[0] + ((d.len + 31) / 32 + 1);                                           \
-		uint32_t fast = NS::classify_read(w, bits + d.bit_off, bits + d.bit_off + d.n_words);                           \
+		if (have_anc) {   /* the anchors lane gl made for this read */                                                  \
+			const uint32_t na = NS::dsb_shfl(g_nanc, (int)gl);                                                          \
+			const DsbAnchor *src = w.lane_anc + (size_t)gl * DSB_LANE_ANC_CAP;                                          \
+			for (uint32_t i = lane; i < na; i += 64) w.anc[i] = src[i];                                                 \
+			w.n_anc = na;                                                                                               \
+			NS::wave_sync();                                                                                            \
+		}                                                                                                               \
+		uint32_t fast = NS::classify_read(w, bits + d.bit_off, bits + d.bit_off + d.n_words, have_anc);                 \
 		if (w.boosted) __builtin_amdgcn_s_setprio(0);                                                                   \
 		/* publish the hits of this read */                                                                             \
 		if (lane == 0) s_word = w.n_hit ? atomicAdd(hout_counter, w.n_hit) : 0u;                                        \
@@ -468,6 +497,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 		if (w.dbg && lane == 0) { w.dbg[0] = 200; if (r < 65536u) for (int i = 0; i < 14; i++) dbg[16 * 65536 + 14 * r + i] = (uint32_t)((w.tacc[i] - tacc0[i]) / 100); } \
 		if (lane == 0) { DsbReadOut ro; ro.first = first; ro.n = n_out; ro.status = w.status | (w.status ? (w.stage << 8) : 0); \
 			ro.fast = fast | ((uint32_t)((wall_clock64() - t_start) / 100) << 1); ro.n_anc = w.n_anc; ro.pad = 0; rout[r] = ro; }                       \
+		}                                                                                                               \
 	}                                                                                                                   \
 }
 
@@ -1044,6 +1074,8 @@ extern "C" long dsb_batch_upload_fastq(dsb_ctx *c, const char *path, size_t skip
 	return rc ? rc : (long)v.size();
 }
 
+// (group mode of k_classify: batches whose reads are all at most this long take 64 reads per work item)
+#define DSB_GROUP_MAX_LEN 400u
 // one k_classify-family launch
 template <class K>
 static void launch_classify(K kern, dsb_ctx *c, hipStream_t st, unsigned grid, const DsbDevIndex &dx, const InSlot &s, uint32_t n_fixed, const unsigned int *n_ptr,
@@ -1052,7 +1084,7 @@ static void launch_classify(K kern, dsb_ctx *c, hipStream_t st, unsigned grid, c
 {
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, st, dx, (const DsbReadDesc *)s.d_rd, n_fixed, n_ptr, list, c->d_bin, (const uint64_t *)c->d_bits, ar, work_counter,
 	                   c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, dbg, item_base, slot_base, (unsigned long long *)(c->d_counters + 16 + 8 * cnt_set),
-	                   pre_seeds ? c->d_seeds : nullptr, (const DsbSeedInfo *)c->d_sinfo, (const uint64_t *)c->d_pk);
+	                   pre_seeds ? c->d_seeds : nullptr, (const DsbSeedInfo *)c->d_sinfo, (const uint64_t *)c->d_pk, (uint32_t)((pre_seeds && s.max_len <= DSB_GROUP_MAX_LEN && !getenv("DSB_NO_GROUP")) ? 1u : 0u));
 }
 
 extern "C" int dsb_batch_run(dsb_ctx *c)

@@ -537,3 +537,25 @@ def test_heavy_reads_on_several_wavefronts_second_index(strain, monkeypatch):
         assert sam == open(strain["sam"], "rb").read()
     finally:
         ctx.close(); idx.close()
+
+
+def test_short_reads_64_per_wavefront(gpu, demo, oracle, tmp_path, monkeypatch):
+    """group mode of k_classify (batches of reads <= 400 bases with seed lists from k_seed_scan): the anchor stage of one read
+    per lane, 64 reads per work item.  6000 x 150 bp at 1 % and 2000 at 8 % error (slow path, reads without hits), plus
+    reads shorter than 40: SAM byte-identical to the oracle's"""
+    import subprocess
+    D, idx, ctx = gpu
+    a = tmp_path / "a.fq"; b = tmp_path / "b.fq"; c = tmp_path / "c.fq"
+    subprocess.check_call([os.path.join(ROOT, "tools", "readsim"), demo["index"], str(a), "6000", "150", "0.01", "901", "ngs"])
+    subprocess.check_call([os.path.join(ROOT, "tools", "readsim"), demo["index"], str(b), "2000", "150", "0.08", "902", "ngs"])
+    c.write_bytes(a.read_bytes() + b"@s1\nACGTACGTACGTACGTACGTACGT\n+\n555555555555555555555555\n@s2\n" + b"A" * 300 + b"\n+\n" + b"5" * 300 + b"\n" + b.read_bytes())
+    recs = D.read_fastq(str(c))
+    monkeypatch.delenv("DSB_SEED_SCAN", raising=False)
+    hits, sam = classify_all(D, ctx, recs)
+    assert ctx.timing().seed_scan == 1
+    exp = tmp_path / "exp.sam"
+    oracle.classify_file(str(c), str(exp), threads=4)
+    assert sam == exp.read_bytes()
+    monkeypatch.setenv("DSB_NO_GROUP", "1")
+    hits2, sam2 = classify_all(D, ctx, recs)
+    assert sam2 == sam
