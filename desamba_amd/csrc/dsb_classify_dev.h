@@ -893,67 +893,20 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 	w.k.uni = 0;                                                   // lanes walk different islands: every lane counts its own work
 	w.anc = w.lane_anc + (size_t)lane * DSB_LANE_ANC_CAP; w.n_anc = 0; w.anc_cap = DSB_LANE_ANC_CAP;
 	w.spset = w.lane_spset + (size_t)lane * DSB_SPHASH;
-	// The walk of fast_island, flattened into ONE loop with the island as lane state: with the island loop outside and the
-	// window loop inside, the lanes of a wavefront would meet again only at the end of every island -- each round of 64
-	// islands as slow as its longest walk (1 to 10 searches).  Here a lane that finishes an island takes the next one in
-	// the same iteration; an iteration is one MEM search for every active lane, then map_seed for the lanes that found one.
-	{
-		DsbXP x = w.x;
-		const int l_ek = x->ek_len, min_index = 21 - l_ek;
-		uint8_t *const bin_read = s_d->bin_read;
-		SpSet sp_set = {w.spset, 0, DSB_SPSET_CAP, &w.sp_gen};
-		bool active = false, done = false;
-		uint32_t t = 0, sidx = 0, start = 0; int st_before = 0, j = 0, skip_next = 0;
-		DsbSeed sv; sv.offset = 0; sv.len = 0; sv.top = 0;
-		for (;;) {
-			if (!active && !done) {
+	for (;;) {
 #ifdef DSB_HOST_EMU
-				t = w.red[0]++;
+		const uint32_t t = w.red[0]++;
 #else
-				t = __hip_atomic_fetch_add((lds_u32 *)w.red, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		const uint32_t t = __hip_atomic_fetch_add((lds_u32 *)w.red, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-				if (t >= n_top) done = true;
-				else {
-					start = w.n_anc; st_before = w.status;
-					// a full scratch: an overflowing walk would overwrite its last slot, which belongs to an earlier island
-					if (start >= DSB_LANE_ANC_CAP) info[t] = (uint32_t)lane | (start << 6) | (1u << 27);
-					else { sidx = top_idx[t]; sv = sv_b[sidx]; j = (int)sv.len - 1; skip_next = 0; sp_set_reset(sp_set); active = true; }
-				}
-			}
-			if (!dsb_ballot64(!done)) break;
-			if (!active) continue;
-			bool finish = j < min_index;
-			if (!finish) {
-				if (LSPENT(w)) { w.status |= DSB_ST_TIMEOUT; finish = true; }
-				else {
-					DsbMem m_r[2];
-					const int kmer_index = sv.offset + j, string_index = kmer_index + l_ek - 1;
-					const uint64_t prefixValue = prefix13(bin_read, string_index);
-					const int n = bwt_MEM_search(x, w.k, bin_read + string_index, prefixValue, 2, 21 - 1, string_index, sp_set, m_r);
-					if (n == 0) j -= 2;
-					else {
-						j -= 3;
-						int max_score = 0;
-						for (int q = 0; q < n; ++q) {
-							m_r[q].read_offset = string_index - m_r[q].match_len;
-							const int sc = map_seed(w, m_r[q], bin_read, read_len, (uint16_t)sidx, (uint8_t)s_d->direction);
-							max_score = MAXV(sc, max_score);
-						}
-						if (max_score > 35) j -= 7;
-						if (max_score > 256) { if (max_score > 512) skip_next = 1; finish = true; }
-					}
-				}
-			}
-			if (finish) {
-				int top_score = 35;
-				for (uint32_t i = start; i < w.n_anc; i++) top_score = MAXV(top_score, w.anc[i].score);
-				for (uint32_t i = start; i < w.n_anc; i++) w.anc[i].useless = (w.anc[i].score < top_score) ? 1 : 0;
-				const int ovf = ((w.status & DSB_ST_ANC_OVF) && !(st_before & DSB_ST_ANC_OVF)) ? 1 : 0;
-				if (ovf) { w.status &= ~DSB_ST_ANC_OVF; w.n_anc = start; }
-				info[t] = (uint32_t)lane | (start << 6) | ((w.n_anc - start) << 16) | ((uint32_t)skip_next << 26) | ((uint32_t)ovf << 27);
-				active = false;
-			}
-		}
+		if (t >= n_top) break;
+		const uint32_t start = w.n_anc; const int st_before = w.status;
+		// a full scratch: an overflowing walk would overwrite its last slot, which belongs to an earlier island
+		if (start >= DSB_LANE_ANC_CAP) { info[t] = (uint32_t)lane | (start << 6) | (1u << 27); continue; }
+		int flag = fast_island(w, s_d, read_len, top_idx[t]);
+		int ovf = ((w.status & DSB_ST_ANC_OVF) && !(st_before & DSB_ST_ANC_OVF)) ? 1 : 0;
+		if (ovf) { w.status &= ~DSB_ST_ANC_OVF; w.n_anc = start; }
+		info[t] = (uint32_t)lane | (start << 6) | ((w.n_anc - start) << 16) | ((uint32_t)flag << 26) | ((uint32_t)ovf << 27);
 	}
 	w.k.uni = 1;
 	w.anc = main_anc; w.n_anc = main_n0; w.anc_cap = w.anc_cap_main; w.spset = main_sp;
