@@ -53,6 +53,11 @@ class DsbTiming(C.Structure):
                 ("n_heavy_mw", C.c_uint32), ("pad2", C.c_uint32)]
 
 
+class DsbBuildStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_bases", "n_refs", "n_kmer", "n_unitig", "n_rows")] + \
+               [(n, C.c_double) for n in ("parse_s", "sort_s", "graph_s", "walk_s", "rows_s", "tables_s", "write_s", "total_s")]
+
+
 class DsbChunk(C.Structure):
     _fields_ = [("start", C.c_uint64), ("end", C.c_uint64), ("hist_max_before", C.c_uint32), ("rank", C.c_int32)]
 
@@ -62,7 +67,7 @@ EXPORTS = ["dsb_index_open", "dsb_index_close", "dsb_index_n_ref", "dsb_index_re
            "dsb_batch_upload", "dsb_batch_upload_fastq", "dsb_batch_upload_text", "dsb_ctx_set_history", "dsb_host_alloc", "dsb_host_free", "dsb_batch_run", "dsb_batch_fetch", "dsb_batch_timing", "dsb_batch_seeds", "dsb_batch_exist_bits",
            "dsb_format_sam", "dsb_format_des", "dsb_strerror", "dsb_version",
            "dsb_device_count", "dsb_ctx_select_slot", "dsb_ctx_create_multi", "dsb_multi_destroy", "dsb_multi_n", "dsb_multi_ctx",
-           "dsb_multi_reset_history", "dsb_multi_classify_batch", "dsb_shard_plan", "dsb_ctx_use_synthetic_filter", "dsb_synthetic_filter_bit", "dsb_index_prefix_interval"]
+           "dsb_multi_reset_history", "dsb_multi_classify_batch", "dsb_shard_plan", "dsb_ctx_use_synthetic_filter", "dsb_synthetic_filter_bit", "dsb_index_prefix_interval", "dsb_index_build"]
 
 _lib = None
 
@@ -113,6 +118,7 @@ def lib():
     L.dsb_ctx_use_synthetic_filter.argtypes = [C.c_void_p, C.c_uint64, C.c_double]
     L.dsb_synthetic_filter_bit.argtypes = [C.c_int, C.c_uint64, C.c_double]
     L.dsb_index_prefix_interval.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.dsb_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(DsbBuildStats)]
     L.dsb_index_close.restype = None; L.dsb_ctx_destroy.restype = None; L.dsb_ctx_reset_history.restype = None
     L.dsb_strerror.argtypes = [C.c_int]; L.dsb_strerror.restype = C.c_char_p
     L.dsb_version.restype = C.c_char_p
@@ -155,6 +161,16 @@ class Index:
         cc = C.c_uint8(c)
         v = lib().dsb_index_occ_host(self.h, r, C.byref(cc))
         return v, cc.value
+
+
+def build_index(fasta, out_dir, kmer_srt=None, device=0):
+    """`deSAMBA index` on the GPU (build_index_main, src/idx.c:1254-1282): writes the deSAMBA.* files of an index
+    directory from a reference FASTA; kmer_srt=None enumerates the 31-mers from the FASTA itself.  Returns DsbBuildStats."""
+    st = DsbBuildStats()
+    rc = lib().dsb_index_build(kmer_srt.encode() if kmer_srt else None, fasta.encode(), out_dir.encode(), device, C.byref(st))
+    if rc != 0:
+        raise DsbError(rc, "dsb_index_build(%s)" % fasta)
+    return st
 
 
 def make_reads(records):

@@ -482,12 +482,43 @@ static int classify_main(int argc, char **argv)
 	return a.n_status ? 1 : 0;
 }
 
+/* `deSAMBA index [-g DEV] [SortedKmer] <Reference> <IndexDir>` (build_index_main, src/idx.c:1238-1282).  With the
+ * reference's three arguments the k-mer list is read from SortedKmer; with two it is enumerated from the reference text. */
+static int index_main(int argc, char **argv)
+{
+	int c, dev = 0;
+	while ((c = getopt(argc, argv, "k:g:h")) >= 0) {
+		if (c == 'g') dev = atoi(optarg);
+		else if (c == 'h') { optind = argc; break; }
+	}
+	if (optind + 2 > argc) {
+		fprintf(stderr, "\nProgram:   deSAMBA (desamba_amd, MI355X)\nVersion:   %s\n\n", dsb_version());
+		fprintf(stderr, "  Usage:     deSAMBA  index  <Options> [SortedKmer] <Reference> <IndexDir>\n  Basic:     \n");
+		fprintf(stderr, "    [SortedKmer]  FILE   sorted kmers file \"kmer.srt\" generated by \"kmersort\"; without it the 31-mers are taken from the reference\n");
+		fprintf(stderr, "    <Reference>   FILE   one fasta REF file, multiple files need to be combined\n");
+		fprintf(stderr, "    <IndexDir>    FOLDER the directory to store deSAMBA index\n  Options:\n    -g INT        GPU device id [0]\n    -h            help\n\n");
+		return 0;
+	}
+	const char *srt = optind + 3 <= argc ? argv[optind++] : NULL;
+	const char *ref = argv[optind++], *dir = argv[optind++];
+	dsb_build_stats st;
+	int rc = dsb_index_build(srt, ref, dir, dev, &st);
+	if (rc) { fprintf(stderr, "deSAMBA index: %s\n", dsb_strerror(rc)); return 1; }
+	fprintf(stderr, "%lu sequences, %lu bases, %lu 31-mers, Number of UNITIG is [%lu], %lu BWT rows\n", (unsigned long)st.n_refs, (unsigned long)st.n_bases,
+	        (unsigned long)st.n_kmer, (unsigned long)st.n_unitig, (unsigned long)st.n_rows);
+	fprintf(stderr, "index built in %.2fs (read %.2f, k-mers %.2f, graph %.2f, unitigs %.2f, BWT rows %.2f, tables %.2f, write %.2f)\n", st.total_s, st.parse_s,
+	        st.sort_s, st.graph_s, st.walk_s, st.rows_s, st.tables_s, st.write_s);
+	return 0;
+}
+
 #ifndef DSB_CLI_NO_MAIN
 int main(int argc, char **argv)
-{	/* dispatcher, src/main.c:35-53: only `classify` is in scope of this build */
+{	/* dispatcher, src/main.c:35-53: `classify` and `index` are in scope of this build */
+	if (argc >= 2 && strcmp(argv[1], "index") == 0) return index_main(argc - 1, argv + 1);
 	if (argc < 2 || strcmp(argv[1], "classify") != 0) {
 		fprintf(stderr, "\nProgram: deSAMBA (desamba_amd)\nUsage:   deSAMBA classify [options] <IndexDir> <reads...>\n"
-		        "         (kmersort / index / analysis are outside this build: use the reference binary)\n\n");
+		        "         deSAMBA index [-g DEV] [SortedKmer] <Reference> <IndexDir>\n"
+		        "         (kmersort / analysis are outside this build: use the reference binary)\n\n");
 		return argc < 2 ? 0 : 1;
 	}
 	int rc = classify_main(argc - 1, argv + 1);

@@ -1,0 +1,147 @@
+// `deSAMBA index` on the GPU: the stages of dsb_build_impl.h as HIP kernels on gfx950.
+//
+// Every stage is one launch of k_for over k-mers / text chunks / unitigs / BWT rows (atomics only where several
+// iterations mark the same k-mer); the three sorts (all 31-mers of the text, the 30 suffixes per unitig, the
+// unitig -> position pairs) are rocPRIM LSD radix sorts, which are stable -- the order of equal keys is part of the
+// file format (see the header of dsb_build_impl.h); prefix sums are a two-level scan below.  The whole working set of a
+// build lives in HBM at once (about 60 bytes per reference base: 23 GB for a 380-Mbp reference).
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <chrono>
+#include "desamba_amd.h"
+#include "dsb_build_host.h"
+
+#define HIPB(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "desamba_amd: %s: %s\n", #x, hipGetErrorString(e_)); failed = true; } } while (0)
+
+template <class F>
+__global__ void __launch_bounds__(256) k_for(uint64_t n, F f)
+{
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) f(i);
+}
+
+// prefix sum of u32 counts into u64 offsets, tiles of 2048 per workgroup: tile sums, their scan (one workgroup), tiles again
+#define DSB_SCAN_TILE 2048u
+__global__ void __launch_bounds__(256) k_scan_tile_sums(const uint32_t *in, uint64_t n, uint64_t *sums)
+{
+	__shared__ uint64_t red[256];
+	const uint64_t base = (uint64_t)blockIdx.x * DSB_SCAN_TILE;
+	uint64_t s = 0;
+	for (uint32_t q = threadIdx.x; q < DSB_SCAN_TILE; q += 256) if (base + q < n) s += in[base + q];
+	red[threadIdx.x] = s; __syncthreads();
+	for (uint32_t d = 128; d; d >>= 1) { if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
+	if (threadIdx.x == 0) sums[blockIdx.x] = red[0];
+}
+__global__ void __launch_bounds__(256) k_scan_sums(uint64_t *sums, uint64_t m, uint64_t *total)
+{	// one workgroup: each thread scans a contiguous slice, the slice totals are scanned through LDS
+	__shared__ uint64_t part[256];
+	const uint64_t per = (m + 255) / 256, lo = threadIdx.x * per, hi = lo + per < m ? lo + per : m;
+	uint64_t s = 0;
+	for (uint64_t i = lo; i < hi; i++) s += sums[i];
+	part[threadIdx.x] = s; __syncthreads();
+	if (threadIdx.x == 0) { uint64_t a = 0; for (int t = 0; t < 256; t++) { const uint64_t v = part[t]; part[t] = a; a += v; } *total = a; }
+	__syncthreads();
+	uint64_t a = part[threadIdx.x];
+	for (uint64_t i = lo; i < hi; i++) { const uint64_t v = sums[i]; sums[i] = a; a += v; }
+}
+__global__ void __launch_bounds__(256) k_scan_tiles(const uint32_t *in, uint64_t n, const uint64_t *sums, uint64_t *out)
+{
+	__shared__ uint64_t part[256];
+	const uint64_t base = (uint64_t)blockIdx.x * DSB_SCAN_TILE + threadIdx.x * 8u;
+	uint32_t v[8]; uint64_t s = 0;
+	for (int q = 0; q < 8; q++) { v[q] = base + q < n ? in[base + q] : 0u; s += v[q]; }
+	part[threadIdx.x] = s; __syncthreads();
+	for (uint32_t d = 1; d < 256; d <<= 1) {          // inclusive Hillis-Steele over the 256 thread totals
+		const uint64_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0; __syncthreads();
+		part[threadIdx.x] += add; __syncthreads();
+	}
+	uint64_t a = sums[blockIdx.x] + part[threadIdx.x] - s;
+	for (int q = 0; q < 8; q++) { if (base + q < n) out[base + q] = a; a += v[q]; }
+}
+
+struct HipBE {
+	bool failed = false;
+	hipStream_t st = 0;
+	int n_cu = 256;
+	template <class T> T *alloc(size_t n) { void *p = nullptr; HIPB(hipMalloc(&p, (n ? n : 1) * sizeof(T))); return (T *)p; }
+	void free(void *p) { if (p) (void)hipFree(p); }
+	void zero(void *p, size_t bytes) { HIPB(hipMemsetAsync(p, 0, bytes, st)); }
+	void fill_ff(void *p, size_t bytes) { HIPB(hipMemsetAsync(p, 0xff, bytes, st)); }
+	void to_dev(void *d, const void *s, size_t bytes) { HIPB(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, st)); HIPB(hipStreamSynchronize(st)); }
+	void to_host(void *d, const void *s, size_t bytes) { HIPB(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToHost, st)); HIPB(hipStreamSynchronize(st)); }
+	template <class F> void for_n(uint64_t n, F f)
+	{
+		if (!n || failed) return;
+		const uint64_t want = (n + 255) / 256, cap = (uint64_t)n_cu * 32;
+		k_for<<<dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, st>>>(n, f);
+		HIPB(hipGetLastError());
+	}
+	void sort_keys(uint64_t *k, uint64_t n, int bits)
+	{
+		if (n < 2 || failed) return;
+		uint64_t *o = alloc<uint64_t>(n); size_t tb = 0; void *tmp = nullptr;
+		HIPB(rocprim::radix_sort_keys(nullptr, tb, k, o, n, 0, bits, st));
+		HIPB(hipMalloc(&tmp, tb ? tb : 1));
+		HIPB(rocprim::radix_sort_keys(tmp, tb, k, o, n, 0, bits, st));
+		HIPB(hipMemcpyAsync(k, o, n * 8, hipMemcpyDeviceToDevice, st)); HIPB(hipStreamSynchronize(st));
+		free(tmp); free(o);
+	}
+	template <class K, class V> void sort_pairs(K *k, V *v, uint64_t n, int bits)
+	{
+		if (n < 2 || failed) return;
+		K *ko = alloc<K>(n); V *vo = alloc<V>(n); size_t tb = 0; void *tmp = nullptr;
+		HIPB(rocprim::radix_sort_pairs(nullptr, tb, k, ko, v, vo, n, 0, bits, st));
+		HIPB(hipMalloc(&tmp, tb ? tb : 1));
+		HIPB(rocprim::radix_sort_pairs(tmp, tb, k, ko, v, vo, n, 0, bits, st));
+		HIPB(hipMemcpyAsync(k, ko, n * sizeof(K), hipMemcpyDeviceToDevice, st)); HIPB(hipMemcpyAsync(v, vo, n * sizeof(V), hipMemcpyDeviceToDevice, st));
+		HIPB(hipStreamSynchronize(st));
+		free(tmp); free(ko); free(vo);
+	}
+	void sort_pairs_u32(uint32_t *k, uint64_t *v, uint64_t n, int bits) { sort_pairs(k, v, n, bits); }
+	void sort_pairs_u64(uint64_t *k, uint32_t *v, uint64_t n, int bits) { sort_pairs(k, v, n, bits); }
+	uint64_t exscan(const uint32_t *in, uint64_t *out, uint64_t n)
+	{
+		if (!n || failed) return 0;
+		const uint64_t m = (n + DSB_SCAN_TILE - 1) / DSB_SCAN_TILE;
+		uint64_t *sums = alloc<uint64_t>(m + 1);
+		k_scan_tile_sums<<<dim3((unsigned)m), dim3(256), 0, st>>>(in, n, sums);
+		k_scan_sums<<<dim3(1), dim3(256), 0, st>>>(sums, m, sums + m);
+		k_scan_tiles<<<dim3((unsigned)m), dim3(256), 0, st>>>(in, n, sums, out);
+		HIPB(hipGetLastError());
+		uint64_t total = 0; to_host(&total, sums + m, 8);
+		free(sums);
+		return total;
+	}
+	double now() { (void)hipStreamSynchronize(st); return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+
+static double wall() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// replaces build_index_main (src/idx.c:1254-1282)
+extern "C" int dsb_index_build(const char *kmer_srt, const char *fasta, const char *out_dir, int device, dsb_build_stats *stats)
+{
+	if (!fasta || !out_dir) return DSB_EINVAL;
+	int n_dev = 0;
+	if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return DSB_ENODEV;
+	hipDeviceProp_t prop;
+	if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) return DSB_ENODEV;
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { fprintf(stderr, "desamba_amd: device %d is %s, this library is built for gfx950 only\n", device, prop.gcnArchName); return DSB_ENODEV; }
+	const double t_all = wall();
+	DsbBuildIn in; DsbBuildOut out;
+	double t0 = wall();
+	if (dsb_build_read_fasta(fasta, in)) return DSB_EIO;
+	if (kmer_srt && *kmer_srt && dsb_build_read_kmers(kmer_srt, in)) return DSB_EIO;
+	const double t_parse = wall() - t0;
+	HipBE be; be.n_cu = prop.multiProcessorCount;
+	const int rc = dsb_build_run(be, in, out);
+	if (be.failed) return DSB_ENODEV;
+	if (rc) return rc;
+	t0 = wall();
+	if (dsb_build_write(in, out, out_dir)) return DSB_EIO;
+	if (stats) {
+		stats->n_bases = in.code.size(); stats->n_refs = in.refs.size(); stats->n_kmer = out.n_kmer; stats->n_unitig = out.n_uni; stats->n_rows = out.n_rows;
+		stats->parse_s = t_parse; stats->sort_s = out.t_sort; stats->graph_s = out.t_graph; stats->walk_s = out.t_walk; stats->rows_s = out.t_rows;
+		stats->tables_s = out.t_tables; stats->write_s = wall() - t0; stats->total_s = wall() - t_all;
+	}
+	return DSB_OK;
+}

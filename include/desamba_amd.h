@@ -100,6 +100,20 @@ typedef struct {
 } dsb_timing;
 
 /* load_idx (src/idx.c:1103-1160, src/bwt.c:68-104): read <dir>/deSAMBA.* into host memory */
+/* Index construction on the GPU -- replaces build_index_main (src/idx.c:1254-1282: `deSAMBA index [SortedKmer]
+ * [Reference] [IndexDir]`, i.e. build_UNITIG src/idx.c:884, build_BWT src/bwt.c:269, bwt_cal_SA src/idx.c:1163,
+ * get_EXIST_kmer src/idx.c:986, write_idx src/idx.c:1046) and, with kmer_srt = NULL, the Jellyfish + kmersort steps in
+ * front of it (src/idx_sort.c:298-401): the 31-mers are then enumerated from the reference text itself.
+ * fasta: plain or gzip FASTA read with the reference's reader rules; out_dir is created; the ten deSAMBA.* files
+ * written are byte-identical to the reference's (.ref_i: the reference leaves the padding behind each name
+ * uninitialised; zeros here).  Limits: < 2^32 distinct 31-mers, < 2^32 / 30 unitigs.  DSB_EINVAL: reference shorter than
+ * 31 bases, a k-mer of the text missing from kmer_srt, or a unitig cycle the reference's builder does not handle either. */
+typedef struct {
+	uint64_t n_bases, n_refs, n_kmer, n_unitig, n_rows;
+	double parse_s, sort_s, graph_s, walk_s, rows_s, tables_s, write_s, total_s;
+} dsb_build_stats;
+int  dsb_index_build(const char *kmer_srt, const char *fasta, const char *out_dir, int device, dsb_build_stats *stats);
+
 int  dsb_index_open(const char *dir, dsb_index **idx);
 void dsb_index_close(dsb_index *idx);
 /* reference names / lengths for the SAM writer (REF_INFO, src/idx.h:15-19) */

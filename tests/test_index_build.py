@@ -1,0 +1,135 @@
+"""Index construction (`deSAMBA index`): the files written must be those of the reference's builder.
+
+Golden digests (tests/golden/build/*.md5.json, made by tests/golden/make_build_golden.py from the reference binary)
+for small synthetic references, and the demo index's md5s.  CPU tests run the builder's stages in the
+host emulation (tests/emu/emu_build.cpp: the same dsb_build_impl.h the GPU runs); GPU tests go through
+dsb_index_build / the CLI."""
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+import zipfile
+
+import pytest
+
+import build_lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "build")
+CASES = ["graph1", "graph2", "graph3", "reader"]
+# md5 of the demo index files as the reference builds them (stable across rebuilds)
+DEMO_MD5 = {".bwt": "1532b15ccccbf7268386e2758000f5c2", ".exk0": "000472fabf9c519d075726634427736f", ".exk1": "bbbd736229d6b4a3e21c494f094c0ac4",
+            ".exki": "02ae172ff75582d3f4ffda7001e7d849", ".sa": "aaef536051f4d95e1370844a1be230dc", ".ref_b": "8e603575e9d0e4116e7d2b3e3369a750",
+            ".ref_p": "00ef48f10125466085d1d8149579e0e1", ".unv": "14f1f3e67a4460e8c925c7108c740533", ".acg": "0c231610f8892d7042b5ea5dd4eef4ec"}
+
+
+def md5_file(p):
+    h = hashlib.md5()
+    with open(p, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def demo_fasta(tmp_path):
+    zipfile.ZipFile(os.path.join(ROOT, "tests", "golden", "demo", "viral-gs.zip")).extractall(tmp_path)
+    return str(tmp_path / "viral-gs.fa")
+
+
+def check_case(name, out):
+    want = json.load(open(os.path.join(GOLD, name + ".md5.json")))
+    got = build_lib.digest_dir(out)
+    assert got == want, {k: (got[k], want[k]) for k in want if got[k] != want[k]}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_emulated_stages_write_the_reference_files(name, tmp_path):
+    """branching graphs, reverse complements, N runs, repeats, runs of exactly 31 / 30 bases, empty and tiny records,
+    duplicates (graph*); CRLF, blank lines, '@' headers, a FASTQ record (reader): gzip FASTA in, every file's digest out"""
+    out = str(tmp_path / "idx")
+    build_lib.emu_build(os.path.join(GOLD, name + ".fa.gz"), out)
+    check_case(name, out)
+
+
+def test_supplied_kmer_list_gives_the_same_index(tmp_path):
+    """`index kmer.srt ref.fa dir` (the reference's form): the k-mer list is read, not enumerated"""
+    text = gzip.open(os.path.join(GOLD, "graph1.fa.gz")).read()
+    srt = str(tmp_path / "kmer.srt")
+    build_lib.write_kmer_srt_from_text(build_lib.reader_view(text), srt)
+    out = str(tmp_path / "idx")
+    build_lib.emu_build(os.path.join(GOLD, "graph1.fa.gz"), out, kmer_srt=srt)
+    check_case("graph1", out)
+
+
+def test_kmer_missing_from_a_supplied_list_is_an_error(tmp_path):
+    """the reference asserts (binSearch, src/idx.c:84-96); here the build returns an error"""
+    text = gzip.open(os.path.join(GOLD, "graph1.fa.gz")).read()
+    recs = build_lib.reader_view(text)
+    srt = str(tmp_path / "kmer.srt")
+    build_lib.write_kmer_srt_from_text(recs[1:], srt)
+    with pytest.raises(RuntimeError):
+        build_lib.emu_build(os.path.join(GOLD, "graph1.fa.gz"), str(tmp_path / "idx"), kmer_srt=srt)
+
+
+def test_reader_view_of_the_awkward_fasta():
+    """the plain-Python restatement of the reader used to make the reader case's k-mer list sees what the reference saw
+    (names and lengths are pinned by the golden .ref_i digest; this spells them out)"""
+    recs = build_lib.reader_view(gzip.open(os.path.join(GOLD, "reader.fa.gz")).read())
+    names = [n for n, _ in recs[:5]]
+    assert names == [b"crlf", b"blank", b"atsign", b"fastq", b"after"]
+    assert [len(s) for _, s in recs[:5]] == [70 + 1 + 64 + 1, 80 + 1 + 17 + 75, 140, 120, 133]       # '\r' kept; '\n' + the swallowed header line
+
+
+def test_emulated_stages_rebuild_the_demo_index(tmp_path):
+    """the 463-genome demo reference (11.5 Mbp): all nine md5s of SURVEY.md 8c"""
+    out = str(tmp_path / "idx")
+    st = build_lib.emu_build(demo_fasta(tmp_path), out)
+    assert st[0] == 10982489 and st[3] == 463
+    got = {e: md5_file(os.path.join(out, "deSAMBA" + e)) for e in DEMO_MD5}
+    assert got == DEMO_MD5
+
+
+# ---------------------------------------------------------------- GPU: through the C ABI and the CLI
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_build_writes_the_reference_files(name, tmp_path):
+    import desamba_amd as D
+    out = str(tmp_path / "idx")
+    st = D.build_index(os.path.join(GOLD, name + ".fa.gz"), out)
+    assert st.n_rows == json.load(open(os.path.join(GOLD, name + ".md5.json")))["n_rows"]
+    check_case(name, out)
+
+
+@pytest.mark.gpu
+def test_gpu_build_of_the_demo_index_and_classify_on_it(tmp_path):
+    """dsb_index_build on the demo reference: the nine md5s; then `deSAMBA classify` of the demo reads on THAT index
+    gives the demo SAM (md5 1da908b6...)"""
+    import desamba_amd as D
+    fa = demo_fasta(tmp_path)
+    out = str(tmp_path / "idx")
+    st = D.build_index(fa, out)
+    print("demo index built in %.2f s (read %.2f, k-mers %.2f, graph %.2f, unitigs %.2f, rows %.2f, tables %.2f, write %.2f)" %
+          (st.total_s, st.parse_s, st.sort_s, st.graph_s, st.walk_s, st.rows_s, st.tables_s, st.write_s))
+    assert st.n_kmer == 10982489 and st.n_refs == 463
+    got = {e: md5_file(os.path.join(out, "deSAMBA" + e)) for e in DEMO_MD5}
+    assert got == DEMO_MD5
+    zipfile.ZipFile(os.path.join(ROOT, "tests", "golden", "demo", "ERR1050068.zip")).extractall(tmp_path)
+    sam = str(tmp_path / "out.sam")
+    subprocess.run([os.path.join(ROOT, "desamba_amd", "bin", "deSAMBA"), "classify", out, str(tmp_path / "ERR1050068.fastq"), "-o", sam], check=True, stderr=subprocess.DEVNULL)
+    assert md5_file(sam) == open(os.path.join(ROOT, "tests", "golden", "demo_sam.md5")).read().split()[0]
+
+
+@pytest.mark.gpu
+def test_cli_index_with_and_without_a_kmer_list(tmp_path):
+    """`deSAMBA index [SortedKmer] <Reference> <IndexDir>` (build_index_main, src/idx.c:1254-1282)"""
+    cli = os.path.join(ROOT, "desamba_amd", "bin", "deSAMBA")
+    fa = os.path.join(GOLD, "graph2.fa.gz")
+    subprocess.run([cli, "index", fa, str(tmp_path / "a")], check=True, stderr=subprocess.DEVNULL)
+    check_case("graph2", str(tmp_path / "a"))
+    srt = str(tmp_path / "kmer.srt")
+    build_lib.write_kmer_srt_from_text(build_lib.reader_view(gzip.open(fa).read()), srt)
+    subprocess.run([cli, "index", srt, fa, str(tmp_path / "b")], check=True, stderr=subprocess.DEVNULL)
+    check_case("graph2", str(tmp_path / "b"))
+    assert subprocess.run([cli, "index", str(tmp_path / "nope.fa"), str(tmp_path / "c")], stderr=subprocess.DEVNULL).returncode == 1
