@@ -10,7 +10,8 @@
 //     src/idx.c:126-239), first / last k-mers of ACGT runs ("heads", "tails"); a k-mer starts a unitig when it has not
 //     exactly one predecessor, is a head, or follows a k-mer that ends one; it ends one symmetrically (setLabel,
 //     src/idx.c:386-505) -- one pass over text windows with atomic ORs, one pass over k-mers;
-//   * unitigs, numbered by the rank of their first k-mer (get_uni_v_worker, src/idx.c:719-766): one walk per unitig;
+//   * unitigs, numbered by the rank of their first k-mer (get_uni_v_worker, src/idx.c:719-766): read off the text, no graph
+//     walks (see stage 3);
 //   * the BWT of  u_0 # u_1 # ... u_{n-1} $  ordered by 31-mer context.  The reference makes, per unitig, the 30 proper
 //     suffixes of its last k-mer ("special k-mers", genSpKmers src/idx.c:507-519), sorts them with '#' below 'A'
 //     (spkmer_cmp_l, src/idx.c:858-881) and merges them into the k-mer list (merge_kmer, src/idx.c:313-361).  A suffix of
@@ -222,36 +223,57 @@ int dsb_build_run(B &be, const DsbBuildIn &in, DsbBuildOut &out)
 	const uint64_t n_uni = be.exscan(flag, uid_of, n);
 	if (n_uni == 0 || n_uni * 30 >= 0xfffffff0ULL) return -4;
 	out.n_uni = n_uni;
-	uint64_t *ustart_k = be.template alloc<uint64_t>(n_uni);           // k-mer index of the first k-mer of each unitig
-	be.for_n(n, DSB_LAMBDA(uint64_t i) { if (flag[i]) ustart_k[uid_of[i]] = i; });
 	be.free(flag);
 	out.t_graph = be.now() - t0; t0 = be.now();
 
-	// ---- 3. one walk per unitig: length, last k-mer, and for every k-mer its place (unitig, offset) and BWT symbol
+	// ---- 3. unitigs.  The reference walks the graph from every start k-mer (get_uni_v_worker, src/idx.c:719-766) -- one
+	// dependent search per k-mer, as long as the longest unitig.  But a unitig is also a stretch of TEXT: a k-mer that is
+	// not a start has one predecessor in the graph, so every occurrence of it in the text is preceded by that k-mer, and
+	// the windows from a start k-mer up to the next end k-mer spell the unitig wherever it occurs.  So: every window
+	// belongs to the unitig of the nearest start window at or before it (the first window of an ACGT run is a head, hence
+	// a start), at offset = distance to it; all occurrences of a k-mer agree on (unitig, offset, base before it).
+	// Nearest start before a chunk: last start of each chunk, carried across chunks on the host (n_chunk values).
 	uint32_t *ulen = be.template alloc<uint32_t>(n_uni + 1);
 	uint64_t *uend = be.template alloc<uint64_t>(n_uni);
 	uint32_t *kpos = be.template alloc<uint32_t>(2 * n);
-	be.for_n(n_uni, DSB_LAMBDA(uint64_t u) {
-		uint64_t loc = ustart_k[u];
-		info[loc] |= (u == 0 ? 5u : 4u) << 10;           // '$' before the very first unitig, '#' before the others (src/idx.c:733,754)
-		kpos[2 * loc] = (uint32_t)u; kpos[2 * loc + 1] = 0;
-		uint32_t len = DSB_BK;
-		while (!(info[loc] & DSB_I_END) && len < 0x7fffffffu) {
-			const uint64_t v = kv[loc];
-			const uint32_t nxt = (uint32_t)__builtin_ctz(info[loc] & 0xfu);
-			loc = b_rank(kv, pre, ((v << 2) & DSB_BK_MASK) | nxt);
-			info[loc] |= (uint32_t)(v >> 60) << 10;
-			kpos[2 * loc] = (uint32_t)u; kpos[2 * loc + 1] = len - (DSB_BK - 1);
-			len++;
-		}
-		ulen[u] = len; uend[u] = kv[loc];
+	uint64_t *cs = be.template alloc<uint64_t>(2 * n_chunk);               // per chunk: position + 1 of its last start window (0: none), and that unitig
+	be.for_n(n_chunk, DSB_LAMBDA(uint64_t ch) {
+		const uint64_t g0 = ch * DSB_BCHUNK, g1 = g0 + DSB_BCHUNK < N ? g0 + DSB_BCHUNK : N;
+		uint64_t at = 0, u = 0;
+		b_windows(code, N, g0, g1, [&](uint64_t g, uint64_t key) {
+			const uint64_t loc = b_rank(kv, pre, key);
+			if (info[loc] & DSB_I_START) { at = g + 1; u = uid_of[loc]; }
+		});
+		cs[2 * ch] = at; cs[2 * ch + 1] = u;
 	});
+	{
+		std::vector<uint64_t> h(2 * n_chunk);
+		be.to_host(h.data(), cs, 16 * n_chunk);
+		uint64_t at = 0, u = 0;
+		for (uint64_t ch = 0; ch < n_chunk; ch++) { const uint64_t a2 = h[2 * ch], u2 = h[2 * ch + 1]; h[2 * ch] = at; h[2 * ch + 1] = u; if (a2) { at = a2; u = u2; } }
+		be.to_dev(cs, h.data(), 16 * n_chunk);
+	}
+	be.for_n(n_chunk, DSB_LAMBDA(uint64_t ch) {
+		const uint64_t g0 = ch * DSB_BCHUNK, g1 = g0 + DSB_BCHUNK < N ? g0 + DSB_BCHUNK : N;
+		uint64_t at = cs[2 * ch], u = cs[2 * ch + 1];
+		b_windows(code, N, g0, g1, [&](uint64_t g, uint64_t key) {
+			const uint64_t loc = b_rank(kv, pre, key);
+			const uint32_t f = info[loc];
+			if (f & DSB_I_START) { at = g + 1; u = uid_of[loc]; }
+			const uint32_t p = (uint32_t)(g + 1 - at);
+			kpos[2 * loc] = (uint32_t)u; kpos[2 * loc + 1] = p;
+			// BWT symbol: the base before the k-mer in its unitig; '$' before the very first unitig, '#' before the others (src/idx.c:733,754)
+			b_or32(&info[loc], (p ? (uint32_t)(code[g - 1] & 3u) : (u == 0 ? 5u : 4u)) << 10);
+			if (f & DSB_I_END) { ulen[u] = p + DSB_BK; uend[u] = key; }
+		});
+	});
+	be.free(cs);
 	uint64_t *uoff = be.template alloc<uint64_t>(n_uni + 1);             // where each unitig starts in the unitig string
 	uint32_t *ulen1 = be.template alloc<uint32_t>(n_uni);
 	be.for_n(n_uni, DSB_LAMBDA(uint64_t u) { ulen1[u] = ulen[u] + 1; });
 	const uint64_t n_rows = be.exscan(ulen1, uoff, n_uni);
 	be.free(ulen1);
-	if (n_rows != n + 31 * n_uni) return -4;                             // a k-mer no walk reached: a cycle without a start
+	if (n_rows != n + 31 * n_uni) return -4;                             // (every k-mer lies in exactly one unitig)
 	out.n_rows = n_rows;
 	uint8_t *ustr = be.template alloc<uint8_t>(n_rows);
 	be.for_n(n, DSB_LAMBDA(uint64_t i) {
@@ -407,7 +429,7 @@ int dsb_build_run(B &be, const DsbBuildIn &in, DsbBuildOut &out)
 	be.to_host(hs.data(), hstart, DSB_PRE_N * 8); be.to_host(hc.data(), hcnt, DSB_PRE_N * 4);
 	std::vector<uint32_t> h_ulen(n_uni), h_ru_u(n_ru); std::vector<uint64_t> h_ru_g(n_ru);
 	be.to_host(h_ulen.data(), ulen, n_uni * 4); be.to_host(h_ru_u.data(), ru_u, n_ru * 4); be.to_host(h_ru_g.data(), ru_g, n_ru * 8);
-	for (void *p : {(void *)code, (void *)kv, (void *)pre, (void *)info, (void *)miss, (void *)uid_of, (void *)ustart_k, (void *)ulen, (void *)uend, (void *)kpos,
+	for (void *p : {(void *)code, (void *)kv, (void *)pre, (void *)info, (void *)miss, (void *)uid_of, (void *)ulen, (void *)uend, (void *)kpos,
 	                (void *)uoff, (void *)ustr, (void *)ru_u, (void *)ru_g, (void *)spk, (void *)spi, (void *)bw, (void *)sa, (void *)hstart, (void *)hcnt,
 	                (void *)bh, (void *)bs, (void *)blocks, (void *)ek0, (void *)ek1, (void *)refb}) be.free(p);
 
