@@ -28,6 +28,7 @@ import ctypes as C
 import json
 import os
 import re
+import shutil
 import statistics
 import subprocess
 import sys
@@ -130,6 +131,66 @@ def cpu_baseline(index_dir, sample_fq, n_sample, bases, gpu_sam):
     return base, parity
 
 
+def second_index(a, D, L, local, gen_threads):
+    """A second, larger index made inside the bench: a synthetic strain collection (tools/synth_ref.py: base genomes,
+    0-3 strains each at 0.5-4 % divergence, mobile elements, tandem repeats of unit length >= 12 -- no dinucleotide
+    repeats) is indexed by THIS repo's builder on the GPU (dsb_index_build), then 50-kbp reads simulated from it are
+    classified; a sample of the reads is compared with the reference binary (UB-pinned build) on the same index."""
+    d = os.path.join(ROOT, "data", "bench_strain")
+    shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
+    fa = os.path.join(d, "syn.fa"); idxd = os.path.join(d, "index")
+    t0 = time.perf_counter()
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "synth_ref.py"), fa, str(a.second_index_mbp), "11", "3", "60", "12"], check=True, stderr=subprocess.DEVNULL)
+    t_syn = time.perf_counter() - t0
+    st = D.build_index(fa, idxd, device=local)
+    os.remove(fa)
+    t0 = time.perf_counter()
+    idx2 = D.Index(idxd); gen2 = Gen(idxd)
+    n = a.second_index_reads; Lr = 50000
+    cap = n * (2 * Lr + 40) + (1 << 20)
+    p = L.dsb_host_alloc(cap)
+    nb, off, ln = gen2.fill(p, cap, n, Lr, 0.15, 777, gen_threads)
+    ctx = D.Ctx(idx2, local, max_read_len=Lr, max_batch_reads=n)
+    ctx.upload_text(p, nb, off, ln, n)
+    t_open = time.perf_counter() - t0
+    ms = []; tm = None
+    for _ in range(4):
+        ctx.run(); tm = ctx.timing(); ms.append(tm.total_ms)
+    med = sorted(ms[1:])[1]
+    res = ctx.fetch(strict=False)
+    out = {"workload": "%d synthetic 50000 bp ONT-15%%-error reads on a %.0f-Mbp synthetic strain index (%d sequences, exist-k-mer length %d) built by this repo's GPU builder"
+                       % (n, st.n_bases / 1e6, st.n_refs, L.dsb_index_ek_len(idx2.h)),
+           "index_build": {"seconds": st.total_s, "stages_s": {"read_fasta": st.parse_s, "kmers_sort": st.sort_s, "graph": st.graph_s, "unitigs": st.walk_s, "bwt_rows": st.rows_s,
+                                                               "tables_and_copy": st.tables_s, "write_files": st.write_s},
+                           "bases": st.n_bases, "kmers_31": st.n_kmer, "unitigs": st.n_unitig, "bwt_rows": st.n_rows, "mbp_per_s": st.n_bases / 1e6 / st.total_s,
+                           "reference_generation_s": t_syn},
+           "open_stage_generate_s": t_open,
+           "reads_per_s": n / (med / 1e3), "gbp_per_s": n * Lr / (med / 1e3) / 1e9, "ms_per_step": med,
+           "kernel_ms": {"k_encode": tm.encode_ms, "order": tm.order_ms, "seed": tm.seed_probe_ms, "k_classify": tm.classify_ms, "tail": tm.tail_ms},
+           "reads_in_second_run": tm.n_retry, "reads_mapped_frac": sum(1 for i in range(n) if res.reads[i].n > 0) / float(n),
+           "reads_with_device_status": sum(1 for i in range(n) if res.reads[i].status != 0), "parity_sample": None}
+    ubf = os.path.join(ROOT, "oracle", "_ref", "deSAMBA_ubfree")
+    ns = min(a.second_index_parity_reads, n)
+    if ns and os.path.exists(ubf):
+        raw = C.string_at(p, off[ns - 1] + 2 * Lr + 8)
+        names = []; pos = 0
+        for i in range(ns):
+            e = raw.index(b"\n", pos); names.append(raw[pos + 1:e]); pos = off[i] + 2 * ln[i] + 4
+        reads = D.make_reads([(names[i], raw[off[i]:off[i] + ln[i]], None) for i in range(ns)])
+        gpu = sam_by_read(D.format_sam(idx2, reads, res))
+        sample = os.path.join(d, "sample.fq")
+        with open(sample, "wb") as f:
+            f.write(raw[:pos])
+        secs = run_ref(ubf, idxd, sample, sample + ".sam", len(os.sched_getaffinity(0)))
+        if secs is not None:
+            ub = sam_by_read(sample + ".sam")
+            out["parity_sample"] = {"reads": ns, "gpu_vs_ubpinned_differing_reads": sum(1 for k in ub if gpu.get(k) != ub[k]) + sum(1 for k in gpu if k not in ub),
+                                    "reference_seconds": secs, "reference_reads_per_s": ns / secs}
+    ctx.close(); idx2.close(); L.dsb_host_free(p)
+    shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +204,10 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-short-reads", action="store_true", help="skip the 1 M x 150 bp measurement (BASELINE configs[2] shape)")
     ap.add_argument("--no-seed-hbm", action="store_true", help="skip the seed-lookup measurement on synthetic multi-GiB filter tables")
+    ap.add_argument("--no-second-index", action="store_true", help="skip building and measuring the second (synthetic strain) index")
+    ap.add_argument("--second-index-mbp", type=int, default=320)
+    ap.add_argument("--second-index-reads", type=int, default=16384)
+    ap.add_argument("--second-index-parity-reads", type=int, default=256)
     ap.add_argument("--seed-hbm-mib", type=int, default=2048, help="size of each synthetic filter table (MiB, power of two 128 .. 16384)")
     ap.add_argument("--slots", type=int, default=0, help="reads in flight per GPU (0 = library default)")
     a = ap.parse_args()
@@ -354,6 +419,10 @@ def main():
                  "reads_mapped_frac": sum(1 for i in range(0, n2, 64) if r4.reads[i].n > 0) / (n2 / 64.0)}
         ctx4.close(); L.dsb_host_free(p2)
 
+    second = None
+    if rank == 0 and not a.no_second_index:
+        second = second_index(a, D, L, local, gen_threads)
+
     if rank == 0:
         steps = max(a.steps, 1)
         value = R * world * a.steps / dt
@@ -400,6 +469,7 @@ def main():
             "roofline_seed_lookup": roof_seed,
             "roofline_seed_lookup_hbm": seed_hbm,
             "config2_short_reads": short,
+            "second_index": second,
             "end_to_end": e2e,
             "reads_mapped_frac": n_mapped / max(R, 1), "reads_with_device_status": n_bad,
             "per_read_wave_us": {"mean": sum(dev_us) / max(len(dev_us), 1), "median": dev_us[len(dev_us) // 2] if dev_us else 0,

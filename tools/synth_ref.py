@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Deterministic synthetic reference collection for index-size experiments:
-`synth_ref.py <out.fa> <Mbp> [seed [tandem_hi unit_hi]]` writes about <Mbp> million bases of FASTA: random base genomes of
+`synth_ref.py <out.fa> <Mbp> [seed [tandem_hi unit_hi [unit_lo]]]` writes about <Mbp> million bases of FASTA: random base genomes of
 60-400 kbp, each followed by 0-3 strains that differ from it by 0.5-4 % substitutions and a few short
 indels (so the de Bruijn graph branches the way a RefSeq collection does), a pool of 1-4 kbp mobile elements
 copied into random genomes, and short tandem repeats (0..tandem_hi-1 per genome, default 3, unit length
-2..unit_hi-1, default 60).  Headers follow the reference's
-`>tid|<n>|ref|<name>` convention.  The index itself is built by the reference binary."""
+unit_lo..unit_hi-1, default 2..59).  Headers follow the reference's
+`>tid|<n>|ref|<name>` convention."""
 import sys
 import numpy as np
 
@@ -15,6 +15,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     tandem_hi = int(sys.argv[4]) if len(sys.argv) > 4 else 3
     unit_hi = int(sys.argv[5]) if len(sys.argv) > 5 else 60
+    unit_lo = int(sys.argv[6]) if len(sys.argv) > 6 else 2
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
     mobile = [rng.integers(0, 4, rng.integers(1000, 4000), dtype=np.uint8) for _ in range(64)]
     total, target, gid = 0, int(mbp * 1e6), 0
@@ -38,7 +39,7 @@ def main():
                 p = int(rng.integers(0, n - len(m)))
                 g[p:p + len(m)] = m
             for _ in range(int(rng.integers(0, tandem_hi))):     # tandem repeats
-                unit = rng.integers(0, 4, int(rng.integers(2, unit_hi)), dtype=np.uint8)
+                unit = rng.integers(0, 4, int(rng.integers(unit_lo, unit_hi)), dtype=np.uint8)
                 ln = int(rng.integers(200, 3000))
                 p = int(rng.integers(0, n - ln))
                 g[p:p + ln] = np.resize(unit, ln)
