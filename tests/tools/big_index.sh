@@ -1,6 +1,6 @@
 #!/bin/bash
 # Index-size experiment on a GPU box: a synthetic reference collection of <Mbp> million bases
-# (tools/synth_ref.py) is indexed by the reference binary, then the CLI of this repo runs against the reference's
+# (tools/synth_ref.py) is indexed by `deSAMBA index` of this repo (byte-identical to the reference's, tests/tools/big_build.sh), then the CLI of this repo runs against the reference's
 # UB-pinned build on reads simulated from it, byte for byte, and the device path is timed kernel by kernel.
 # >= 240 Mbp moves the exist tables to 2 x 256 MiB and the exist-k-mer length to 17 (src/idx.c:988-989,971).
 #   tests/tools/big_index.sh [outdir] [Mbp]
@@ -10,10 +10,8 @@ R=oracle/_ref/deSAMBA_ubfree; G=desamba_amd/bin/deSAMBA; I=$D/index; T=$(nproc)
 TIMEFORMAT="%R"
 if [ ! -f $I/deSAMBA.ref_p ]; then
 	python3 tools/synth_ref.py $D/syn.fa $MBP 1 2>&1
-	t1=$( { time oracle/_ref/kmer_srt $D/syn.fa $D/kmer.srt > "$OUT/big_kmer.log" 2>&1; } 2>&1 )
-	t2=$( { time oracle/_ref/deSAMBA index $D/kmer.srt $D/syn.fa $I > "$OUT/big_build.log" 2>&1; } 2>&1 )
-	rm -f $D/kmer.srt
-	echo "index built by the reference: k-mer list ${t1}s, index ${t2}s; $(du -sm $I | cut -f1) MB; exist-k-mer length $(grep -o 'l_e_kmer: [0-9]*' "$OUT/big_build.log")"
+	t1=$( { time $G index $D/syn.fa $I > /dev/null 2> "$OUT/big_build.log"; } 2>&1 )
+	echo "index built by this repo's builder in ${t1}s wall ($(tail -1 "$OUT/big_build.log")); $(du -sm $I | cut -f1) MB"
 fi
 for cfg in "ont50k 16384 50000 0.15 1 ont" "ngs150 500000 150 0.01 7 ngs" "pacbio 32768 12000 0.12 9 pacbio"; do
 	set -- $cfg
