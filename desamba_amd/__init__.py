@@ -50,7 +50,7 @@ class DsbTiming(C.Structure):
                 ("n_regrow", C.c_uint32), ("seed_scan", C.c_uint32),
                 ("n_occ", C.c_uint64), ("n_mem", C.c_uint64), ("n_sa", C.c_uint64), ("ref_bases", C.c_uint64),
                 ("main_occ", C.c_uint64), ("main_mem", C.c_uint64), ("main_sa", C.c_uint64), ("main_ref_bases", C.c_uint64),
-                ("n_heavy_mw", C.c_uint32), ("pad2", C.c_uint32)]
+                ("n_heavy_mw", C.c_uint32), ("n_requeue", C.c_uint32)]
 
 
 class DsbBuildStats(C.Structure):

@@ -51,6 +51,7 @@ struct DsbDevIndex {
 	int filter_min_length, filter_min_score, filter_min_score_LV3;
 	uint32_t sms_cap;          // entries of the per-wave match-node arena (sized from the longest read of the batch)
 	uint32_t step_limit;       // loop budget per read of this launch (DSB_STEP_LIMIT; 16x in the second run)
+	uint32_t heavy_limit;      // predecessors the sparse DP of a read may scan on a single wavefront before the read is handed to k_classify_heavy (0: no limit)
 };
 
 // ---- per-read records produced on the device -------------------------------------------------
@@ -83,6 +84,7 @@ struct DsbReadOut { uint32_t first, n; int32_t status; uint32_t fast; uint32_t n
 #define DSB_TPAD_VAL 4
 #define DSB_ANC_CAP 8192
 #define DSB_STEP_LIMIT 20000000u
+#define DSB_HEAVY_PREDS 100000000u   /* default of DsbDevIndex.heavy_limit for first-run launches (env DSB_HEAVY_PREDS) */
 #define DSB_HIT_CAP 4096
 #define DSB_SMS_CAP 16384
 // The extension loops keep every match node of one uninterrupted extension (src/cly.c:2532-2819, a kvec there), so the
@@ -98,3 +100,4 @@ static inline uint32_t dsb_sms_cap_for(uint32_t max_len) { uint32_t c = 2 * max_
 #define DSB_ST_SMS_OVF 4
 #define DSB_ST_OUT_OVF 8
 #define DSB_ST_TIMEOUT 16   // the per-read loop budget ran out (guards the grid against a spinning wave)
+#define DSB_ST_HEAVY 32     // the sparse DP of this read scanned more than heavy_limit predecessors on one wavefront: it is run again on several (not an error)

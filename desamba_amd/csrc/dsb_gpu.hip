@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	w.win_mid = slot + ar.off_win; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;         \
 	w.lane_anc = (DsbAnchor *)(slot + ar.off_lane_anc); w.lane_spset = (uint64_t *)(slot + ar.off_lane_sp);             \
 	w.top_idx = (uint32_t *)(slot + ar.off_top); w.round_info = (uint32_t *)(slot + ar.off_round);                      \
-	w.anc_cap = ar.anc_cap; w.anc_cap_main = ar.anc_cap; w.hit_cap = ar.hit_cap; w.step_limit = x.step_limit; w.sp_gen = 0; w.mw = nullptr; w.n_waves = 1;                                                                            \
+	w.anc_cap = ar.anc_cap; w.anc_cap_main = ar.anc_cap; w.hit_cap = ar.hit_cap; w.step_limit = x.step_limit; w.heavy_limit = x.heavy_limit; w.sp_gen = 0; w.mw = nullptr; w.n_waves = 1;                                                                            \
 	/* visited-row sets are generation-tagged: clear them once per launch */                                          \
 	for (uint32_t i = lane; i < (uint32_t)THREADS * DSB_SPHASH; i += THREADS) w.lane_spset[i] = 0;                       \
 	for (uint32_t i = lane; i < DSB_SPHASH; i += THREADS) w.spset[i] = 0;                                                \
@@ -435,7 +435,10 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	/* group_mode (short reads with seed lists from k_seed_scan): a work item is 64 reads -- the anchor stage of one read per  \
 	   lane (fast_classify_lane), then the reads one after the other on the whole wavefront from those anchors; a read     \
 	   whose anchors outgrew its lane scratch is done afterwards the usual way (pass 1) */                                  \
+	/* Group g takes the reads at positions g, g + n_groups, g + 2 n_groups, ... of the (heaviest-first) order: 64         \
+	   consecutive positions would put the 64 heaviest reads of the batch into one group, on one wavefront */             \
 	const unsigned int n_grp = (group_mode && seed_blob) ? 64u : 1u;                                                    \
+	const unsigned int n_groups = (n_items > item_base ? n_items - item_base + 63u : 0u) / 64u;   /* (positions below item_base belong to the early launch) */ \
 	for (;;) {                                                                                                          \
 		if (lane == 0) s_word = atomicAdd(work_counter, n_grp);                                                         \
 		__syncthreads();                                                                                                \
@@ -448,8 +451,9 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 		}                                                                                                               \
 		uint32_t g_nanc = 0, g_ovf = 0;                                                                                 \
 		if (n_grp > 1) {                                                                                                \
-			const bool valid = k + lane < n_items;                                                                      \
-			const unsigned int rl = valid ? (list ? list[k + lane] : k + lane) : 0u;                                    \
+			const unsigned int pl = item_base + (unsigned int)lane * n_groups + ((k - item_base) >> 6);                 \
+			const bool valid = pl < n_items;                                                                            \
+			const unsigned int rl = valid ? (list ? list[pl] : pl) : 0u;                                                \
 			const DsbReadDesc dl = rd[rl];                                                                              \
 			uint64_t tg = w.dbg ? wall_clock64() : 0;                                                                   \
 			NS::fast_classify_lane(w, valid, bin + dl.bin_off + DSB_QPAD_L, dl.len, seed_blob + dl.seed_off, sinfo + rl, &g_nanc, &g_ovf); \
@@ -457,14 +461,15 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 		}                                                                                                               \
 		for (unsigned int pass = 0; pass < (n_grp > 1 ? 2u : 1u); pass++)                                               \
 		for (unsigned int gl = 0; gl < n_grp; gl++) {                                                                   \
-			if (k + gl >= n_items) break;                                                                               \
+			const unsigned int pos = n_grp > 1 ? item_base + gl * n_groups + ((k - item_base) >> 6) : k + gl;           \
+			if (pos >= n_items) break;                                                                                  \
 			bool have_anc = false;                                                                                      \
 			if (n_grp > 1) {                                                                                            \
 				const uint32_t ovf_l = NS::dsb_shfl(g_ovf, (int)gl);                                                    \
 				if ((ovf_l != 0) != (pass == 1)) continue;                                                              \
 				have_anc = !ovf_l;                                                                                      \
 			}                                                                                                           \
-		unsigned int r = list ? list[k + gl] : k + gl;                                                                  \
+		unsigned int r = list ? list[pos] : pos;                                                                        \
 		DsbReadDesc d = rd[r];                                                                                          \
 		uint64_t t_start = wall_clock64();                                                                              \
 		uint64_t tacc0[14]; if (w.dbg) for (int i = 0; i < 14; i++) tacc0[i] = w.tacc[i];                               \
@@ -481,7 +486,8 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 		}                                                                                                               \
 		uint32_t fast = NS::classify_read(w, bits + d.bit_off, bits + d.bit_off + d.n_words, have_anc);                 \
 		if (w.boosted) __builtin_amdgcn_s_setprio(0);                                                                   \
-		/* publish the hits of this read */                                                                             \
+		/* publish the hits of this read (none if it is handed over to k_classify_heavy) */                            \
+		if (w.status & DSB_ST_HEAVY) w.n_hit = 0;                                                                       \
 		if (lane == 0) s_word = w.n_hit ? atomicAdd(hout_counter, w.n_hit) : 0u;                                        \
 		__syncthreads();                                                                                                \
 		unsigned int first = s_word;                                                                                    \
@@ -513,10 +519,11 @@ DSB_DEFINE_CLASSIFY(k_classify_second, dsb_g64, 64)
 // runs classify_read as everywhere else, the other waves sleep at the workgroup barrier and are woken for the pass over
 // the old predecessors of a batch of DP nodes (sdp_batch_old_mw), which they split chunk by chunk.  Work items as in
 // k_classify (atomic counter over the LPT order); every wave reaches every barrier, so the grid drains.
-#define DSB_MW_WAVES 4
-__global__ void __launch_bounds__(64 * DSB_MW_WAVES, DSB_WAVES_PER_EU) k_classify_heavy(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed,
+#define DSB_MW_WAVES 8
+__global__ void __launch_bounds__(64 * DSB_MW_WAVES, DSB_WAVES_PER_EU) k_classify_heavy(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,
         const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout,
-        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t slot_base, unsigned long long *work_cnt, const uint64_t *pk)
+        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t slot_base, unsigned long long *work_cnt, const uint64_t *pk,
+        DsbSeed *seed_blob, const DsbSeedInfo *sinfo)
 {
 	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const uint32_t slot_id = slot_base + blockIdx.x;
@@ -548,18 +555,19 @@ __global__ void __launch_bounds__(64 * DSB_MW_WAVES, DSB_WAVES_PER_EU) k_classif
 		w.win_mid = slot + ar.off_win; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
 		w.lane_anc = (DsbAnchor *)(slot + ar.off_lane_anc); w.lane_spset = (uint64_t *)(slot + ar.off_lane_sp);
 		w.top_idx = (uint32_t *)(slot + ar.off_top); w.round_info = (uint32_t *)(slot + ar.off_round);
-		w.anc_cap = ar.anc_cap; w.anc_cap_main = ar.anc_cap; w.hit_cap = ar.hit_cap; w.step_limit = x.step_limit; w.sp_gen = 0;
+		w.anc_cap = ar.anc_cap; w.anc_cap_main = ar.anc_cap; w.hit_cap = ar.hit_cap; w.step_limit = x.step_limit; w.heavy_limit = 0; w.sp_gen = 0;
 		w.mw = &mw; w.n_waves = DSB_MW_WAVES;
 		for (uint32_t i = lane; i < 64u * DSB_SPHASH; i += 64) w.lane_spset[i] = 0;
 		for (uint32_t i = lane; i < DSB_SPHASH; i += 64) w.spset[i] = 0;
 	}
 	__syncthreads();
+	const unsigned int n_items = n_ptr ? *n_ptr : n_fixed;
 	for (;;) {
 		if (threadIdx.x == 0) s_word = atomicAdd(work_counter, 1u);
 		__syncthreads();
 		const unsigned int k = s_word;
 		__syncthreads();
-		if (k >= n_fixed) {
+		if (k >= n_items) {
 			if (threadIdx.x < 4 && lds_cnt[threadIdx.x]) atomicAdd(work_cnt + threadIdx.x, (unsigned long long)lds_cnt[threadIdx.x]);
 			break;
 		}
@@ -568,7 +576,7 @@ __global__ void __launch_bounds__(64 * DSB_MW_WAVES, DSB_WAVES_PER_EU) k_classif
 			DsbReadDesc d = rd[r];
 			const uint64_t t_start = wall_clock64();
 			w.bin = bin + d.bin_off + DSB_QPAD_L; w.L = d.len; w.status = 0; w.max_read_l = d.hist_max;
-			w.pre_seeds = nullptr; w.pre_info = nullptr;
+			w.pre_seeds = seed_blob ? seed_blob + d.seed_off : nullptr; w.pre_info = sinfo + r;
 			w.pk[0] = pk + d.pk_off; w.pk[1] = w.pk[0] + ((d.len + 31) / 32 + 1);
 			const uint32_t fast = dsb_g64::classify_read(w, bits + d.bit_off, bits + d.bit_off + d.n_words);
 			if (w.boosted) __builtin_amdgcn_s_setprio(0);
@@ -592,7 +600,8 @@ __global__ void __launch_bounds__(64 * DSB_MW_WAVES, DSB_WAVES_PER_EU) k_classif
 				__syncthreads();                                            // wave 0 posted a command
 				const uint32_t cmd = mw.cmd;
 				if (cmd == 3) break;
-				if (cmd == 1) dsb_g64::sdp_batch_old_mw<1>(&mw, lds_ring, lds_red, lane, wv, DSB_MW_WAVES, nullptr);
+				if (cmd == 4) dsb_g64::sdp_batch_old0_mw(&mw, lds_red, lane, wv, DSB_MW_WAVES, nullptr);
+				else if (cmd == 1) dsb_g64::sdp_batch_old_mw<1>(&mw, lds_ring, lds_red, lane, wv, DSB_MW_WAVES, nullptr);
 				else dsb_g64::sdp_batch_old_mw<2>(&mw, lds_ring, lds_red, lane, wv, DSB_MW_WAVES, nullptr);
 			}
 		}
@@ -729,7 +738,7 @@ struct dsb_ctx {
 	unsigned int *d_counters = nullptr;            // u32: [0] work, [1] hits, [2..3] u64 table-1 probes, [4] early work, [6] listed reads, [7] work of the second run, [8] third run list, [9] its work; u64 x 4 at +16 (main launch), +24 (early launch), +32 (second runs): occ, MEM searches, SA lookups, reference bases
 	DsbSlotArena arena; int n_slots = 0;
 	DsbSlotArena arena_big; int n_slots_big = 0;  // second run of reads that outgrew an arena or their loop budget
-	uint32_t *d_score = nullptr, *d_order = nullptr; size_t cap_score = 0, cap_order = 0;
+	uint32_t *d_score = nullptr, *d_order = nullptr, *d_heavy = nullptr; size_t cap_score = 0, cap_order = 0, cap_heavy = 0;
 	DsbSeed *d_seeds = nullptr; DsbSeedInfo *d_sinfo = nullptr; size_t cap_seeds = 0, cap_sinfo = 0;   // seed lists of the batch (k_seed_scan)
 	uint8_t *d_summ = nullptr; int summ_shift = 0;   // summary of exist table 0 in use (the staged index's, or none with synthetic tables)
 	uint8_t *syn0 = nullptr, *syn1 = nullptr; bool seed_only = false;   // dsb_ctx_use_synthetic_filter
@@ -762,7 +771,7 @@ extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 	if (c->stream2) hipStreamSynchronize(c->stream2);
 	for (InSlot &s : c->in) { hipFree(s.d_rd); hipFree(s.d_ascii); hipFree(s.d_scan_order); }
 	hipFree(c->d_wd); hipFree(c->d_bin); hipFree(c->d_pk); hipFree(c->d_bits);
-	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->arena_big.base); hipFree(c->d_score); hipFree(c->d_order); hipFree(c->d_seeds); hipFree(c->d_sinfo); hipFree(c->syn0); hipFree(c->syn1);
+	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->arena_big.base); hipFree(c->d_score); hipFree(c->d_order); hipFree(c->d_heavy); hipFree(c->d_seeds); hipFree(c->d_sinfo); hipFree(c->syn0); hipFree(c->syn1);
 	if (c->dbg_host) hipHostFree(c->dbg_host);
 	for (int i = 0; i < 4; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	if (c->ev_order) hipEventDestroy(c->ev_order);
@@ -953,6 +962,7 @@ static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_b
 		if (c->cap_hout != want_hout) { if (c->d_hout) hipFree(c->d_hout); c->d_hout = nullptr; c->cap_hout = 0; if (hipMalloc((void **)&c->d_hout, want_hout * sizeof(DsbHitOut)) != hipSuccess) return DSB_ENOMEM; c->cap_hout = want_hout; }
 	}
 	if ((rc = grow(&c->d_score, &c->cap_score, n + 1))) return rc;
+	if ((rc = grow(&c->d_heavy, &c->cap_heavy, n + 1))) return rc;
 	if ((rc = grow(&c->d_order, &c->cap_order, n + 1))) return rc;
 	// reads in flight: one wavefront each; default = what is resident at once (12 waves per CU: LDS), bounded by the batch
 	int want = c->opts.n_slots > 0 ? c->opts.n_slots : 256 * 12;
@@ -1128,6 +1138,11 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	uint32_t step_limit = DSB_STEP_LIMIT;
 	if (const char *e = getenv("DSB_STEP_LIMIT_RT")) { long v = atol(e); if (v > 0) step_limit = (uint32_t)v; }   // diagnostics: a small budget forces second runs
 	DsbDevIndex dx1 = c->dx; dx1.sms_cap = c->arena.sms_cap; dx1.step_limit = step_limit;
+	// a read whose sparse DP scans more predecessors than this on one wavefront is given up there and run again by a
+	// workgroup of DSB_MW_WAVES wavefronts (k_classify_heavy) after the main launch; DSB_HEAVY_PREDS=0 switches that off
+	dx1.heavy_limit = DSB_HEAVY_PREDS;
+	if (dbg) dx1.heavy_limit = 0;                                 // (stage dumps describe whole reads, unless the limit is asked for)
+	if (const char *e = getenv("DSB_HEAVY_PREDS")) dx1.heavy_limit = (uint32_t)strtoul(e, nullptr, 10);
 	if (n_heavy) {
 		// their probes first, alone on the device (about a millisecond), then their classify launch on the second stream
 		hipLaunchKernelGGL(k_seed_probe_reads, dim3(n_heavy * DSB_HPROBE_SPLIT), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const uint32_t *)c->d_order, c->d_pk, c->d_bits, c->d_summ, c->summ_shift);
@@ -1140,9 +1155,9 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		c->timing.n_heavy_mw = n_mw;
 		if (n_mw) {
 			HIPCHK(hipStreamWaitEvent(c->stream3, c->ev_hprobe, 0));
-			hipLaunchKernelGGL(k_classify_heavy, dim3(n_mw), dim3(64 * DSB_MW_WAVES), 0, c->stream3, dx1, (const DsbReadDesc *)s.d_rd, (uint32_t)n_mw, (const uint32_t *)c->d_order, c->d_bin,
+			hipLaunchKernelGGL(k_classify_heavy, dim3(n_mw), dim3(64 * DSB_MW_WAVES), 0, c->stream3, dx1, (const DsbReadDesc *)s.d_rd, (uint32_t)n_mw, (const unsigned int *)nullptr, (const uint32_t *)c->d_order, c->d_bin,
 			                   (const uint64_t *)c->d_bits, c->arena, c->d_counters + 10, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, (uint32_t)c->n_slots,
-			                   (unsigned long long *)(c->d_counters + 16 + 8), (const uint64_t *)c->d_pk);
+			                   (unsigned long long *)(c->d_counters + 16 + 8), (const uint64_t *)c->d_pk, (DsbSeed *)nullptr, (const DsbSeedInfo *)c->d_sinfo);
 			HIPCHK(hipEventRecord(c->ev_heavy3, c->stream3));
 		}
 		HIPCHK(hipStreamWaitEvent(c->stream2, c->ev_hprobe, 0));
@@ -1198,7 +1213,17 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	// DSB_STEP_LIMIT loop iterations.  Reads that outgrew any of these are listed on the device and run again from
 	// scratch in DSB_RETRY_SLOTS slots with DSB_RETRY_GROW times the match nodes, 8x the anchors, 4x the chains and 16x
 	// the budget; with an empty list the launch drains at once.  counters: [6] listed reads, [7] work counter of the second run.
-	DsbDevIndex dx2 = c->dx; dx2.sms_cap = c->arena_big.sms_cap; dx2.step_limit = step_limit > 0xffffffffu / 16 ? 0xffffffffu : step_limit * 16u;
+	// Reads given up as heavy (DSB_ST_HEAVY): listed on the device, then one workgroup of DSB_MW_WAVES wavefronts per read in
+	// the slots the finished launches left free.  counters: [12] listed reads, [13] work counter.  An empty list drains at once.
+	if (dx1.heavy_limit) {
+		DsbDevIndex dxh = dx1; dxh.heavy_limit = 0;
+		unsigned gh = (unsigned)(c->n_slots + DSB_HEAVY_SLOTS); if (gh > 256u) gh = 256u;
+		hipLaunchKernelGGL(k_collect_retry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const DsbReadOut *)c->d_rout, (uint32_t)n, c->d_heavy, c->d_counters + 12, DSB_ST_HEAVY, 0);
+		hipLaunchKernelGGL(k_classify_heavy, dim3(gh), dim3(64 * DSB_MW_WAVES), 0, c->stream, dxh, (const DsbReadDesc *)s.d_rd, 0u, (const unsigned int *)(c->d_counters + 12), (const uint32_t *)c->d_heavy, c->d_bin,
+		                   (const uint64_t *)c->d_bits, c->arena, c->d_counters + 13, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, 0u,
+		                   (unsigned long long *)(c->d_counters + 16 + 8), (const uint64_t *)c->d_pk, use_scan ? c->d_seeds : (DsbSeed *)nullptr, (const DsbSeedInfo *)c->d_sinfo);
+	}
+	DsbDevIndex dx2 = c->dx; dx2.sms_cap = c->arena_big.sms_cap; dx2.heavy_limit = 0; dx2.step_limit = step_limit > 0xffffffffu / 16 ? 0xffffffffu : step_limit * 16u;
 	const int retry_mask = DSB_ST_SMS_OVF | DSB_ST_ANC_OVF | DSB_ST_HIT_OVF | DSB_ST_TIMEOUT;
 	hipLaunchKernelGGL(k_collect_retry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const DsbReadOut *)c->d_rout, (uint32_t)n, c->d_score, c->d_counters + 6, retry_mask, 0);
 	launch_classify(k_classify_second, c, c->stream, (unsigned)c->n_slots_big, dx2, s, 0u, (const unsigned int *)(c->d_counters + 6), (const uint32_t *)c->d_score, c->arena_big, c->d_counters + 7, nullptr, 0u, 0u, 2, use_scan);
@@ -1251,6 +1276,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	unsigned long long wk[12] = {0};                   // work counters: main launch, early launch, second runs
 	HIPCHK(hipMemcpy(&c->p1, c->d_counters + 2, 8, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(&c->timing.n_retry, c->d_counters + 6, 4, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(&c->timing.n_requeue, c->d_counters + 12, 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(wk, c->d_counters + 16, 96, hipMemcpyDeviceToHost));
 	c->timing.windows = s.total_windows; c->timing.probes_t1 = c->p1; c->timing.bases = s.total_bases;
 	c->timing.seed_scan = use_scan ? 1 : 0;

@@ -96,7 +96,7 @@ typedef struct {
 	uint64_t ref_bases;    /* reference bases fetched by get_ref (src/cly.c:435) */
 	uint64_t main_occ, main_mem, main_sa, main_ref_bases;   /* the same for the main k_classify launch alone (what classify_ms times) */
 	uint32_t n_heavy_mw;   /* reads of the early launch that ran on several wavefronts each (k_classify_heavy) */
-	uint32_t pad2;
+	uint32_t n_requeue;    /* reads given up by their wavefront as heavy (quadratic sparse DP) and run again by a workgroup of wavefronts */
 } dsb_timing;
 
 /* load_idx (src/idx.c:1103-1160, src/bwt.c:68-104): read <dir>/deSAMBA.* into host memory */

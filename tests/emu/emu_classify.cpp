@@ -69,6 +69,7 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	static uint4 emu_ring[DSB_RING]; w.ring = emu_ring;
 	static uint32_t emu_red[4]; w.red = emu_red; w.round_info = (uint32_t *)(s + off[17]);
 	w.lane_anc = (DsbAnchor *)(s + off[14]); w.lane_spset = (uint64_t *)(s + off[15]); w.top_idx = (uint32_t *)(s + off[16]); w.anc_cap = DSB_ANC_CAP;
+	w.heavy_limit = 0;
 	w.anc_cap_main = DSB_ANC_CAP; w.hit_cap = DSB_HIT_CAP; w.step_limit = getenv("DSB_EMU_STEP_LIMIT") ? (uint32_t)atol(getenv("DSB_EMU_STEP_LIMIT")) : DSB_STEP_LIMIT;
 }
 

@@ -12,4 +12,4 @@ for _ in range(reps):
 tm = ctx.timing()
 res = ctx.fetch(strict=False)
 bad = sum(1 for i in range(n) if res.reads[i].status); mapped = sum(1 for i in range(n) if res.reads[i].n)
-print("ms encode %.2f probe %.2f classify %.2f total %.2f | %.0f reads/s %.3f Gbp/s | mapped %d status!=0 %d second-run %d" % (tm.encode_ms, tm.seed_probe_ms, tm.classify_ms, tm.total_ms, n / (tm.total_ms / 1e3), tm.bases / (tm.total_ms / 1e3) / 1e9, mapped, bad, tm.n_retry))
+print("ms encode %.2f probe %.2f classify %.2f total %.2f | %.0f reads/s %.3f Gbp/s | mapped %d status!=0 %d second-run %d requeued-heavy %d tail %.1f" % (tm.encode_ms, tm.seed_probe_ms, tm.classify_ms, tm.total_ms, n / (tm.total_ms / 1e3), tm.bases / (tm.total_ms / 1e3) / 1e9, mapped, bad, tm.n_retry, tm.n_requeue, tm.tail_ms))
