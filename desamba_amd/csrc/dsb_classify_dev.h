@@ -70,13 +70,19 @@
 // the batch does not wait for it.  Reset when the read is done (k_classify).
 #ifndef DSB_BOOST_IF_HEAVY
 #define DSB_BOOST_PREDS 300000u
+#define DSB_MIDDLE_HEAVY_MIN 16384u /* nodes of a middle gap from which a single-wavefront launch gives the read up as heavy (>= 134 M predecessor tests) */
+#ifndef DSB_LANE_STEPS
 #define DSB_LANE_STEPS 256u        /* search steps a lane may spend on its read in fast_classify_lane */
+#endif
 #ifdef DSB_HOST_EMU
 #define DSB_BOOST_IF_HEAVY(w) do { } while (0)
 #else
 #define DSB_BOOST_IF_HEAVY(w) do { if (!(w).boosted && (w).dp_preds > DSB_BOOST_PREDS) { __builtin_amdgcn_s_setprio(3); (w).boosted = 1; } } while (0)
 #endif
 #endif
+// ... and beyond heavy_limit predecessors a single-wavefront launch gives the read up (DSB_ST_HEAVY): spending the loop budget
+// makes the extension loops stop at their next SPENT test, so the hand-over costs nothing per node
+#define DSB_HEAVY_CHECK(w) do { if ((w).heavy_limit && (w).dp_preds > (w).heavy_limit) { (w).status |= DSB_ST_HEAVY; (w).steps = (w).step_limit; } } while (0)
 
 namespace DSB_NS {
 
@@ -664,7 +670,6 @@ DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, u
 		bool ref_search_l = (l_pre < 12 || d_pre == 0), ref_search_r = (l_suf < 12 || d_suf == 0);
 		if ((int64_t)rp_e - (int64_t)rp_s > 50) { if (!((int64_t)rp_e - (int64_t)rp_s < 1000)) return 50; }
 		for (uint32_t r = rp_s; r < rp_e; r++) {
-			if (LSPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }        // (up to 999 positions per MEM: they count against the budget)
 			uint64_t rp = DSB_G64(x->refpos, r);
 			uint64_t rp_go = rp & 0xFFFFFFFFFFULL; uint32_t rp_ref = (uint32_t)(rp >> 40) & 0x7FFFFF;
 			uint32_t ed_l, ed_r, len_l, len_r, l_m_ext_l = 0, l_m_ext_r;
@@ -1925,6 +1930,7 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 		if (stopm == (1u << DSB_DPB) - 1u) break;
 	}
 	w.dp_preds += preds;
+	DSB_HEAVY_CHECK(w);
 #pragma unroll
 	for (int j = 0; j < DSB_DPB; j++) b.old_best[j] = ((uint32_t)j < b.K) ? grp_max_i(w.red, w.lane, best[j]) : 0;
 }
@@ -2088,100 +2094,6 @@ DV int sdp_best_pred_b(WCtx &w, DpBatch &b, const DsbSms &cs, int32_t cur)
 	int ob = b.old_best[cur - (int32_t)b.n0];
 	if (!cut && ob > best) best = ob;
 	return best;
-}
-
-// ---- batched sparse DP for large gaps of sdp_middle_M2 (no distance cut: every earlier node is a predecessor) -----------
-// one predecessor of a middle node, as sdp_best_pred<0> judges it (src/cly.c:2495-2517)
-DV void sdp_judge0(uint32_t c_q, uint32_t c_t, int c_l, const DsbSms &ps, int &best)
-{
-	const uint32_t lim_q = c_q + 6, lim_t = c_t + 6;
-	const int pre_q_ed = ps.q_pos + ps.len + 9 - 1, pre_t_ed = ps.t_pos + ps.len + 9 - 1;
-	if (((uint32_t)pre_q_ed > lim_q) || ((uint32_t)pre_t_ed > lim_t)) return;
-	const int indel = ps.q_pos - ps.t_pos - (lim_q - lim_t); const int ai = ABSV(indel);
-	if (ai > 200) return;
-	int ns = ps.score + c_l - (ai >> 3);
-	if ((uint32_t)pre_q_ed > c_q || (uint32_t)pre_t_ed > c_t) { const int oq = pre_q_ed - c_q, ot = pre_t_ed - c_t; ns -= MAXV(oq, ot); }
-	best = MAXV(best, ns);
-}
-// best score of each of K <= DSB_DPB nodes among the predecessors S[lo .. n0) taken by this wave: chunks of
-// DSB_DP_UNROLL x 64, chunk number first, first + stride, ... counted from the newest; lane maxima only (no reduction)
-DV void sdp_old0_slice(const DsbSms *S, int32_t n0, uint32_t K, const uint32_t *nq, const uint32_t *nt, const int *nl, int lane, int first, int stride, int *best, uint32_t *preds)
-{
-	const int32_t step = DSB_DP_UNROLL * DSB_WAVE;
-	for (int32_t hi = n0 - 1 - first * step; hi >= 0; hi -= stride * step) {
-		DsbSms pv[DSB_DP_UNROLL];
-#pragma unroll
-		for (int u = 0; u < DSB_DP_UNROLL; u++) { const int32_t pi = hi - u * DSB_WAVE - lane; if (pi >= 0) pv[u] = S[pi]; else { pv[u].t_pos = pv[u].q_pos = 0x7ffffff0u; pv[u].len = 0; pv[u].score = 0; } }
-#pragma unroll
-		for (int j = 0; j < DSB_DPB; j++) {
-			if ((uint32_t)j >= K) break;
-#pragma unroll
-			for (int u = 0; u < DSB_DP_UNROLL; u++) { const int32_t pi = hi - u * DSB_WAVE - lane; if (pi >= 0) sdp_judge0(nq[j], nt[j], nl[j], pv[u], best[j]); }
-		}
-		*preds += (uint32_t)step * K;
-	}
-}
-#ifndef DSB_HOST_EMU
-// the same pass on W wavefronts (k_classify_heavy): wave v takes every W-th chunk; results meet in mw->best
-DN void sdp_batch_old0_mw(DsbMw *mw, uint32_t *red, const int lane, const int wv, const int W, uint32_t *preds_out)
-{
-	uint32_t nq[DSB_DPB], nt[DSB_DPB]; int nl[DSB_DPB], best[DSB_DPB]; uint32_t preds = 0;
-	const uint32_t K = mw->K;
-#pragma unroll
-	for (int j = 0; j < DSB_DPB; j++) { nq[j] = mw->nd_q[j]; nt[j] = mw->nd_t[j]; nl[j] = (int)mw->nd_l[j]; best[j] = -2147483647 - 1; }
-	sdp_old0_slice(mw->sms, (int32_t)mw->n0, K, nq, nt, nl, lane, wv, W, best, &preds);
-#pragma unroll
-	for (int j = 0; j < DSB_DPB; j++) { const int m = grp_max_i(red, lane, best[j]); if (lane == 0) mw->best[wv][j] = m; }
-	__syncthreads();
-	if (preds_out) *preds_out = preds;
-}
-#endif
-// node DP of one large gap: nodes S[1 .. n_sms), S[0] = the previous anchor with the running score; returns the
-// maximum node score (>= score_in).  DSB_DPB nodes at a time share the pass over the nodes before the batch.
-DV int sdp_middle_dp(WCtx &w, DsbSms *S, uint32_t n_sms, int score)
-{
-	for (uint32_t n0 = 1; n0 < n_sms; n0 += DSB_DPB) {
-		if (w.heavy_limit && w.dp_preds > w.heavy_limit) { w.status |= DSB_ST_HEAVY; break; }      // quadratic DP: not on one wavefront
-		const uint32_t K = MINV((uint32_t)DSB_DPB, n_sms - n0);
-		uint32_t nq[DSB_DPB], nt[DSB_DPB]; int nl[DSB_DPB], ob[DSB_DPB];
-#pragma unroll
-		for (int j = 0; j < DSB_DPB; j++) { const DsbSms nd = S[n0 + ((uint32_t)j < K ? (uint32_t)j : 0u)]; nq[j] = nd.q_pos; nt[j] = nd.t_pos; nl[j] = (int)nd.len; ob[j] = -2147483647 - 1; }
-		uint32_t preds = 0;
-#ifndef DSB_HOST_EMU
-		if (w.mw && n0 >= DSB_MW_MIN_PREDS) {
-			DsbMw *mw = w.mw;
-			if (w.lane < DSB_DPB) { mw->nd_t[w.lane] = nt[w.lane]; mw->nd_q[w.lane] = nq[w.lane]; mw->nd_l[w.lane] = (uint32_t)nl[w.lane]; }
-			if (w.lane == 0) { mw->cmd = 4; mw->n0 = n0; mw->K = K; mw->sms = S; }
-			__syncthreads();
-			sdp_batch_old0_mw(mw, w.red, w.lane, 0, w.n_waves, &preds);
-			for (uint32_t j = 0; j < DSB_DPB; j++) { int m = -2147483647 - 1; for (int u = 0; u < w.n_waves; u++) m = MAXV(m, mw->best[u][j]); ob[j] = m; }
-		} else
-#endif
-		{
-			sdp_old0_slice(S, (int32_t)n0, K, nq, nt, nl, w.lane, 0, 1, ob, &preds);
-#pragma unroll
-			for (int j = 0; j < DSB_DPB; j++) ob[j] = grp_max_i(w.red, w.lane, ob[j]);
-		}
-		w.dp_preds += preds;
-		// the nodes of the batch one after the other: predecessors inside the batch have their final scores by then
-		int sc[DSB_DPB];
-#pragma unroll
-		for (int j = 0; j < DSB_DPB; j++) {
-			if ((uint32_t)j >= K) break;
-			int best = MAXV(nl[j], ob[j]);
-#pragma unroll
-			for (int i = 0; i < DSB_DPB; i++) {
-				if (i >= j) break;
-				DsbSms ps; ps.q_pos = nq[i]; ps.t_pos = nt[i]; ps.len = nl[i]; ps.score = sc[i];
-				sdp_judge0(nq[j], nt[j], nl[j], ps, best);
-			}
-			sc[j] = best;
-			score = MAXV(best, score);
-			S[n0 + (uint32_t)j].score = best;
-		}
-		wave_sync();
-	}
-	return score;
 }
 
 DV void fill_window(const WCtx &w, uint8_t *win, int n)
@@ -2484,8 +2396,14 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 				S[0] = first; S[n_sms - 1].q_pos = last.q_pos; S[n_sms - 1].t_pos = last.t_pos; S[n_sms - 1].len = last.len;
 				wave_sync();
 				w.n_sms = n_sms;
-				score = sdp_middle_dp(w, S, n_sms, score);
-				if (w.status & DSB_ST_HEAVY) { w.n_sms = 0; return 0; }
+				// a big gap (a tandem repeat between two anchors) is quadratic work: not beside other reads on one wavefront
+				if (w.heavy_limit && n_sms >= DSB_MIDDLE_HEAVY_MIN) { w.status |= DSB_ST_HEAVY; w.steps = w.step_limit; w.n_sms = 0; return 0; }
+				for (uint32_t ci = 1; ci < n_sms; ci++) {
+					DsbSms cs = S[ci];
+					int max_score = sdp_best_pred<0>(w, cs, (int32_t)ci);
+					score = MAXV(max_score, score);
+					S[ci].score = max_score;
+				}
 			}
 		}
 	}
@@ -2517,7 +2435,6 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 	int last_search = false;
 	while (1) {
 		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
-		if (w.heavy_limit && w.dp_preds > w.heavy_limit) { w.status |= DSB_ST_HEAVY; break; }      // quadratic DP: not on one wavefront
 		DSB_BOOST_IF_HEAVY(w);
 		if (w.n_sms == current_sms) {
 			uint32_t next_step = t_length - c_t_offset;
@@ -2596,7 +2513,6 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 	int last_search = false;
 	while (1) {
 		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
-		if (w.heavy_limit && w.dp_preds > w.heavy_limit) { w.status |= DSB_ST_HEAVY; break; }      // quadratic DP: not on one wavefront
 		DSB_BOOST_IF_HEAVY(w);
 		if (w.n_sms == current_sms) {
 			uint32_t next_step = c_t_offset;

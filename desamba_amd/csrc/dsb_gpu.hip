@@ -435,11 +435,13 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	/* group_mode (short reads with seed lists from k_seed_scan): a work item is 64 reads -- the anchor stage of one read per  \
 	   lane (fast_classify_lane), then the reads one after the other on the whole wavefront from those anchors; a read     \
 	   whose anchors outgrew its lane scratch is done afterwards the usual way (pass 1) */                                  \
-	/* Group g takes the reads at positions g, g + n_groups, g + 2 n_groups, ... of the (heaviest-first) order: 64         \
-	   consecutive positions would put the 64 heaviest reads of the batch into one group, on one wavefront */             \
-	const unsigned int n_grp = (group_mode && seed_blob) ? 64u : 1u;                                                    \
-	const unsigned int n_groups = (n_items > item_base ? n_items - item_base + 63u : 0u) / 64u;   /* (positions below item_base belong to the early launch) */ \
+	/* The first group_mode reads of the launch (the heaviest by the order) still go one by one: 64 of them in a row on one \
+	   wavefront would outlast the rest of the launch.  Groups are 64 consecutive positions of the order (similar reads    \
+	   keep the lanes of the anchor stage together). */                                                                    \
 	for (;;) {                                                                                                          \
+		unsigned int n_grp = 1u;                                                                                        \
+		if (group_mode && seed_blob) n_grp = __hip_atomic_load(work_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= group_mode ? 64u : 1u; \
+		n_grp = (unsigned int)__builtin_amdgcn_readfirstlane((int)n_grp);                                               \
 		if (lane == 0) s_word = atomicAdd(work_counter, n_grp);                                                         \
 		__syncthreads();                                                                                                \
 		unsigned int k = s_word + item_base;                                                                            \
@@ -451,9 +453,8 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 		}                                                                                                               \
 		uint32_t g_nanc = 0, g_ovf = 0;                                                                                 \
 		if (n_grp > 1) {                                                                                                \
-			const unsigned int pl = item_base + (unsigned int)lane * n_groups + ((k - item_base) >> 6);                 \
-			const bool valid = pl < n_items;                                                                            \
-			const unsigned int rl = valid ? (list ? list[pl] : pl) : 0u;                                                \
+			const bool valid = k + lane < n_items;                                                                      \
+			const unsigned int rl = valid ? (list ? list[k + lane] : k + lane) : 0u;                                    \
 			const DsbReadDesc dl = rd[rl];                                                                              \
 			uint64_t tg = w.dbg ? wall_clock64() : 0;                                                                   \
 			NS::fast_classify_lane(w, valid, bin + dl.bin_off + DSB_QPAD_L, dl.len, seed_blob + dl.seed_off, sinfo + rl, &g_nanc, &g_ovf); \
@@ -461,7 +462,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 		}                                                                                                               \
 		for (unsigned int pass = 0; pass < (n_grp > 1 ? 2u : 1u); pass++)                                               \
 		for (unsigned int gl = 0; gl < n_grp; gl++) {                                                                   \
-			const unsigned int pos = n_grp > 1 ? item_base + gl * n_groups + ((k - item_base) >> 6) : k + gl;           \
+			const unsigned int pos = k + gl;                                                                            \
 			if (pos >= n_items) break;                                                                                  \
 			bool have_anc = false;                                                                                      \
 			if (n_grp > 1) {                                                                                            \
@@ -515,12 +516,14 @@ DSB_DEFINE_CLASSIFY(k_classify_second, dsb_g64, 64)
 
 
 // Several wavefronts per read, for the handful of reads whose sparse DP is the batch's tail (tandem repeats: tens of
-// thousands of match nodes, a quadratic predecessor scan).  A workgroup of DSB_MW_WAVES wavefronts takes one read: wave 0
+// thousands of match nodes, a quadratic predecessor scan).  A workgroup of MWW wavefronts takes one read: wave 0
 // runs classify_read as everywhere else, the other waves sleep at the workgroup barrier and are woken for the pass over
 // the old predecessors of a batch of DP nodes (sdp_batch_old_mw), which they split chunk by chunk.  Work items as in
 // k_classify (atomic counter over the LPT order); every wave reaches every barrier, so the grid drains.
-#define DSB_MW_WAVES 8
-__global__ void __launch_bounds__(64 * DSB_MW_WAVES, DSB_WAVES_PER_EU) k_classify_heavy(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,
+// MWW wavefronts per read: 4 for the early launch (it runs beside the main launch and its helper waves hold wave slots the
+// whole time), 8 for the pass over the reads given up as heavy (the device is theirs by then)
+template <int MWW>
+__global__ void __launch_bounds__(64 * MWW, DSB_WAVES_PER_EU) k_classify_heavy(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,
         const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout,
         DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t slot_base, unsigned long long *work_cnt, const uint64_t *pk,
         DsbSeed *seed_blob, const DsbSeedInfo *sinfo)
@@ -531,7 +534,7 @@ __global__ void __launch_bounds__(64 * DSB_MW_WAVES, DSB_WAVES_PER_EU) k_classif
 	__shared__ DsbDevIndex sx;
 	__shared__ uint4 lds_ring[DSB_RING];
 	__shared__ __attribute__((aligned(16))) uint32_t lds_wtab[DSB_WTAB_SLOTS];
-	__shared__ uint32_t lds_red[DSB_MW_WAVES + 1];
+	__shared__ uint32_t lds_red[MWW + 1];
 	__shared__ unsigned int s_word;
 	__shared__ uint32_t lds_cnt[4];
 	__shared__ dsb_g64::DsbMw mw;
@@ -556,7 +559,7 @@ __global__ void __launch_bounds__(64 * DSB_MW_WAVES, DSB_WAVES_PER_EU) k_classif
 		w.lane_anc = (DsbAnchor *)(slot + ar.off_lane_anc); w.lane_spset = (uint64_t *)(slot + ar.off_lane_sp);
 		w.top_idx = (uint32_t *)(slot + ar.off_top); w.round_info = (uint32_t *)(slot + ar.off_round);
 		w.anc_cap = ar.anc_cap; w.anc_cap_main = ar.anc_cap; w.hit_cap = ar.hit_cap; w.step_limit = x.step_limit; w.heavy_limit = 0; w.sp_gen = 0;
-		w.mw = &mw; w.n_waves = DSB_MW_WAVES;
+		w.mw = &mw; w.n_waves = MWW;
 		for (uint32_t i = lane; i < 64u * DSB_SPHASH; i += 64) w.lane_spset[i] = 0;
 		for (uint32_t i = lane; i < DSB_SPHASH; i += 64) w.spset[i] = 0;
 	}
@@ -600,9 +603,8 @@ __global__ void __launch_bounds__(64 * DSB_MW_WAVES, DSB_WAVES_PER_EU) k_classif
 				__syncthreads();                                            // wave 0 posted a command
 				const uint32_t cmd = mw.cmd;
 				if (cmd == 3) break;
-				if (cmd == 4) dsb_g64::sdp_batch_old0_mw(&mw, lds_red, lane, wv, DSB_MW_WAVES, nullptr);
-				else if (cmd == 1) dsb_g64::sdp_batch_old_mw<1>(&mw, lds_ring, lds_red, lane, wv, DSB_MW_WAVES, nullptr);
-				else dsb_g64::sdp_batch_old_mw<2>(&mw, lds_ring, lds_red, lane, wv, DSB_MW_WAVES, nullptr);
+				if (cmd == 1) dsb_g64::sdp_batch_old_mw<1>(&mw, lds_ring, lds_red, lane, wv, MWW, nullptr);
+				else dsb_g64::sdp_batch_old_mw<2>(&mw, lds_ring, lds_red, lane, wv, MWW, nullptr);
 			}
 		}
 	}
@@ -1094,7 +1096,7 @@ static void launch_classify(K kern, dsb_ctx *c, hipStream_t st, unsigned grid, c
 {
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, st, dx, (const DsbReadDesc *)s.d_rd, n_fixed, n_ptr, list, c->d_bin, (const uint64_t *)c->d_bits, ar, work_counter,
 	                   c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, dbg, item_base, slot_base, (unsigned long long *)(c->d_counters + 16 + 8 * cnt_set),
-	                   pre_seeds ? c->d_seeds : nullptr, (const DsbSeedInfo *)c->d_sinfo, (const uint64_t *)c->d_pk, (uint32_t)((pre_seeds && s.max_len <= DSB_GROUP_MAX_LEN && !getenv("DSB_NO_GROUP")) ? 1u : 0u));
+	                   pre_seeds ? c->d_seeds : nullptr, (const DsbSeedInfo *)c->d_sinfo, (const uint64_t *)c->d_pk, (uint32_t)((pre_seeds && s.max_len <= DSB_GROUP_MAX_LEN && !getenv("DSB_NO_GROUP")) ? (getenv("DSB_GROUP_HEAD") ? (unsigned)atoi(getenv("DSB_GROUP_HEAD")) : 8u * grid) : 0u));
 }
 
 extern "C" int dsb_batch_run(dsb_ctx *c)
@@ -1139,7 +1141,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	if (const char *e = getenv("DSB_STEP_LIMIT_RT")) { long v = atol(e); if (v > 0) step_limit = (uint32_t)v; }   // diagnostics: a small budget forces second runs
 	DsbDevIndex dx1 = c->dx; dx1.sms_cap = c->arena.sms_cap; dx1.step_limit = step_limit;
 	// a read whose sparse DP scans more predecessors than this on one wavefront is given up there and run again by a
-	// workgroup of DSB_MW_WAVES wavefronts (k_classify_heavy) after the main launch; DSB_HEAVY_PREDS=0 switches that off
+	// workgroup of 8 wavefronts (k_classify_heavy) after the main launch; DSB_HEAVY_PREDS=0 switches that off
 	dx1.heavy_limit = DSB_HEAVY_PREDS;
 	if (dbg) dx1.heavy_limit = 0;                                 // (stage dumps describe whole reads, unless the limit is asked for)
 	if (const char *e = getenv("DSB_HEAVY_PREDS")) dx1.heavy_limit = (uint32_t)strtoul(e, nullptr, 10);
@@ -1155,7 +1157,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 		c->timing.n_heavy_mw = n_mw;
 		if (n_mw) {
 			HIPCHK(hipStreamWaitEvent(c->stream3, c->ev_hprobe, 0));
-			hipLaunchKernelGGL(k_classify_heavy, dim3(n_mw), dim3(64 * DSB_MW_WAVES), 0, c->stream3, dx1, (const DsbReadDesc *)s.d_rd, (uint32_t)n_mw, (const unsigned int *)nullptr, (const uint32_t *)c->d_order, c->d_bin,
+			hipLaunchKernelGGL(k_classify_heavy<4>, dim3(n_mw), dim3(64 * 4), 0, c->stream3, dx1, (const DsbReadDesc *)s.d_rd, (uint32_t)n_mw, (const unsigned int *)nullptr, (const uint32_t *)c->d_order, c->d_bin,
 			                   (const uint64_t *)c->d_bits, c->arena, c->d_counters + 10, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, (uint32_t)c->n_slots,
 			                   (unsigned long long *)(c->d_counters + 16 + 8), (const uint64_t *)c->d_pk, (DsbSeed *)nullptr, (const DsbSeedInfo *)c->d_sinfo);
 			HIPCHK(hipEventRecord(c->ev_heavy3, c->stream3));
@@ -1213,13 +1215,13 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	// DSB_STEP_LIMIT loop iterations.  Reads that outgrew any of these are listed on the device and run again from
 	// scratch in DSB_RETRY_SLOTS slots with DSB_RETRY_GROW times the match nodes, 8x the anchors, 4x the chains and 16x
 	// the budget; with an empty list the launch drains at once.  counters: [6] listed reads, [7] work counter of the second run.
-	// Reads given up as heavy (DSB_ST_HEAVY): listed on the device, then one workgroup of DSB_MW_WAVES wavefronts per read in
+	// Reads given up as heavy (DSB_ST_HEAVY): listed on the device, then one workgroup of 8 wavefronts per read in
 	// the slots the finished launches left free.  counters: [12] listed reads, [13] work counter.  An empty list drains at once.
 	if (dx1.heavy_limit) {
 		DsbDevIndex dxh = dx1; dxh.heavy_limit = 0;
 		unsigned gh = (unsigned)(c->n_slots + DSB_HEAVY_SLOTS); if (gh > 256u) gh = 256u;
 		hipLaunchKernelGGL(k_collect_retry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const DsbReadOut *)c->d_rout, (uint32_t)n, c->d_heavy, c->d_counters + 12, DSB_ST_HEAVY, 0);
-		hipLaunchKernelGGL(k_classify_heavy, dim3(gh), dim3(64 * DSB_MW_WAVES), 0, c->stream, dxh, (const DsbReadDesc *)s.d_rd, 0u, (const unsigned int *)(c->d_counters + 12), (const uint32_t *)c->d_heavy, c->d_bin,
+		hipLaunchKernelGGL(k_classify_heavy<8>, dim3(gh), dim3(64 * 8), 0, c->stream, dxh, (const DsbReadDesc *)s.d_rd, 0u, (const unsigned int *)(c->d_counters + 12), (const uint32_t *)c->d_heavy, c->d_bin,
 		                   (const uint64_t *)c->d_bits, c->arena, c->d_counters + 13, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, 0u,
 		                   (unsigned long long *)(c->d_counters + 16 + 8), (const uint64_t *)c->d_pk, use_scan ? c->d_seeds : (DsbSeed *)nullptr, (const DsbSeedInfo *)c->d_sinfo);
 	}
