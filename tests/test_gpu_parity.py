@@ -539,6 +539,41 @@ def test_heavy_reads_on_several_wavefronts_second_index(strain, monkeypatch):
         ctx.close(); idx.close()
 
 
+@pytest.mark.parametrize("scan", ["0", "1"])
+def test_heavy_reads_are_handed_over(strain, monkeypatch, scan):
+    """DSB_ST_HEAVY: a read whose sparse DP scans more than heavy_limit predecessors on its one wavefront is given up there,
+    listed on the device and run again by a workgroup of eight wavefronts (k_classify_heavy<8>) after the main launch --
+    with the limit forced down (DSB_HEAVY_PREDS) so that most reads of the strain set go that way, from hit bits
+    (DSB_SEED_SCAN=0) and from the seed lists of k_seed_scan: same SAM, nothing left with a status"""
+    import desamba_amd as D
+    monkeypatch.setenv("DSB_HEAVY_PREDS", "20000"); monkeypatch.setenv("DSB_SEED_SCAN", scan)
+    monkeypatch.setenv("DSB_HEAVY_FIRST", "8"); monkeypatch.setenv("DSB_HEAVY_MW", "4")
+    idx = D.Index(strain["index"]); ctx = D.Ctx(idx, 0)
+    try:
+        recs = D.read_fastq(strain["fastq"])
+        hits, sam = classify_all(D, ctx, recs)
+        t = ctx.timing()
+        assert t.n_requeue > len(recs) // 4 and t.n_retry == 0
+        assert sam == open(strain["sam"], "rb").read()
+        monkeypatch.setenv("DSB_HEAVY_PREDS", "0")                      # switched off: nothing is handed over
+        hits, sam = classify_all(D, ctx, recs)
+        assert ctx.timing().n_requeue == 0 and sam == open(strain["sam"], "rb").read()
+    finally:
+        ctx.close(); idx.close()
+
+
+@pytest.mark.parametrize("name", ["heavy", "manyanchors", "ont20k"])
+def test_heavy_hand_over_on_the_demo_index(gpu, name, monkeypatch):
+    """the same on golden sets of the demo index (hand-over from the right/left extension loops and from a large middle gap)"""
+    D, idx, ctx = gpu
+    monkeypatch.setenv("DSB_HEAVY_PREDS", "5000")
+    recs = D.read_fastq(os.path.join(GOLDEN, "synth", name + ".fq"))
+    exp = open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read()
+    hits, sam = classify_all(D, ctx, recs)
+    assert ctx.timing().n_requeue > 0
+    assert sam == exp
+
+
 def test_short_reads_64_per_wavefront(gpu, demo, oracle, tmp_path, monkeypatch):
     """group mode of k_classify (batches of reads <= 400 bases with seed lists from k_seed_scan): the anchor stage of one read
     per lane, 64 reads per work item.  6000 x 150 bp at 1 % and 2000 at 8 % error (slow path, reads without hits), plus
