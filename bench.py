@@ -371,7 +371,7 @@ def main():
             dt2 = float(t.item())
         e2e = {"reads_per_s": len(order) * R * world / dt2, "gbp_per_s": len(order) * bases_per_batch * world / dt2 / 1e9, "ms_per_step": dt2 / len(order) * 1e3,
                "batches": len(order), "hits_fetched": hits[0] + hits[1],
-               "what": "per batch: H2D of the raw FASTQ text (sequence + quality lines, %.1f GB) from pinned memory, all kernels, D2H of per-read results and hits; two contexts on the GPU share the staged index and overlap each other" % (bufs[0][1] / 1e9)}
+               "what": "per batch: H2D of the raw FASTQ text (sequence + quality lines, %.1f GB) from pinned memory, all kernels, D2H of per-read results and hits; two contexts on the GPU share the staged index; the kernels of one batch at a time (dsb_batch_run takes a per-device turn), the other context's upload and fetch overlap them" % (bufs[0][1] / 1e9)}
         ctx2.close()
 
     # ---- the seed-lookup kernel in the HBM regime: 2 x 2 GiB synthetic filter tables, 20 % full (no index of that size exists here;
