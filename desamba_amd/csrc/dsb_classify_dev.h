@@ -395,47 +395,68 @@ DV int64_t get_uni(DsbXP x, const Cnt &k, uint64_t bwt_pos, int search_l, uint64
 
 // ---- lv_extd (src/cly.c:510-609).  Both strings live in local byte arrays with 8 bytes in
 // front (oracle U5); the sentinels '#'/'$' are placed by the caller at index len.
+// ---- edit distance of two strings of <= 12 bases: the reference's banded furthest-reaching recurrence (lv_extd,
+// src/cly.c:510-609: <= 4 errors, diagonals -4 .. 4, its own tie rules) with everything in registers.
+// A string and its surroundings are 3-bit symbols in one 64-bit word, position p (-5 .. 15) at bits 3 (p + 5): 0-3 bases,
+// 4 = the end mark of the reference string, 5 = the end mark of the query, 6 / 7 = anything else in the query / the
+// reference -- no symbol above 3 of one string equals a symbol of the other, as with the reference's '#', '$' and the
+// never-matching bytes in front of its local strings (oracle U5).  Extending a match along a diagonal is one XOR and a
+// count of trailing zeros instead of a byte loop; the two tables of the recurrence (12 diagonals: furthest query
+// position + 1, errors spent) are 4-bit fields of two more words.
+DV uint64_t lv_pack(const uint8_t *s, int32_t len, bool query)
+{
+	uint64_t v = 0;
+	for (int32_t p = query ? -1 : -5; p <= len; p++) {
+		const uint32_t b = s[p];
+		const uint32_t c = b < 4u ? b : (query ? (b == '$' ? 5u : 6u) : (b == '#' ? 4u : 7u));
+		v |= (uint64_t)c << (3 * (p + 5));
+	}
+	const uint64_t fill = query ? 0x6DB6DB6DB6DB6DB6ULL : 0x7FFFFFFFFFFFFFFFULL;      // 6 / 7 in every field
+	const int lo = 3 * ((query ? -1 : -5) + 5), hi = 3 * (len + 1 + 5);
+	const uint64_t inside = ((hi >= 64 ? 0ULL : (1ULL << hi)) - 1ULL) & ~((1ULL << lo) - 1ULL);
+	return (v & inside) | (fill & ~inside);
+}
+DV uint32_t lv_sym(uint64_t s, int32_t p) { return (uint32_t)(s >> (3 * (p + 5))) & 7u; }
+DV int32_t lv_get(uint64_t tab, int32_t d) { return (int32_t)((tab >> (4 * (d + 5))) & 15u); }
+DV void lv_put(uint64_t &tab, int32_t d, int32_t v) { const int sh = 4 * (d + 5); tab = (tab & ~(15ULL << sh)) | ((uint64_t)(uint32_t)v << sh); }
 DN int32_t lv_extd(const uint8_t *ref, int32_t ref_length, const uint8_t *query, int32_t query_length)
 {
-	if (ref_length == 0 && query_length == 0) return 0;
-	int32_t mn_d[12], ed_d[12];
-	int32_t prev_mn, cur_mn, next_mn, prev_ed, cur_ed, next_ed;
-	int32_t best = query_length;
-#define MN(i) mn_d[(i) + 5]
-#define ED(i) ed_d[(i) + 5]
-	for (int i = -5; i <= 6; i++) { MN(i) = -1; ED(i) = (i > 0) ? i : -i; }
-	for (int i = 0; i <= 4; i++) {
-		prev_mn = -1; cur_mn = i - 1; next_mn = MN(-i + 1);
-		prev_ed = i + 1; cur_ed = i; next_ed = ED(-i + 1);
-		for (int j = -i; j <= 4; j++) {
-			int mnj, edj;
-			if (cur_mn + j < ref_length - 1) {
-				int m = cur_mn + 1 - cur_ed;
-				mnj = cur_mn + 1; edj = cur_ed + 1;
-				if (m < next_mn + 1 - next_ed) { mnj = next_mn + 1; edj = next_ed + 1; m = next_mn - next_ed; }
-				if (m < prev_mn - prev_ed) { mnj = prev_mn + 1; edj = prev_ed + 1; }
+	const int32_t len = ref_length;                     // (all callers pass two strings of one length)
+	if (len == 0 && query_length == 0) return 0;
+	const uint64_t R = lv_pack(ref, len, false), Q = lv_pack(query, len, true);
+	// reach[d] = furthest query position on diagonal d, + 1 (0 = nothing yet); spent[d] = errors behind it; d = -5 .. 6
+	uint64_t reach = 0, spent = 0;
+	for (int32_t d = -5; d <= 6; d++) lv_put(spent, d, d > 0 ? d : -d);
+	int32_t best = len;
+	for (int32_t e = 0; e <= 4; e++) {
+		// (left, here, right) = the previous round's diagonals j - 1, j, j + 1
+		int32_t l_m = -1, h_m = e - 1, r_m = lv_get(reach, -e + 1) - 1;
+		int32_t l_e = e + 1, h_e = e, r_e = lv_get(spent, -e + 1);
+		for (int32_t j = -e; j <= 4; j++) {
+			int32_t m, c;
+			if (h_m + j < len - 1) {                    // room on the reference: a substitution moves on, an insertion / deletion comes from a neighbour
+				int32_t key = h_m + 1 - h_e; m = h_m + 1; c = h_e + 1;
+				if (key < r_m + 1 - r_e) { m = r_m + 1; c = r_e + 1; key = r_m - r_e; }
+				if (key < l_m - l_e) { m = l_m + 1; c = l_e + 1; }
 			} else {
-				int m = cur_mn - cur_ed;
-				mnj = cur_mn; edj = cur_ed + 1;
-				if (m < prev_mn - prev_ed) { mnj = prev_mn; edj = prev_ed + 1; m = prev_mn - prev_ed; }
-				if (m < next_mn + 1 - next_ed) { mnj = next_mn + 1; edj = next_ed + 1; }
+				int32_t key = h_m - h_e; m = h_m; c = h_e + 1;
+				if (key < l_m - l_e) { m = l_m; c = l_e + 1; key = l_m - l_e; }
+				if (key < r_m + 1 - r_e) { m = r_m + 1; c = r_e + 1; }
 			}
-			ED(j) = edj;
-			int mn_j = MINV(mnj, query_length);
-			mn_j = MINV(mn_j, ref_length - j);
-			for (; ref[mn_j + j] == query[mn_j]; mn_j++);
-			MN(j) = mn_j;
-			if (query[mn_j] == '$' || ref[mn_j + j] == '#') {
-				best = MINV(edj - 1, best);
-				if (j <= i + 1) return best;
+			lv_put(spent, j, c);
+			m = MINV(m, len); m = MINV(m, len - j);
+			const uint64_t x = (R >> (3 * (m + j + 5))) ^ (Q >> (3 * (m + 5)));       // never 0: the end marks differ from everything
+			m += (int32_t)(__builtin_ctzll(x) / 3);
+			lv_put(reach, j, m + 1);
+			if (lv_sym(Q, m) == 5u || lv_sym(R, m + j) == 4u) {
+				best = MINV(c - 1, best);
+				if (j <= e + 1) return best;
 			}
-			prev_mn = cur_mn; cur_mn = next_mn; next_mn = MN(j + 2);
-			prev_ed = cur_ed; cur_ed = next_ed; next_ed = ED(j + 2);
+			l_m = h_m; h_m = r_m; r_m = lv_get(reach, j + 2) - 1;
+			l_e = h_e; h_e = r_e; r_e = lv_get(spent, j + 2);
 		}
 	}
 	return best;
-#undef MN
-#undef ED
 }
 
 // ---- FM search (src/cly.c:1286-1447) --------------------------------------------------------
