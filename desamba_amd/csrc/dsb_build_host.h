@@ -19,10 +19,24 @@
 struct DsbGz {
 	gzFile f; unsigned char *buf; int begin, end, eof;
 	bool at_eof() const { return eof && begin >= end; }
+	bool fill() { begin = 0; end = gzread(f, buf, 1 << 20); if (end < (1 << 20)) eof = 1; if (end <= 0) { end = 0; return false; } return true; }
 	int getc() {
 		if (eof && begin >= end) return -1;
-		if (begin >= end) { begin = 0; end = gzread(f, buf, 1 << 16); if (end < (1 << 16)) eof = 1; if (end <= 0) { end = 0; return -1; } }
+		if (begin >= end && !fill()) return -1;
 		return buf[begin++];
+	}
+	// the rest of the current line (up to and without its '\n'), translated through lut, appended to out
+	void line_to(std::vector<uint8_t> &out, const uint8_t *lut) {
+		for (;;) {
+			if (begin >= end) { if (eof || !fill()) return; }
+			const unsigned char *p = buf + begin, *nl = (const unsigned char *)memchr(p, '\n', (size_t)(end - begin));
+			const size_t n = nl ? (size_t)(nl - p) : (size_t)(end - begin), o = out.size();
+			out.resize(o + n);
+			uint8_t *w = out.data() + o;
+			for (size_t i = 0; i < n; i++) w[i] = lut[p[i]];
+			begin += (int)n + (nl ? 1 : 0);
+			if (nl) return;
+		}
 	}
 };
 
@@ -31,7 +45,8 @@ static inline int dsb_build_read_fasta(const char *path, DsbBuildIn &in)
 	static uint8_t codes[256]; static int init = 0;
 	if (!init) { memset(codes, 4, 256); codes['A'] = codes['a'] = 0; codes['C'] = codes['c'] = 1; codes['G'] = codes['g'] = 2; codes['T'] = codes['t'] = 3; init = 1; }
 	DsbGz z; z.f = gzopen(path, "r"); if (!z.f) return -1;
-	z.buf = (unsigned char *)malloc(1 << 16); z.begin = z.end = z.eof = 0;
+	z.buf = (unsigned char *)malloc(1 << 20); z.begin = z.end = z.eof = 0;
+	gzbuffer(z.f, 1 << 20);
 	int last = 0, c;
 	uint64_t total = 0;
 	for (;;) {
@@ -43,7 +58,7 @@ static inline int dsb_build_read_fasta(const char *path, DsbBuildIn &in)
 		const size_t s0 = in.code.size();
 		while ((c = z.getc()) != -1 && c != '>' && c != '+' && c != '@') {
 			in.code.push_back(codes[c]);
-			int d; while ((d = z.getc()) != -1 && d != '\n') in.code.push_back(codes[d]);
+			z.line_to(in.code, codes);                       // (after an empty line -- c == '\n', now part of the text -- this is the whole next line)
 		}
 		last = (c == '>' || c == '@') ? c : 0;
 		uint64_t seq_l = in.code.size() - s0;
