@@ -51,23 +51,18 @@ __device__ __forceinline__ uint32_t d_code(uint8_t ch)
 
 // sequence lines of a FASTQ text in pinned host memory -> contiguous ASCII blob in HBM: the kernel reads the host text
 // in place (zero-copy over PCIe), so only the sequence bytes travel -- half of a FASTQ file is quality lines.
-// One block per read, 16 bytes per thread and step; src[i] = host address of read i, dst offset = its seq_off.
-__global__ void __launch_bounds__(256) k_gather_text(const DsbReadDesc *rd, const char *const *src, char *ascii)
+// One wavefront per read; src[i] = host address of read i, dst offset = its seq_off.
+typedef uint32_t __attribute__((aligned(1), may_alias)) dsb_u32_any;
+__global__ void __launch_bounds__(64) k_gather_text(const DsbReadDesc *rd, const char *const *src, char *ascii)
 {
-	const DsbReadDesc d = rd[blockIdx.x];
-	const char *s = src[blockIdx.x];
-	char *o = ascii + d.seq_off;
-	const uint32_t L = d.len;
-	const uint32_t head = (uint32_t)((16u - ((uintptr_t)s & 15u)) & 15u) < L ? (uint32_t)((16u - ((uintptr_t)s & 15u)) & 15u) : L;   // up to the first 16-byte boundary of the source
-	if (threadIdx.x < head) o[threadIdx.x] = s[threadIdx.x];
-	const uint32_t body = (L - head) / 16u;
-	for (uint32_t q = threadIdx.x; q < body; q += 256) {
-		const uint4 v = *reinterpret_cast<const uint4 *>(s + head + 16u * q);
-		char *w = o + head + 16u * q;                               // (destination alignment differs from the source's)
-		uint32_t t[4] = {v.x, v.y, v.z, v.w};
-		for (int k = 0; k < 4; k++) { w[4 * k] = (char)t[k]; w[4 * k + 1] = (char)(t[k] >> 8); w[4 * k + 2] = (char)(t[k] >> 16); w[4 * k + 3] = (char)(t[k] >> 24); }
-	}
-	for (uint32_t i = head + 16u * body + threadIdx.x; i < L; i += 256) o[i] = s[i];
+	// A wavefront of this kernel must fit beside the persistent k_classify of the context whose turn it is (3 x 168 of a
+	// SIMD's 512 VGPRs): uniform base addresses, one 32-bit offset and one data register per lane -- 8 VGPRs.
+	const uint32_t r = blockIdx.x;
+	const char *s = src[r];
+	char *o = ascii + rd[r].seq_off;
+	const uint32_t L = rd[r].len, body = L & ~3u;
+	for (uint32_t i = 4u * threadIdx.x; i < body; i += 256u) *reinterpret_cast<dsb_u32_any *>(o + i) = *reinterpret_cast<const dsb_u32_any *>(s + i);
+	if (threadIdx.x < L - body) o[body + threadIdx.x] = s[body + threadIdx.x];
 }
 
 // one block per read; byte strands
@@ -897,7 +892,46 @@ extern "C" int dsb_ctx_select_slot(dsb_ctx *c, int slot)
 	c->cur = slot;
 	return DSB_OK;
 }
-extern "C" void *dsb_host_alloc(size_t bytes) { void *p = nullptr; return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr; }
+// Pinned host memory for read text.  The pages are made by the driver on behalf of the calling thread, on the NUMA node
+// of the CPU it runs on: for the duration of the call the thread is moved to the CPUs of the node the current GPU hangs
+// off (a buffer on the other socket crosses the inter-socket link on every upload).  DSB_NO_NUMA=1 leaves the thread alone.
+#include <sched.h>
+static bool gpu_node_cpus(cpu_set_t *set)
+{
+	int dev = 0; char bdf[64] = {0};
+	if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetPCIBusId(bdf, sizeof bdf, dev) != hipSuccess) return false;
+	for (char *q = bdf; *q; q++) *q = (char)tolower(*q);
+	char path[192]; snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+	FILE *f = fopen(path, "r"); if (!f) return false;
+	int node = -1; if (fscanf(f, "%d", &node) != 1) node = -1;
+	fclose(f);
+	if (node < 0) return false;
+	snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+	f = fopen(path, "r"); if (!f) return false;
+	char list[4096] = {0}; const bool got = fgets(list, sizeof list, f) != nullptr; fclose(f);
+	if (!got) return false;
+	CPU_ZERO(set); int n = 0;
+	for (char *q = list; *q && *q != '\n';) {               // "0-63,128-191"
+		char *e; long a = strtol(q, &e, 10), b = a;
+		if (e == q) break;
+		if (*e == '-') { q = e + 1; b = strtol(q, &e, 10); }
+		for (long c = a; c <= b && c < CPU_SETSIZE; c++) { CPU_SET((int)c, set); n++; }
+		q = (*e == ',') ? e + 1 : e;
+	}
+	return n > 0;
+}
+extern "C" void *dsb_host_alloc(size_t bytes)
+{
+	cpu_set_t old, want; bool moved = false;
+	if (!getenv("DSB_NO_NUMA") && sched_getaffinity(0, sizeof old, &old) == 0 && gpu_node_cpus(&want)) {
+		cpu_set_t both; CPU_AND(&both, &old, &want);          // stay inside what the process is allowed to use
+		if (CPU_COUNT(&both) > 0) moved = sched_setaffinity(0, sizeof both, &both) == 0;
+	}
+	void *p = nullptr;
+	const bool ok = hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess;
+	if (moved) sched_setaffinity(0, sizeof old, &old);
+	return ok ? p : nullptr;
+}
 extern "C" void dsb_host_free(void *p) { if (p) hipHostFree(p); }
 
 template <class T> static int grow(T **p, size_t *cap, size_t need)
@@ -1062,7 +1096,7 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 			if ((rc = grow(&s.d_src, &s.cap_src, n + 1))) return rc;
 			HIPCHK(hipMemcpyAsync(s.d_src, src.data(), n * sizeof(char *), hipMemcpyHostToDevice, c->stream));
 			HIPCHK(hipStreamSynchronize(c->stream));       // `src` goes out of scope
-			hipLaunchKernelGGL(k_gather_text, dim3((unsigned)n), dim3(256), 0, c->stream, (const DsbReadDesc *)s.d_rd, (const char *const *)s.d_src, s.d_ascii);
+			hipLaunchKernelGGL(k_gather_text, dim3((unsigned)n), dim3(64), 0, c->stream, (const DsbReadDesc *)s.d_rd, (const char *const *)s.d_src, s.d_ascii);
 		} else if (ext_text) HIPCHK(hipMemcpyAsync(s.d_ascii, ext_text, ext_len, hipMemcpyHostToDevice, c->stream));
 		else {
 			// sequences: copied read by read out of the caller's buffers (caller owns read memory)
