@@ -49,22 +49,6 @@ __device__ __forceinline__ uint32_t d_code(uint8_t ch)
 	return (ch == 'A' || ch == 'a') ? 0u : (ch == 'G' || ch == 'g') ? 2u : (ch == 'T' || ch == 't') ? 3u : 1u;
 }
 
-// sequence lines of a FASTQ text in pinned host memory -> contiguous ASCII blob in HBM: the kernel reads the host text
-// in place (zero-copy over PCIe), so only the sequence bytes travel -- half of a FASTQ file is quality lines.
-// One wavefront per read; src[i] = host address of read i, dst offset = its seq_off.
-typedef uint32_t __attribute__((aligned(1), may_alias)) dsb_u32_any;
-__global__ void __launch_bounds__(64) k_gather_text(const DsbReadDesc *rd, const char *const *src, char *ascii)
-{
-	// A wavefront of this kernel must fit beside the persistent k_classify of the context whose turn it is (3 x 168 of a
-	// SIMD's 512 VGPRs): uniform base addresses, one 32-bit offset and one data register per lane -- 8 VGPRs.
-	const uint32_t r = blockIdx.x;
-	const char *s = src[r];
-	char *o = ascii + rd[r].seq_off;
-	const uint32_t L = rd[r].len, body = L & ~3u;
-	for (uint32_t i = 4u * threadIdx.x; i < body; i += 256u) *reinterpret_cast<dsb_u32_any *>(o + i) = *reinterpret_cast<const dsb_u32_any *>(s + i);
-	if (threadIdx.x < L - body) o[body + threadIdx.x] = s[body + threadIdx.x];
-}
-
 // one block per read; byte strands
 __global__ void __launch_bounds__(256) k_encode_bytes(const DsbReadDesc *rd, const char *ascii, uint8_t *bin)
 {
@@ -743,7 +727,6 @@ struct InSlot {
 	std::vector<DsbReadDesc> h_rd;
 	size_t n_reads = 0; uint64_t n_words_total = 0, total_bases = 0, total_windows = 0, seed_entries = 0; uint32_t max_len = 0, min_len = 0;
 	uint32_t *d_scan_order = nullptr; size_t cap_scan_order = 0;   // reads longest first (ragged batches only), for k_seed_scan
-	const char **d_src = nullptr; size_t cap_src = 0;              // host addresses of the sequence lines (k_gather_text)
 	bool ragged = false;
 };
 
@@ -789,7 +772,7 @@ extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
 	if (c->stream2) hipStreamSynchronize(c->stream2);
-	for (InSlot &s : c->in) { hipFree(s.d_rd); hipFree(s.d_ascii); hipFree(s.d_scan_order); hipFree(s.d_src); }
+	for (InSlot &s : c->in) { hipFree(s.d_rd); hipFree(s.d_ascii); hipFree(s.d_scan_order); }
 	hipFree(c->d_wd); hipFree(c->d_bin); hipFree(c->d_pk); hipFree(c->d_bits);
 	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->arena_big.base); hipFree(c->d_score); hipFree(c->d_order); hipFree(c->d_heavy); hipFree(c->d_seeds); hipFree(c->d_sinfo); hipFree(c->syn0); hipFree(c->syn1);
 	if (c->dbg_host) hipHostFree(c->dbg_host);
@@ -1054,16 +1037,9 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 	const int k = c->dx.ek_len;
 	s.h_rd.resize(n);
 	uint64_t seq_off = 0, bin_off = 0, pk_off = 0, bit_off = 0, windows = 0, seed_off = 0; uint32_t max_len = 64, min_len = 0xffffffffu; int hist = c->hist_max;
-	// a caller's text in pinned (device-visible) host memory is not copied as a whole: a kernel fetches the sequence lines (k_gather_text)
-	bool gather = false;
-	if (ext_text && n && !getenv("DSB_NO_GATHER")) {
-		hipPointerAttribute_t at;
-		if (hipPointerGetAttributes(&at, ext_text) == hipSuccess && at.type == hipMemoryTypeHost) gather = true;
-		else (void)hipGetLastError();
-	}
 	for (size_t i = 0; i < n; i++) {
 		DsbReadDesc &d = s.h_rd[i];
-		d.len = reads[i].len; d.seq_off = (ext_text && !gather) ? ext_off[i] : seq_off; d.bin_off = bin_off; d.pk_off = pk_off; d.bit_off = bit_off;
+		d.len = reads[i].len; d.seq_off = ext_text ? ext_off[i] : seq_off; d.bin_off = bin_off; d.pk_off = pk_off; d.bit_off = bit_off;
 		d.n_win = d.len >= 40 ? d.len - k + 1 : 0; d.n_words = (d.n_win + 63) / 64;
 		d.hist_max = hist; if ((int)d.len > hist) hist = d.len;
 		d.seed_off = seed_off; seed_off += ((uint64_t)d.len >> 1) + 64;
@@ -1078,7 +1054,7 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 	s.min_len = n ? min_len : 0; s.ragged = n && (uint64_t)max_len > (uint64_t)min_len + (min_len >> 3) + 64;
 	int rc;
 	if ((rc = grow(&s.d_rd, &s.cap_rd, n + 1))) return rc;
-	if ((rc = grow(&s.d_ascii, &s.cap_ascii, ((ext_text && !gather) ? ext_len : (size_t)seq_off) + 64))) return rc;
+	if ((rc = grow(&s.d_ascii, &s.cap_ascii, (ext_text ? ext_len : (size_t)seq_off) + 64))) return rc;
 	if ((rc = ensure_buffers(c, n, max_len, bin_off, pk_off, bit_off, seed_off))) return rc;
 	if (n) {
 		HIPCHK(hipMemcpyAsync(s.d_rd, s.h_rd.data(), n * sizeof(DsbReadDesc), hipMemcpyHostToDevice, c->stream));
@@ -1090,14 +1066,7 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 			if ((rc = grow(&s.d_scan_order, &s.cap_scan_order, n + 1))) return rc;
 			HIPCHK(hipMemcpy(s.d_scan_order, ord.data(), n * 4, hipMemcpyHostToDevice));
 		}
-		if (gather) {
-			std::vector<const char *> src(n);
-			for (size_t i = 0; i < n; i++) src[i] = reads[i].p;
-			if ((rc = grow(&s.d_src, &s.cap_src, n + 1))) return rc;
-			HIPCHK(hipMemcpyAsync(s.d_src, src.data(), n * sizeof(char *), hipMemcpyHostToDevice, c->stream));
-			HIPCHK(hipStreamSynchronize(c->stream));       // `src` goes out of scope
-			hipLaunchKernelGGL(k_gather_text, dim3((unsigned)n), dim3(64), 0, c->stream, (const DsbReadDesc *)s.d_rd, (const char *const *)s.d_src, s.d_ascii);
-		} else if (ext_text) HIPCHK(hipMemcpyAsync(s.d_ascii, ext_text, ext_len, hipMemcpyHostToDevice, c->stream));
+		if (ext_text) HIPCHK(hipMemcpyAsync(s.d_ascii, ext_text, ext_len, hipMemcpyHostToDevice, c->stream));
 		else {
 			// sequences: copied read by read out of the caller's buffers (caller owns read memory)
 			std::vector<char> stage((size_t)seq_off);
