@@ -511,14 +511,18 @@ static int index_main(int argc, char **argv)
 	return 0;
 }
 
+int analysis_main(int argc, char **argv, const char *version);   /* desamba_analysis.c */
+
 #ifndef DSB_CLI_NO_MAIN
 int main(int argc, char **argv)
-{	/* dispatcher, src/main.c:35-53: `classify` and `index` are in scope of this build */
+{	/* dispatcher, src/main.c:35-53: `classify`, `index` and `analysis ana_meta[_base]` are in scope of this build */
 	if (argc >= 2 && strcmp(argv[1], "index") == 0) return index_main(argc - 1, argv + 1);
+	if (argc >= 2 && strcmp(argv[1], "analysis") == 0) return analysis_main(argc - 1, argv + 1, dsb_version());
 	if (argc < 2 || strcmp(argv[1], "classify") != 0) {
 		fprintf(stderr, "\nProgram: deSAMBA (desamba_amd)\nUsage:   deSAMBA classify [options] <IndexDir> <reads...>\n"
 		        "         deSAMBA index [-g DEV] [SortedKmer] <Reference> <IndexDir>\n"
-		        "         (kmersort / analysis are outside this build: use the reference binary)\n\n");
+		        "         deSAMBA analysis ana_meta|ana_meta_base <SAM_file.sam> <nodes.dmp>\n"
+		        "         (kmersort is not needed: `index` takes the 31-mers from the reference itself)\n\n");
 		return argc < 2 ? 0 : 1;
 	}
 	int rc = classify_main(argc - 1, argv + 1);
