@@ -206,7 +206,7 @@ def main():
     ap.add_argument("--no-seed-hbm", action="store_true", help="skip the seed-lookup measurement on synthetic multi-GiB filter tables")
     ap.add_argument("--no-second-index", action="store_true", help="skip building and measuring the second (synthetic strain) index")
     ap.add_argument("--second-index-mbp", type=int, default=320)
-    ap.add_argument("--second-index-reads", type=int, default=16384)
+    ap.add_argument("--second-index-reads", type=int, default=65536)
     ap.add_argument("--second-index-parity-reads", type=int, default=256)
     ap.add_argument("--seed-hbm-mib", type=int, default=2048, help="size of each synthetic filter table (MiB, power of two 128 .. 16384)")
     ap.add_argument("--slots", type=int, default=0, help="reads in flight per GPU (0 = library default)")
