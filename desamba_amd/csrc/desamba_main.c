@@ -246,6 +246,18 @@ static int parse_parallel(batch_t *b, size_t end, int eof, uint32_t *hist, size_
 	return 1;
 }
 
+typedef struct { app_t *a; batch_t *b; int n; } prefill_t;
+static void *prefill_main(void *arg)
+{
+	prefill_t *p = arg;
+	for (int i = 0; i < p->n; i++) {
+		p->b[i].text = dsb_host_alloc(p->a->batch_cap + 64);
+		if (!p->b[i].text) break;                      /* the reader tries again (and reports) when it needs the buffer */
+		p->b[i].cap = p->a->batch_cap;
+	}
+	return NULL;
+}
+
 static void *reader_main(void *arg)
 {
 	app_t *a = arg; long seqno = 0;
@@ -448,19 +460,24 @@ static int classify_main(int argc, char **argv)
 	if (a.batch_cap < (1 << 16)) a.batch_cap = 1 << 16;
 	setvbuf(a.out, NULL, _IOFBF, 8 << 20);
 
-	fprintf(stderr, "loading index\t");
-	int rc = dsb_index_open(index_dir, &a.idx);
-	if (rc) { fprintf(stderr, "\n[load_idx] %s\n", dsb_strerror(rc)); exit(1); }
 	/* CTX_PER_DEV contexts per listed device; the contexts of one device share its staged index */
 	int ids[MAX_CTX]; a.n_ctx = 0;
 	for (int k = 0; k < CTX_PER_DEV; k++) for (int d = 0; d < n_dev; d++) ids[a.n_ctx++] = dev[d];
+	/* the pinned text buffers of the batches are made while the index loads (pinning 1.5 GB takes a few tenths of a
+	 * second, and HIP calls of the GPU threads would wait behind it) */
+	static batch_t batches[N_BATCH];
+	prefill_t pf = { &a, batches, a.n_ctx + 2 };
+	pthread_t th_pf; int have_pf = !a.pageable && pthread_create(&th_pf, NULL, prefill_main, &pf) == 0;
+	fprintf(stderr, "loading index\t");
+	int rc = dsb_index_open(index_dir, &a.idx);
+	if (rc) { fprintf(stderr, "\n[load_idx] %s\n", dsb_strerror(rc)); exit(1); }
 	rc = dsb_ctx_create_multi(a.idx, ids, a.n_ctx, &a.o, &a.multi);
 	if (rc) { fprintf(stderr, "\n[dsb_ctx_create] %s\n", dsb_strerror(rc)); exit(1); }
 	for (int k = 0; k < a.n_ctx; k++) a.ctx[k] = dsb_multi_ctx(a.multi, k);
 	double t0 = now(), cpu0 = cputime();
 	fprintf(stderr, "Start classify\n");
 	q_init(&a.free_q); q_init(&a.parsed_q); q_init(&a.done_q);
-	static batch_t batches[N_BATCH];
+	if (have_pf) pthread_join(th_pf, NULL);
 	for (int i = 0; i < a.n_ctx + 2; i++) q_push(&a.free_q, &batches[i]);
 	pthread_t th_r, th_w, th_g[MAX_CTX]; gpu_arg_t ga[MAX_CTX];
 	pthread_create(&th_r, NULL, reader_main, &a);
