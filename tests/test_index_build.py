@@ -72,6 +72,15 @@ def test_kmer_missing_from_a_supplied_list_is_an_error(tmp_path):
         build_lib.emu_build(os.path.join(GOLD, "graph1.fa.gz"), str(tmp_path / "idx"), kmer_srt=srt)
 
 
+@pytest.mark.parametrize("text", [b">short\nACGTACGTACGTACGTACGT\n", b">no_kmers\n" + b"ACGTACGTAC" * 2 + b"N" + b"TTGCA" * 5 + b"\n>n\n" + b"N" * 100 + b"\n"])
+def test_references_without_a_31_mer_are_refused(text, tmp_path):
+    """a reference shorter than 31 bases, or without any ACGT run of 31: an error code, not a crash (the reference's builder
+    reads an empty kmer.srt and asserts later)"""
+    fa = tmp_path / "r.fa"; fa.write_bytes(text)
+    with pytest.raises(RuntimeError):
+        build_lib.emu_build(str(fa), str(tmp_path / "idx"))
+
+
 def test_reader_view_of_the_awkward_fasta():
     """the plain-Python restatement of the reader used to make the reader case's k-mer list sees what the reference saw
     (names and lengths are pinned by the golden .ref_i digest; this spells them out)"""
