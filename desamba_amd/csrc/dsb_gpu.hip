@@ -49,16 +49,27 @@ __device__ __forceinline__ uint32_t d_code(uint8_t ch)
 	return (ch == 'A' || ch == 'a') ? 0u : (ch == 'G' || ch == 'g') ? 2u : (ch == 'T' || ch == 't') ? 3u : 1u;
 }
 
-// one block per read; byte strands
+// one block per read; byte strands.  Eight bases per thread and step: one 8-byte load of the text, one 8-byte store
+// into the forward strand, one (byte-reversed, complemented) into the reverse strand.
+typedef uint64_t __attribute__((aligned(1), may_alias)) dsb_u64_any;
 __global__ void __launch_bounds__(256) k_encode_bytes(const DsbReadDesc *rd, const char *ascii, uint8_t *bin)
 {
 	DsbReadDesc d = rd[blockIdx.x];
 	const char *s = ascii + d.seq_off;
 	uint8_t *base = bin + d.bin_off, *F = base + DSB_QPAD_L, *R = F + d.len;
-	uint32_t L = d.len;
+	const uint32_t L = d.len, body = L & ~7u;
 	if (threadIdx.x < DSB_QPAD_L) base[threadIdx.x] = 0;
 	if (threadIdx.x < DSB_QPAD_R) R[L + threadIdx.x] = DSB_QPAD_R_VAL;
-	for (uint32_t i = threadIdx.x; i < L; i += 256) {
+	for (uint32_t i = 8u * threadIdx.x; i < body; i += 2048u) {
+		const uint64_t t = *reinterpret_cast<const dsb_u64_any *>(s + i);
+		uint64_t f = 0;
+#pragma unroll
+		for (int k = 0; k < 8; k++) f |= (uint64_t)d_code((uint8_t)(t >> (8 * k))) << (8 * k);
+		*reinterpret_cast<dsb_u64_any *>(F + i) = f;
+		// reverse strand: base i + k goes to R[L - 1 - i - k] as its complement (3 - code)
+		*reinterpret_cast<dsb_u64_any *>(R + (L - 8u - i)) = __builtin_bswap64(0x0303030303030303ULL - f);
+	}
+	for (uint32_t i = body + threadIdx.x; i < L; i += 256) {
 		uint32_t c = d_code((uint8_t)s[i]);
 		F[i] = (uint8_t)c; R[L - 1 - i] = (uint8_t)(3u - c);
 	}
