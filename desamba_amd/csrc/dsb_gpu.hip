@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(256) k_synth_table(uint8_t *tab, uint64_t n_by
 // The batch ends when its slowest read ends, and the slow reads are the ones whose sparse DP explodes:
 // tandem-repeat-like reads, where every reference 9-mer matches many read positions.  k_repeat_score
 // estimates that cheaply -- the number of 12-mers of the forward strand that already occurred in the read,
-// (every second one) via a 2-hash Bloom filter of 2^18 bits in LDS -- and k_order sorts the reads into 32 log2 buckets,
+// (every second one) via a 2-hash Bloom filter of 2^18 bits in LDS -- and k_order sorts the reads into 2048 buckets (64 per octave),
 // heaviest first.  Only the order of processing changes, never a result.
 __global__ void __launch_bounds__(256) k_repeat_score(const DsbReadDesc *rd, const uint64_t *pk, uint32_t *score)
 {
@@ -374,16 +374,25 @@ __global__ void __launch_bounds__(256) k_repeat_score(const DsbReadDesc *rd, con
 	__syncthreads();
 	if (threadIdx.x == 0) score[blockIdx.x] = dup;
 }
+// 2048 buckets: 64 per octave of the score (the heaviest reads differ by less than a factor of two: whole octaves put
+// hundreds of them into one bucket in arbitrary order, and a heavy read that starts late is the tail of the launch)
+__device__ __forceinline__ uint32_t order_bucket(uint32_t s)
+{
+	s |= 1u;
+	const uint32_t lg = 31u - (uint32_t)__clz((int)s);
+	const uint32_t mant = lg >= 6u ? (s >> (lg - 6u)) & 63u : (s << (6u - lg)) & 63u;
+	return lg * 64u + mant;
+}
 __global__ void __launch_bounds__(1024) k_order(const uint32_t *score, uint32_t n, uint32_t *order)
 {
-	__shared__ uint32_t hist[32], start[32];
-	if (threadIdx.x < 32) hist[threadIdx.x] = 0;
+	__shared__ uint32_t hist[2048], start[2048];
+	hist[threadIdx.x] = 0; hist[threadIdx.x + 1024] = 0;
 	__syncthreads();
-	for (uint32_t i = threadIdx.x; i < n; i += 1024) { uint32_t b = 31u - (uint32_t)__clz((int)(score[i] | 1u)); atomicAdd(&hist[b], 1u); }
+	for (uint32_t i = threadIdx.x; i < n; i += 1024) atomicAdd(&hist[order_bucket(score[i])], 1u);
 	__syncthreads();
-	if (threadIdx.x == 0) { uint32_t acc = 0; for (int b = 31; b >= 0; b--) { start[b] = acc; acc += hist[b]; } }
+	if (threadIdx.x == 0) { uint32_t acc = 0; for (int b = 2047; b >= 0; b--) { start[b] = acc; acc += hist[b]; } }
 	__syncthreads();
-	for (uint32_t i = threadIdx.x; i < n; i += 1024) { uint32_t b = 31u - (uint32_t)__clz((int)(score[i] | 1u)); order[atomicAdd(&start[b], 1u)] = i; }
+	for (uint32_t i = threadIdx.x; i < n; i += 1024) order[atomicAdd(&start[order_bucket(score[i])], 1u)] = i;
 }
 
 // ---- classify kernel: persistent waves, one read each ------------------------------------------
@@ -531,8 +540,8 @@ DSB_DEFINE_CLASSIFY(k_classify_second, dsb_g64, 64)
 // runs classify_read as everywhere else, the other waves sleep at the workgroup barrier and are woken for the pass over
 // the old predecessors of a batch of DP nodes (sdp_batch_old_mw), which they split chunk by chunk.  Work items as in
 // k_classify (atomic counter over the LPT order); every wave reaches every barrier, so the grid drains.
-// MWW wavefronts per read: 4 for the early launch (it runs beside the main launch and its helper waves hold wave slots the
-// whole time), 8 for the pass over the reads given up as heavy (the device is theirs by then)
+// MWW wavefronts per read (8 in both uses: the 16 heaviest reads of the order from the start, beside the main launch --
+// their helper waves hold 112 wave slots the whole time -- and the pass over the reads given up as heavy)
 template <int MWW>
 __global__ void __launch_bounds__(64 * MWW, DSB_WAVES_PER_EU) k_classify_heavy(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,
         const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout,
@@ -1210,14 +1219,14 @@ static int batch_run_locked(dsb_ctx *c)
 		hipLaunchKernelGGL(k_seed_probe_reads, dim3(n_heavy * DSB_HPROBE_SPLIT), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const uint32_t *)c->d_order, c->d_pk, c->d_bits, c->d_summ, c->summ_shift);
 		HIPCHK(hipEventRecord(c->ev_hprobe, c->stream));
 		HIPCHK(hipEventRecord(c->ev_order, c->stream));             // order_ms covers scoring, ordering and these probes
-		// the very heaviest of them (DSB_HEAVY_MW, default 32) get several wavefronts each (k_classify_heavy) on a third stream
-		unsigned n_mw = 32;
+		// the very heaviest of them (DSB_HEAVY_MW, default 16) get eight wavefronts each (k_classify_heavy) on a third stream
+		unsigned n_mw = 16;
 		if (const char *e = getenv("DSB_HEAVY_MW")) n_mw = (unsigned)atoi(e);
 		if (n_mw > n_heavy) n_mw = n_heavy;
 		c->timing.n_heavy_mw = n_mw;
 		if (n_mw) {
 			HIPCHK(hipStreamWaitEvent(c->stream3, c->ev_hprobe, 0));
-			hipLaunchKernelGGL(k_classify_heavy<4>, dim3(n_mw), dim3(64 * 4), 0, c->stream3, dx1, (const DsbReadDesc *)s.d_rd, (uint32_t)n_mw, (const unsigned int *)nullptr, (const uint32_t *)c->d_order, c->d_bin,
+			hipLaunchKernelGGL(k_classify_heavy<8>, dim3(n_mw), dim3(64 * 8), 0, c->stream3, dx1, (const DsbReadDesc *)s.d_rd, (uint32_t)n_mw, (const unsigned int *)nullptr, (const uint32_t *)c->d_order, c->d_bin,
 			                   (const uint64_t *)c->d_bits, c->arena, c->d_counters + 10, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, (uint32_t)c->n_slots,
 			                   (unsigned long long *)(c->d_counters + 16 + 8), (const uint64_t *)c->d_pk, (DsbSeed *)nullptr, (const DsbSeedInfo *)c->d_sinfo);
 			HIPCHK(hipEventRecord(c->ev_heavy3, c->stream3));
