@@ -541,7 +541,7 @@ DSB_DEFINE_CLASSIFY(k_classify_second, dsb_g64, 64)
 // the old predecessors of a batch of DP nodes (sdp_batch_old_mw), which they split chunk by chunk.  Work items as in
 // k_classify (atomic counter over the LPT order); every wave reaches every barrier, so the grid drains.
 // MWW wavefronts per read (8 in both uses: the 16 heaviest reads of the order from the start, beside the main launch --
-// their helper waves hold 112 wave slots the whole time -- and the pass over the reads given up as heavy)
+// their helper waves hold 112 wave slots the whole time (32 reads: +1 % on the bench workload, -15 % on the tandem-repeat strain index) -- and the pass over the reads given up as heavy)
 template <int MWW>
 __global__ void __launch_bounds__(64 * MWW, DSB_WAVES_PER_EU) k_classify_heavy(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,
         const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout,
