@@ -512,7 +512,7 @@ def test_seed_lookup_on_synthetic_multi_gib_tables(demo, tmp_path, monkeypatch):
 
 @pytest.mark.parametrize("name", ["heavy", "wrapq", "ont20k", "ont5k_e25", "manyanchors"])
 def test_heavy_reads_on_several_wavefronts(gpu, name, monkeypatch):
-    """k_classify_heavy: the very heaviest reads of a batch run on a workgroup of four wavefronts each (wave 0 runs the read,
+    """k_classify_heavy: the very heaviest reads of a batch run on a workgroup of eight wavefronts each (wave 0 runs the read,
     the others split the old-predecessor pass of the batched sparse DP); forced onto small golden sets"""
     D, idx, ctx = gpu
     monkeypatch.setenv("DSB_HEAVY_FIRST", "16"); monkeypatch.setenv("DSB_HEAVY_MW", "16")
