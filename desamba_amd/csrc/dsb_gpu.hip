@@ -1187,6 +1187,14 @@ static int batch_run_locked(dsb_ctx *c)
 	// of 12: both stream the packed reads.)
 	hipLaunchKernelGGL(k_repeat_score, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, c->d_pk, c->d_score);
 	hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, c->stream, c->d_score, (uint32_t)n, c->d_order);
+	if (const char *of = getenv("DSB_ORDER_FILE")) {
+		// experiments: a processing order from outside (n x u32, a permutation of the reads) -- e.g. the measured wave times of an
+		// earlier run of the same batch, to see what a perfect longest-first order is worth.  Changes no result.
+		std::vector<uint32_t> ord(n); FILE *f = fopen(of, "rb");
+		if (f && fread(ord.data(), 4, n, f) == n) HIPCHK(hipMemcpyAsync(c->d_order, ord.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+		if (f) fclose(f);
+		HIPCHK(hipStreamSynchronize(c->stream));
+	}
 	HIPCHK(hipEventRecord(c->ev_order, c->stream));
 	// Head start for the tail: the kernel's duration is the duration of its heaviest read (tandem repeats: minutes of
 	// sparse DP on the CPU, ~0.2 s here).  The first n_heavy reads of the LPT order get their probes and their own
