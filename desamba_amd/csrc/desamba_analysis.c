@@ -1,5 +1,6 @@
 /* `deSAMBA analysis ana_meta | ana_meta_base <SAM> <nodes.dmp>` -- the taxonomy roll-up of a classify result
- * (simDataTest / ana_meta_des / ana_meta_des_base, src/analysis.c:2639-2641,1831-1855).
+ * (simDataTest / ana_meta_des / ana_meta_des_base, src/analysis.c:2639-2641,1831-1855), and the three
+ * FASTQ helpers of the same usage text (count_base, split_fastq, fastq_to_fasta).
  *
  * Host-side text processing, no GPU: it is here so that the tool is usable end to end.  The reference converts the SAM
  * into a temporary record file and reads it back (dump_des_sam_file + getOneSAM src/analysis.c:430-464,196-300,
@@ -215,12 +216,80 @@ static int ana_meta(const char *sam, const char *nodes, int by_base)
 	return 0;
 }
 
+/* ---- count_base / split_fastq / fastq_to_fasta (src/analysis.c:2372-2387,2440-2466,2584-2596): loops over the records the
+ * reference's reader delivers (kseq_read, src/lib/utils.c:939-977 -- the rules of dsb_fastq_scan.h: '\n' is the only line
+ * end, the first character of a sequence line is data whatever it is, quality in whole lines).  The reader keeps its
+ * comment and quality strings from record to record and only overwrites them when a record has one, so a record without a
+ * comment is printed with the previous record's (and "(null)" before the first): kept, it is in the output. */
+#include <zlib.h>
+#include <ctype.h>
+typedef struct { char *s; size_t l, m; } str_t;
+typedef struct { gzFile f; unsigned char buf[1 << 16]; int begin, end, eof, last; str_t name, comment, seq, qual; } rd_t;
+static int rd_getc(rd_t *r)
+{
+	if (r->eof && r->begin >= r->end) return -1;
+	if (r->begin >= r->end) { r->begin = 0; r->end = gzread(r->f, r->buf, sizeof r->buf); if (r->end < (int)sizeof r->buf) r->eof = 1; if (r->end <= 0) { r->end = 0; return -1; } }
+	return r->buf[r->begin++];
+}
+static void str_put(str_t *s, int c) { if (s->l + 2 > s->m) { s->m = s->m ? 2 * s->m : 256; s->s = (char *)realloc(s->s, s->m); } s->s[s->l++] = (char)c; s->s[s->l] = 0; }
+static void str_end(str_t *s) { if (!s->s) { s->m = 256; s->s = (char *)calloc(1, s->m); } s->s[s->l] = 0; }
+/* up to `delim` (0: any white space); the delimiter is consumed and returned (-1: the file ended first) */
+static int rd_until(rd_t *r, int delim, str_t *s)
+{
+	int c;
+	while ((c = rd_getc(r)) != -1 && !(delim ? c == delim : isspace(c))) str_put(s, c);
+	str_end(s);
+	return c;
+}
+static long rd_next(rd_t *r)
+{
+	int c;
+	if (r->last == 0) { while ((c = rd_getc(r)) != -1 && c != '>' && c != '@') {} if (c == -1) return -1; r->last = c; }
+	r->comment.l = r->seq.l = r->qual.l = 0;
+	if (r->eof && r->begin >= r->end) return -1;
+	r->name.l = 0; c = rd_until(r, 0, &r->name);
+	if (c != -1 && c != '\n') rd_until(r, '\n', &r->comment);
+	while ((c = rd_getc(r)) != -1 && c != '>' && c != '+' && c != '@') { str_put(&r->seq, c); rd_until(r, '\n', &r->seq); }
+	if (c == '>' || c == '@') r->last = c;
+	str_end(&r->seq);
+	if (c != '+') return (long)r->seq.l;
+	while ((c = rd_getc(r)) != -1 && c != '\n') {}
+	if (c == -1) return -2;
+	while (!(r->eof && r->begin >= r->end)) { rd_until(r, '\n', &r->qual); if (r->qual.l >= r->seq.l) break; }
+	r->last = 0;
+	return r->seq.l != r->qual.l ? -2 : (long)r->seq.l;
+}
+static const char *nz(const char *s) { return s ? s : "(null)"; }
+static int fastq_tool(int which, const char *path, long begin_, long step_)
+{
+	rd_t *r = (rd_t *)calloc(1, sizeof *r);
+	r->f = gzopen(path, "r");
+	if (!r->f) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", path); return 1; }
+	uint64_t total = 0, n = 0; const int begin = (int)begin_, step = (int)step_;
+	while (rd_next(r) >= 0) {
+		if (which == 0) total += r->seq.l;                                  /* count_base */
+		else if (which == 1) {                                              /* split_fastq: records begin, begin + step, ... */
+			if (step != 0 && (n >= (uint64_t)begin) && ((n - (uint64_t)begin) % (uint64_t)step == 0)) {
+				printf("@%s %s\n%s\n+\n%s\n", nz(r->name.s), nz(r->comment.s), nz(r->seq.s), nz(r->qual.s));
+				total += r->seq.l;
+			}
+		} else printf(">%s %s\n%s\n", nz(r->name.s), nz(r->comment.s), nz(r->seq.s));   /* fastq_to_fasta */
+		n++;
+	}
+	gzclose(r->f);
+	if (which != 2) fprintf(stderr, "%s read number: %ld base number %ld ( %f Mbp)\n", path, (long)n, (long)total, (float)total / 1000000);
+	return 0;
+}
+
 static int analysis_usage(const char *version)
 {
 	fprintf(stderr, "\nProgram:   deSAMBA (desamba_amd, MI355X)\nVersion:   %s\n\n", version);
 	fprintf(stderr, "  Usage:     deSAMBA analysis <command> [file]\n\n  Command list: \n");
 	fprintf(stderr, "    analysis ana_meta    \t [SAM_file.sam] [node.dmp]\n");
 	fprintf(stderr, "    analysis ana_meta_base    [SAM_file.sam] [node.dmp]\n");
+	fprintf(stderr, "    analysis count_base    \t [FASTQ_file.fq]\n");
+	fprintf(stderr, "    analysis split_fastq    \t [FASTQ_file.fq] [start_number] [step_length]\n");
+	fprintf(stderr, "    analysis fastq_to_fasta   [FASTQ_file.fq] \n");
 	fprintf(stderr, "  Basic:\n    [SAM_file.sam]  FILE  Classify file generated from \"classify\" command\n");
 	fprintf(stderr, "    [node.dmp]      FILE  node.dmp file download from: \n                          ftp://ftp.ncbi.nih.gov/pub/taxonomy/taxdump.tar.gz\n\n");
 	return 0;
@@ -234,6 +303,9 @@ int analysis_main(int argc, char **argv, const char *version)
 		if (argc < 4) return analysis_usage(version);
 		return ana_meta(argv[2], argv[3], base);
 	}
+	if (strcmp(argv[1], "count_base") == 0 && argc >= 3) return fastq_tool(0, argv[2], 0, 1);
+	if (strcmp(argv[1], "split_fastq") == 0 && argc >= 5) return fastq_tool(1, argv[2], (long)strtoul(argv[3], 0, 10), (long)strtoul(argv[4], 0, 10));
+	if (strcmp(argv[1], "fastq_to_fasta") == 0 && argc >= 3) return fastq_tool(2, argv[2], 0, 1);
 	fprintf(stderr, "command [%s] unsupported!\n\n", argv[1]);
 	analysis_usage(version);
 	return 0;

@@ -54,6 +54,13 @@ def main():
             os.remove(tmp)
             if os.path.exists(tmp + ".temp"):
                 os.remove(tmp + ".temp")
+    # the FASTQ helpers of the same usage text on the reader fixtures (tests/golden/kseq): stdout + the summary line on stderr
+    kd = os.path.join(ROOT, "tests", "golden", "kseq")
+    for fq in sorted(f for f in os.listdir(kd) if f.endswith((".fq", ".fa"))):
+        for tag, args in (("count_base", ["count_base", fq]), ("fastq_to_fasta", ["fastq_to_fasta", fq]), ("split_1_2", ["split_fastq", fq, "1", "2"]), ("split_0_3", ["split_fastq", fq, "0", "3"])):
+            p = subprocess.run([REF, "analysis"] + args, cwd=kd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+            err = b"".join(l for l in p.stderr.splitlines(True) if b"read number:" in l)
+            open(os.path.join(OUT, "%s.%s.txt" % (fq, tag)), "wb").write(p.stdout + b"--- stderr ---\n" + err)
     print(sorted(os.listdir(OUT)))
 
 

@@ -33,6 +33,21 @@ def test_analysis_output_is_the_reference_s(built, name, sam, cmd, tmp_path):
     assert p.stdout == open(os.path.join(ANA, "%s.%s.txt" % (name, cmd)), "rb").read()
 
 
+KSEQ = os.path.join(GOLDEN, "kseq")
+
+
+@pytest.mark.parametrize("fq", sorted(f for f in os.listdir(KSEQ) if f.endswith((".fq", ".fa"))))
+@pytest.mark.parametrize("tag,args", [("count_base", ["count_base"]), ("fastq_to_fasta", ["fastq_to_fasta"]), ("split_1_2", ["split_fastq", "1", "2"]), ("split_0_3", ["split_fastq", "0", "3"])])
+def test_fastq_helpers_of_analysis(built, fq, tag, args, tmp_path):
+    """count_base / fastq_to_fasta / split_fastq (src/analysis.c:2372-2387,2584-2596,2440-2466) on the reader fixtures: CRLF,
+    multi-line, blank lines, bad quality, FASTA, no final newline -- including the comment a record inherits from the one
+    before it"""
+    p = subprocess.run([CLI, "analysis", args[0], fq] + args[1:], cwd=KSEQ, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0
+    err = b"".join(l for l in p.stderr.splitlines(True) if b"read number:" in l)
+    assert p.stdout + b"--- stderr ---\n" + err == open(os.path.join(ANA, "%s.%s.txt" % (fq, tag)), "rb").read()
+
+
 def test_analysis_usage_and_errors(built, tmp_path):
     p = subprocess.run([CLI, "analysis"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert p.returncode == 0 and b"analysis ana_meta" in p.stderr and p.stdout == b""
