@@ -63,8 +63,15 @@ struct HipBE {
 	bool failed = false;
 	hipStream_t st = 0;
 	int n_cu = 256;
-	template <class T> T *alloc(size_t n) { void *p = nullptr; HIPB(hipMalloc(&p, (n ? n : 1) * sizeof(T))); return (T *)p; }
-	void free(void *p) { if (p) (void)hipFree(p); }
+	std::vector<void *> live;                          // what a failed build leaves behind is freed with the backend
+	~HipBE() { for (void *p : live) (void)hipFree(p); }
+	template <class T> T *alloc(size_t n) { void *p = nullptr; HIPB(hipMalloc(&p, (n ? n : 1) * sizeof(T))); if (p) live.push_back(p); return (T *)p; }
+	void free(void *p)
+	{
+		if (!p) return;
+		for (size_t i = live.size(); i-- > 0;) if (live[i] == p) { live[i] = live.back(); live.pop_back(); break; }
+		(void)hipFree(p);
+	}
 	void zero(void *p, size_t bytes) { HIPB(hipMemsetAsync(p, 0, bytes, st)); }
 	void fill_ff(void *p, size_t bytes) { HIPB(hipMemsetAsync(p, 0xff, bytes, st)); }
 	void to_dev(void *d, const void *s, size_t bytes) { HIPB(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, st)); HIPB(hipStreamSynchronize(st)); }

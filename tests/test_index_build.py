@@ -131,6 +131,25 @@ def test_gpu_build_of_the_demo_index_and_classify_on_it(tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpu_build_errors_are_codes_not_crashes(tmp_path):
+    """a k-mer of the text missing from the supplied list, a reference without any 31-mer, a missing file: error codes (the
+    device memory of a failed build is released with its backend); a good build still works afterwards"""
+    import desamba_amd as D
+    text = gzip.open(os.path.join(GOLD, "graph1.fa.gz")).read()
+    srt = str(tmp_path / "kmer.srt")
+    build_lib.write_kmer_srt_from_text(build_lib.reader_view(text)[1:], srt)
+    with pytest.raises(D.DsbError):
+        D.build_index(os.path.join(GOLD, "graph1.fa.gz"), str(tmp_path / "a"), kmer_srt=srt)
+    (tmp_path / "short.fa").write_bytes(b">s\nACGTACGTAC\n")
+    with pytest.raises(D.DsbError):
+        D.build_index(str(tmp_path / "short.fa"), str(tmp_path / "b"))
+    with pytest.raises(D.DsbError):
+        D.build_index(str(tmp_path / "missing.fa"), str(tmp_path / "c"))
+    D.build_index(os.path.join(GOLD, "graph1.fa.gz"), str(tmp_path / "d"))
+    check_case("graph1", str(tmp_path / "d"))
+
+
+@pytest.mark.gpu
 def test_cli_index_with_and_without_a_kmer_list(tmp_path):
     """`deSAMBA index [SortedKmer] <Reference> <IndexDir>` (build_index_main, src/idx.c:1254-1282)"""
     cli = os.path.join(ROOT, "desamba_amd", "bin", "deSAMBA")
