@@ -64,7 +64,7 @@ class DsbChunk(C.Structure):
 
 EXPORTS = ["dsb_index_open", "dsb_index_close", "dsb_index_n_ref", "dsb_index_ref_name", "dsb_index_ref_len", "dsb_index_ek_len",
            "dsb_index_occ_host", "dsb_ctx_create", "dsb_ctx_destroy", "dsb_ctx_reset_history", "dsb_classify_batch",
-           "dsb_batch_upload", "dsb_batch_upload_fastq", "dsb_batch_upload_text", "dsb_ctx_set_history", "dsb_host_alloc", "dsb_host_free", "dsb_batch_run", "dsb_batch_fetch", "dsb_batch_timing", "dsb_batch_seeds", "dsb_batch_exist_bits",
+           "dsb_batch_upload", "dsb_batch_upload_fastq", "dsb_batch_upload_text", "dsb_ctx_set_history", "dsb_host_alloc", "dsb_host_free", "dsb_host_cpus", "dsb_batch_run", "dsb_batch_fetch", "dsb_batch_timing", "dsb_batch_seeds", "dsb_batch_exist_bits",
            "dsb_format_sam", "dsb_format_des", "dsb_strerror", "dsb_version",
            "dsb_device_count", "dsb_ctx_select_slot", "dsb_ctx_create_multi", "dsb_multi_destroy", "dsb_multi_n", "dsb_multi_ctx",
            "dsb_multi_reset_history", "dsb_multi_classify_batch", "dsb_shard_plan", "dsb_ctx_use_synthetic_filter", "dsb_synthetic_filter_bit", "dsb_index_prefix_interval", "dsb_index_build"]

@@ -4,16 +4,21 @@
  * Extra option: -g LIST  GPUs to run on: "0", "0,1,2", "all"; a device may be listed twice [0].
  *
  * The reference's pipeline (kt_pipeline, src/cly_mt.c:393-410: read -> classify -> write, one batch
- * per step) is kept as three kinds of threads around two device contexts:
- *   reader   fills pinned buffers with raw (plain or gzip) FASTQ/FASTA text and finds the records in
- *            place (record rules of kseq_read, src/lib/utils.c:939-977): no per-read copies; the buffer
- *            goes to the device as it is (dsb_batch_upload_text)
+ * per step) is kept as three kinds of threads around two device contexts per GPU:
+ *   reader   never copies the text.  A plain file is mapped; a gzip file is inflated ahead of the parser by a thread
+ *            of its own per upcoming file (BGZF files block-parallel).  The text is parsed in waves: a wave is cut at
+ *            guessed record starts into one piece per host thread, the pieces are parsed side by side and accepted only
+ *            if each ends exactly where the next begins -- i.e. if the sequential kseq parse (src/lib/utils.c:939-977)
+ *            would have produced the same records; anything else is parsed again sequentially.  A batch is a list of
+ *            dsb_read whose pointers lead into the mapped file / the inflated blocks.
  *   GPU      per listed device two dsb_ctx (they share the index staged in that device's HBM), one host thread
  *            each, so that the upload of one batch overlaps the kernels of another; batches are dealt to
  *            whichever worker is free -- the kt_for of the reference (src/cly_mt.c:389, src/lib/kthread.c:61-86)
- *            with GPUs for threads; max_read_l (src/cly.c:2958), the only cross-read state, travels in the
- *            batch header as the prefix maximum of read length (dsb_ctx_set_history)
- *   writer   formats SAM in input order
+ *            with GPUs for threads; dsb_batch_upload gathers the sequence lines (only those) through pinned chunks on
+ *            several threads; max_read_l (src/cly.c:2958), the only cross-read state, travels in the batch header as
+ *            the prefix maximum of read length (dsb_ctx_set_history)
+ *   writer   formats SAM in input order (several formatter threads per batch)
+ * Host thread counts follow dsb_host_cpus(): the CPUs the process may use, capped by its cgroup quota.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -24,6 +29,8 @@
 #include <pthread.h>
 #include <fcntl.h>
 #include <unistd.h>
+#include <dlfcn.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/time.h>
 #include <sys/resource.h>
@@ -33,19 +40,25 @@
 #define MAX_DEV 16
 #define CTX_PER_DEV 2                 /* contexts per device: the upload of one batch overlaps the kernels of the other */
 #define MAX_CTX (MAX_DEV * CTX_PER_DEV)
-#define N_BATCH (MAX_CTX + 2)          /* batch buffers (allocated on first use; n_ctx + 2 of them are put in circulation) */
-#define MAX_BATCH_READS (1u << 23)
+#define N_BATCH (MAX_CTX + 2)          /* batch records (n_ctx + 2 of them are put in circulation) */
+#define MAX_THREADS 64
 
 static double now(void);
 static void die(const char *msg) { fprintf(stderr, "%s\n", msg); exit(1); }
+static void *xmalloc(size_t n) { void *p = malloc(n ? n : 1); if (!p) die("[classify] out of memory"); return p; }
+static void *xrealloc(void *q, size_t n) { void *p = realloc(q, n ? n : 1); if (!p) die("[classify] out of memory"); return p; }
+
+/* ---------------------------------------------------------------- inflated text blocks (gzip input) */
+typedef struct gzbuf { char *p; size_t cap, len; int eof; struct gzbuf *next; } gzbuf_t;
 
 /* ---------------------------------------------------------------- batches and queues */
 typedef struct {
-	char *text; size_t cap, len;                      /* pinned; the records of this batch lie in text[0, len) */
-	size_t n, cap_n;
-	uint64_t *seq_off, *name_off, *qual_off; uint32_t *seq_len; unsigned char *has_qual;
+	dsb_read *reads; size_t n, cap_n;                 /* pointers into mapped files, inflated blocks, name blocks */
+	size_t bytes;                                     /* text the batch was parsed from */
 	uint32_t hist_before;                             /* longest read of the run before this batch */
 	long seqno;
+	void **own; int n_own, cap_own;                   /* malloc'd blocks the reads point into: names, records joined across blocks */
+	gzbuf_t **gzb; int n_gzb, cap_gzb;                /* inflated blocks the reads point into */
 	dsb_read_result *rr; dsb_hit *hits; size_t cap_rr, cap_hits, n_hits;
 } batch_t;
 
@@ -72,10 +85,18 @@ static void batch_reserve(batch_t *b, size_t n)
 {
 	if (n <= b->cap_n) return;
 	size_t m = b->cap_n ? b->cap_n * 2 : 4096; while (m < n) m *= 2;
-	b->seq_off = realloc(b->seq_off, m * 8); b->name_off = realloc(b->name_off, m * 8); b->qual_off = realloc(b->qual_off, m * 8);
-	b->seq_len = realloc(b->seq_len, m * 4); b->has_qual = realloc(b->has_qual, m);
-	if (!b->seq_off || !b->name_off || !b->qual_off || !b->seq_len || !b->has_qual) die("[classify] out of memory");
+	b->reads = xrealloc(b->reads, m * sizeof *b->reads);
 	b->cap_n = m;
+}
+static void batch_own(batch_t *b, void *p)
+{
+	if (b->n_own == b->cap_own) { b->cap_own = b->cap_own ? b->cap_own * 2 : 16; b->own = xrealloc(b->own, (size_t)b->cap_own * sizeof *b->own); }
+	b->own[b->n_own++] = p;
+}
+static void batch_hold(batch_t *b, gzbuf_t *g)
+{
+	if (b->n_gzb == b->cap_gzb) { b->cap_gzb = b->cap_gzb ? b->cap_gzb * 2 : 16; b->gzb = xrealloc(b->gzb, (size_t)b->cap_gzb * sizeof *b->gzb); }
+	b->gzb[b->n_gzb++] = g;
 }
 
 /* ---------------------------------------------------------------- record parser: dsb_fastq_scan.h (the rules of the
@@ -86,84 +107,223 @@ typedef dsb_rec_t rec_t;
 
 /* ---------------------------------------------------------------- shared state */
 typedef struct {
+	double parse_s, wait_free_s, wait_text_s; size_t bytes, waves, waves_parallel;          /* reader */
+	double fmt_s, write_s; size_t out_bytes;                                                 /* writer */
+	double up_s[MAX_CTX], run_s[MAX_CTX], fetch_s[MAX_CTX], idle_s[MAX_CTX]; long batches[MAX_CTX];   /* device workers */
+	double inflate_s; size_t inflate_out;                                                    /* inflaters (summed over their threads) */
+} trace_t;
+
+typedef struct {
 	int argc; char **argv; int first_file;
 	dsb_index *idx; dsb_multi *multi; dsb_ctx *ctx[MAX_CTX]; dsb_opts o; int full; FILE *out;
 	queue_t free_q, parsed_q, done_q;
-	size_t batch_cap; unsigned long total;
-	int pageable;                                     /* batch buffers from malloc instead of pinned memory (parser tests without a GPU) */
+	size_t wave_bytes;                                /* text parsed per wave (plain files) / per inflated block (gzip) */
+	size_t batch_bytes, batch_reads, batch_max_bytes, batch_max_reads;   /* a batch closes once it has batch_reads reads AND batch_bytes of text, or either maximum */
+	size_t seg_min;                                   /* smallest piece worth a parse thread of its own */
+	int n_parse, n_format, n_inflate;
+	unsigned long total;
 	unsigned long n_badqual;                          /* records dropped because their quality string had the wrong length */
 	unsigned long n_status;                           /* reads whose device status stayed non-zero after the second run */
 	int n_ctx;
+	int trace; trace_t tr; pthread_mutex_t tr_mu;
+	/* recycled inflated blocks */
+	gzbuf_t *gz_free; pthread_mutex_t gz_mu;
 } app_t;
 
-typedef struct { int fd; gzFile gz; } src_t;
-static int src_open(src_t *s, const char *path)
+/* ================================================================ gzip input: inflate ahead of the parser ==========
+ * The reference reads .gz through zlib's gzread on the one reader thread (src/cly_mt.c:553, src/lib/utils.c:841-905).
+ * Here every upcoming .gz file gets an inflater thread that fills blocks of wave_bytes ahead of the parser (at most
+ * GZ_AHEAD blocks per file).  A BGZF file (bgzip: independent deflate blocks of <= 64 KB whose sizes stand in their
+ * headers) is inflated block-parallel: the inflater walks the headers, knows from the ISIZE fields where every block's
+ * text goes, and lets n_inflate threads inflate straight into place.  libdeflate is used when the system has it (found
+ * with dlopen, no build dependency), zlib otherwise; a plain single-member file is one serial zlib stream. */
+#define GZ_AHEAD 4
+typedef struct {
+	app_t *a; const char *path; const unsigned char *z; size_t zlen; int fd;
+	int stream;                                       /* not a regular file (a pipe): read through gzread, plain or gzip, as the reference does */
+	pthread_t th; int started;
+	gzbuf_t *head, *tail; int n_ready, done; pthread_mutex_t mu; pthread_cond_t cv;
+} inflater_t;
+
+typedef void *(*ld_alloc_t)(void); typedef void (*ld_free_t)(void *);
+typedef int (*ld_inflate_t)(void *, const void *, size_t, void *, size_t, size_t *);
+static ld_alloc_t ld_alloc; static ld_free_t ld_free; static ld_inflate_t ld_inflate;
+static void libdeflate_find(void)
 {
-	unsigned char m[2] = {0, 0};
-	s->gz = NULL; s->fd = open(path, O_RDONLY);
-	if (s->fd < 0) return -1;
-	ssize_t k = pread(s->fd, m, 2, 0);
-	if (k == 2 && m[0] == 0x1f && m[1] == 0x8b) {          /* gzip: through zlib like the reference (src/cly_mt.c:553) */
-		s->gz = gzdopen(s->fd, "r");
-		if (!s->gz) { close(s->fd); return -1; }
-		gzbuffer(s->gz, 1 << 20);
+	static int tried = 0; if (tried) return; tried = 1;
+	if (getenv("DSB_CLI_NO_LIBDEFLATE")) return;
+	void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL); if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
+	if (!h) return;
+	ld_alloc = (ld_alloc_t)dlsym(h, "libdeflate_alloc_decompressor"); ld_free = (ld_free_t)dlsym(h, "libdeflate_free_decompressor");
+	ld_inflate = (ld_inflate_t)dlsym(h, "libdeflate_deflate_decompress");
+	if (!ld_alloc || !ld_free || !ld_inflate) ld_alloc = NULL;
+}
+
+static gzbuf_t *gzbuf_get(app_t *a)
+{
+	pthread_mutex_lock(&a->gz_mu);
+	gzbuf_t *g = a->gz_free; if (g) a->gz_free = g->next;
+	pthread_mutex_unlock(&a->gz_mu);
+	if (!g) { g = xmalloc(sizeof *g); g->cap = a->wave_bytes; g->p = xmalloc(g->cap + 64); }
+	g->len = 0; g->eof = 0; g->next = NULL;
+	return g;
+}
+static void gzbuf_put(app_t *a, gzbuf_t *g) { pthread_mutex_lock(&a->gz_mu); g->next = a->gz_free; a->gz_free = g; pthread_mutex_unlock(&a->gz_mu); }
+static void inflater_emit(inflater_t *f, gzbuf_t *g)
+{
+	pthread_mutex_lock(&f->mu);
+	while (f->n_ready >= GZ_AHEAD) pthread_cond_wait(&f->cv, &f->mu);
+	if (f->tail) f->tail->next = g; else f->head = g;
+	f->tail = g; f->n_ready++;
+	pthread_cond_broadcast(&f->cv); pthread_mutex_unlock(&f->mu);
+}
+static gzbuf_t *inflater_next(inflater_t *f)
+{	/* NULL at the end of the file */
+	pthread_mutex_lock(&f->mu);
+	while (!f->head && !f->done) pthread_cond_wait(&f->cv, &f->mu);
+	gzbuf_t *g = f->head;
+	if (g) { f->head = g->next; if (!f->head) f->tail = NULL; f->n_ready--; g->next = NULL; pthread_cond_broadcast(&f->cv); }
+	pthread_mutex_unlock(&f->mu);
+	return g;
+}
+
+/* BGZF block at z[p]: 0 if it is not one; else its total length, *isize = bytes of text in it */
+static size_t bgzf_block(const unsigned char *z, size_t p, size_t zlen, uint32_t *isize)
+{
+	if (p + 18 > zlen || z[p] != 0x1f || z[p + 1] != 0x8b || z[p + 2] != 8 || !(z[p + 3] & 4)) return 0;
+	const unsigned xlen = z[p + 10] | (z[p + 11] << 8);
+	if (p + 12 + xlen > zlen) return 0;
+	size_t q = p + 12, xe = q + xlen, bs = 0;
+	while (q + 4 <= xe) {
+		const unsigned sl = z[q + 2] | (z[q + 3] << 8);
+		if (z[q] == 'B' && z[q + 1] == 'C' && sl == 2 && q + 6 <= xe) bs = (size_t)(z[q + 4] | (z[q + 5] << 8)) + 1;
+		q += 4 + sl;
 	}
-	return 0;
+	if (z[p + 3] & ~4 || bs < 12 + xlen + 8 || p + bs > zlen) return 0;       /* (only FEXTRA set, as bgzip writes it) */
+	const unsigned char *t = z + p + bs - 4;
+	*isize = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+	return bs;
 }
-/* plain files: the copy out of the page cache runs at one core's memcpy speed per thread, so big reads are split */
-#define N_PREAD 8
-typedef struct { int fd; char *buf; size_t len; off_t off; size_t got; } pread_job_t;
-static void *pread_main(void *arg)
+typedef struct { const unsigned char *z; size_t off, len, data_off; char *out; uint32_t isize; } bgzf_job_t;
+typedef struct { bgzf_job_t *job; size_t lo, hi; int ok; } bgzf_part_t;
+static void *bgzf_main(void *arg)
 {
-	pread_job_t *j = arg;
-	while (j->got < j->len) { ssize_t k = pread(j->fd, j->buf + j->got, j->len - j->got, j->off + (off_t)j->got); if (k <= 0) break; j->got += (size_t)k; }
-	return NULL;
-}
-static size_t src_read(src_t *s, char *buf, size_t want)
-{
-	size_t got = 0;
-	static long pread_min = -1;
-	if (pread_min < 0) { const char *e = getenv("DSB_CLI_PREAD_MIN"); pread_min = e ? atol(e) : (64L << 20); }
-	if (!s->gz && want >= (size_t)pread_min) {
-		off_t pos = lseek(s->fd, 0, SEEK_CUR); struct stat st;
-		if (pos >= 0 && fstat(s->fd, &st) == 0 && S_ISREG(st.st_mode)) {
-			size_t avail = st.st_size > pos ? (size_t)(st.st_size - pos) : 0; if (avail > want) avail = want;
-			pthread_t th[N_PREAD]; pread_job_t job[N_PREAD]; size_t part = (avail + N_PREAD - 1) / N_PREAD;
-			for (int i = 0; i < N_PREAD; i++) {
-				size_t o = (size_t)i * part; job[i].fd = s->fd; job[i].buf = buf + o; job[i].off = pos + (off_t)o; job[i].got = 0;
-				job[i].len = o >= avail ? 0 : (avail - o < part ? avail - o : part);
-				pthread_create(&th[i], NULL, pread_main, &job[i]);
-			}
-			int ok = 1;
-			for (int i = 0; i < N_PREAD; i++) { pthread_join(th[i], NULL); if (job[i].got != job[i].len) ok = 0; }
-			if (ok) { lseek(s->fd, pos + (off_t)avail, SEEK_SET); return avail; }
-			lseek(s->fd, pos, SEEK_SET);                          /* short read somewhere: fall back to the sequential loop */
+	bgzf_part_t *pt = arg; void *d = ld_alloc ? ld_alloc() : NULL;
+	pt->ok = 1;
+	for (size_t i = pt->lo; i < pt->hi && pt->ok; i++) {
+		bgzf_job_t *j = &pt->job[i];
+		const unsigned char *in = j->z + j->off + j->data_off; const size_t in_n = j->len - j->data_off - 8;
+		if (d) { size_t got = 0; if (ld_inflate(d, in, in_n, j->out, j->isize, &got) != 0 || got != j->isize) pt->ok = 0; }
+		else {
+			z_stream zs; memset(&zs, 0, sizeof zs);
+			if (inflateInit2(&zs, -15) != Z_OK) { pt->ok = 0; break; }
+			zs.next_in = (Bytef *)in; zs.avail_in = (uInt)in_n; zs.next_out = (Bytef *)j->out; zs.avail_out = j->isize;
+			const int rc = inflate(&zs, Z_FINISH);
+			if (!(rc == Z_STREAM_END || (rc == Z_BUF_ERROR && j->isize == 0)) || zs.total_out != j->isize) pt->ok = 0;
+			inflateEnd(&zs);
 		}
 	}
-	while (got < want) {
-		size_t ask = want - got > (1u << 30) ? (1u << 30) : want - got;
-		long k = s->gz ? (long)gzread(s->gz, buf + got, (unsigned)ask) : (long)read(s->fd, buf + got, ask);
-		if (k <= 0) break;
-		got += (size_t)k;
-	}
-	return got;
+	if (d) ld_free(d);
+	return NULL;
 }
-static void src_close(src_t *s) { if (s->gz) gzclose(s->gz); else close(s->fd); }
+/* serial zlib stream from z[p] on, with gzread's rules: concatenated members are one text, what follows the last member
+ * that is not a gzip header is ignored */
+static void inflate_serial(inflater_t *f, size_t p)
+{
+	app_t *a = f->a; z_stream zs; memset(&zs, 0, sizeof zs);
+	if (inflateInit2(&zs, 15 + 16) != Z_OK) die("[classify] inflateInit2 failed");
+	gzbuf_t *g = gzbuf_get(a);
+	int in_member = 0;
+	while (p < f->zlen || zs.avail_in) {
+		if (!zs.avail_in) { const size_t k = f->zlen - p > (1u << 30) ? (1u << 30) : f->zlen - p; zs.next_in = (Bytef *)(f->z + p); zs.avail_in = (uInt)k; p += k; }
+		if (!in_member) {
+			/* a member starts here only if the gzip magic does (gzread: trailing garbage ends the text) */
+			const unsigned char *q = zs.next_in;
+			if (zs.avail_in >= 2 && !(q[0] == 0x1f && q[1] == 0x8b)) break;
+			if (zs.avail_in < 2 && p >= f->zlen) break;
+			in_member = 1;
+		}
+		if (g->len == g->cap) { inflater_emit(f, g); g = gzbuf_get(a); }
+		zs.next_out = (Bytef *)(g->p + g->len); const size_t room = g->cap - g->len > (1u << 30) ? (1u << 30) : g->cap - g->len; zs.avail_out = (uInt)room;
+		const int rc = inflate(&zs, Z_NO_FLUSH);
+		g->len += room - zs.avail_out;
+		if (rc == Z_STREAM_END) { in_member = 0; inflateReset(&zs); continue; }
+		if (rc != Z_OK && rc != Z_BUF_ERROR) break;                              /* corrupt data: the text ends here, as with gzread */
+		if (rc == Z_BUF_ERROR && zs.avail_in == 0 && p >= f->zlen) break;        /* truncated file */
+	}
+	inflateEnd(&zs);
+	g->eof = 1; inflater_emit(f, g);
+}
+static void *inflater_main(void *arg)
+{
+	inflater_t *f = arg; app_t *a = f->a;
+	const double t0 = now(); size_t out_total = 0;
+	size_t p = 0; uint32_t isz;
+	if (f->stream) {
+		gzFile gz = gzdopen(f->fd, "r");
+		if (!gz) die("[classify] gzdopen failed");
+		gzbuffer(gz, 1 << 20);
+		gzbuf_t *g = gzbuf_get(a);
+		for (;;) {
+			if (g->len == g->cap) { inflater_emit(f, g); g = gzbuf_get(a); }
+			const size_t room = g->cap - g->len > (1u << 30) ? (1u << 30) : g->cap - g->len;
+			const int k = gzread(gz, g->p + g->len, (unsigned)room);
+			if (k <= 0) break;
+			g->len += (size_t)k; out_total += (size_t)k;
+		}
+		g->eof = 1; inflater_emit(f, g);
+		gzclose(gz);
+	} else if (bgzf_block(f->z, 0, f->zlen, &isz) && !getenv("DSB_CLI_NO_BGZF")) {
+		/* groups of blocks whose text fills one output block, inflated in place by n_inflate threads */
+		bgzf_job_t *job = NULL; size_t cap_job = 0; int bad = 0;
+		while (p < f->zlen && !bad) {
+			gzbuf_t *g = gzbuf_get(a); size_t nj = 0, q = p, out = 0, bs;
+			while (q < f->zlen && (bs = bgzf_block(f->z, q, f->zlen, &isz)) != 0 && out + isz <= g->cap) {
+				if (nj == cap_job) { cap_job = cap_job ? cap_job * 2 : 4096; job = xrealloc(job, cap_job * sizeof *job); }
+				const unsigned xlen = f->z[q + 10] | (f->z[q + 11] << 8);
+				job[nj].z = f->z; job[nj].off = q; job[nj].len = bs; job[nj].data_off = 12 + xlen; job[nj].out = g->p + out; job[nj].isize = isz;
+				nj++; out += isz; q += bs;
+			}
+			if (nj == 0) {                                 /* not a BGZF block (or one larger than an output block): the rest goes through zlib */
+				gzbuf_put(a, g);
+				if (q < f->zlen) { inflate_serial(f, q); p = f->zlen; goto finished; }
+				break;
+			}
+			int nt = a->n_inflate; if ((size_t)nt > nj) nt = (int)nj; if (nt < 1) nt = 1;
+			pthread_t th[MAX_THREADS]; bgzf_part_t part[MAX_THREADS];
+			for (int t = 0; t < nt; t++) { part[t].job = job; part[t].lo = nj * (size_t)t / (size_t)nt; part[t].hi = nj * (size_t)(t + 1) / (size_t)nt; if (t) pthread_create(&th[t], NULL, bgzf_main, &part[t]); }
+			bgzf_main(&part[0]);
+			for (int t = 1; t < nt; t++) pthread_join(th[t], NULL);
+			for (int t = 0; t < nt; t++) if (!part[t].ok) bad = 1;
+			if (bad) { gzbuf_put(a, g); break; }               /* corrupt block: the text ends before this group, as a failed gzread ends it */
+			g->len = out; out_total += out; p = q;
+			inflater_emit(f, g);
+		}
+		free(job);
+		gzbuf_t *g = gzbuf_get(a); g->eof = 1; inflater_emit(f, g);          /* (an empty last block: the end mark) */
+	} else inflate_serial(f, 0);
+finished:
+	pthread_mutex_lock(&f->mu); f->done = 1; pthread_cond_broadcast(&f->cv); pthread_mutex_unlock(&f->mu);
+	if (a->trace) { pthread_mutex_lock(&a->tr_mu); a->tr.inflate_s += now() - t0; a->tr.inflate_out += out_total; pthread_mutex_unlock(&a->tr_mu); }
+	return NULL;
+}
 
-/* ---------------------------------------------------------------- parallel parse of one buffer (plain 4-line FASTQ)
- * The buffer is cut at guessed record starts ("\n@", a '+' line two lines later, quality as long as the sequence), every
+/* ================================================================ parallel parse of one wave of text ================
+ * The wave is cut at guessed record starts ("\n@", a '+' line two lines later, quality as long as the sequence), every
  * piece is parsed by its own thread without touching the text, and the pieces are accepted only if each one ends exactly
  * where the next was guessed to start -- i.e. if the sequential kseq parse would have produced the same records.
- * Anything else (multi-line records, '\r', a wrong guess) falls back to the sequential loop. */
-#define N_PARSE 8
+ * Anything else (multi-line records, FASTA, '\r', a wrong guess) is parsed again by the sequential loop. */
 typedef struct {
-	char *t; size_t start, limit, end; int eof, is_last;
-	size_t n, cap; uint64_t *name_off, *name_end, *seq_off, *qual_off; uint32_t *seq_len; unsigned char *has_qual;
-	size_t end_pos; int ok;
+	char *t; size_t start, limit, end; int eof, last_in, sequential;
+	size_t n, cap; const char **name, **seq, **qual; uint32_t *name_len, *seq_len;
+	size_t name_bytes, end_pos; int ok, last_out; unsigned long n_bad; uint32_t max_len;
+	batch_t *b;                                       /* sequential parse: owner of the copies of records that span several lines */
+	/* second pass: the records become dsb_read in the batch */
+	dsb_read *out; char *names;
 } seg_t;
 static size_t guess_record_start(const char *t, size_t from, size_t end)
 {
-	size_t lim = from + (4u << 20) < end ? from + (4u << 20) : end;
+	size_t lim = from + (64u << 20) < end ? from + (64u << 20) : end;
 	for (size_t p = from; p < lim;) {
 		const char *nl = memchr(t + p, '\n', lim - p);
 		if (!nl) break;
@@ -179,140 +339,267 @@ static size_t guess_record_start(const char *t, size_t from, size_t end)
 	}
 	return (size_t)-1;
 }
+static void seg_push(seg_t *g, const char *t, const rec_t *r)
+{
+	if (g->n == g->cap) {
+		size_t m = g->cap ? g->cap * 2 : 4096;
+		g->name = xrealloc(g->name, m * sizeof *g->name); g->seq = xrealloc(g->seq, m * sizeof *g->seq); g->qual = xrealloc(g->qual, m * sizeof *g->qual);
+		g->name_len = xrealloc(g->name_len, m * 4); g->seq_len = xrealloc(g->seq_len, m * 4);
+		g->cap = m;
+	}
+	g->name[g->n] = t + r->name_off; g->name_len[g->n] = (uint32_t)(r->name_end - r->name_off); g->seq[g->n] = t + r->seq_off;
+	g->qual[g->n] = r->has_qual ? t + r->qual_off : NULL; g->seq_len[g->n] = (uint32_t)r->seq_len; g->n++;
+	g->name_bytes += r->name_end - r->name_off + 1;
+	if (r->seq_len > g->max_len) g->max_len = (uint32_t)r->seq_len;
+}
 static void *parse_main(void *arg)
 {
-	seg_t *g = arg; size_t pos = g->start; rec_t r;
-	g->ok = 1; g->n = 0;
+	seg_t *g = arg; size_t pos = g->start; rec_t r; int last = g->last_in;
+	g->ok = 1; g->n = 0; g->name_bytes = 0; g->n_bad = 0; g->max_len = 0;
 	for (;;) {
-		if (!g->is_last && pos >= g->limit) break;
-		int rc = scan_record(g->t, pos, g->end, g->is_last ? g->eof : 0, 0, 0, &r);
-		if (rc == 0 && g->is_last) { pos = r.next; break; }                       /* the rest continues in the next buffer */
-		if (rc == -1 && g->is_last) { pos = g->end; break; }
-		if (rc != 1 || !r.plain || r.next_last != 0 || r.seq_len > 0xffffffffUL) { g->ok = 0; break; }
-		if (g->n == g->cap) {
-			size_t m = g->cap ? g->cap * 2 : 4096;
-			g->name_off = realloc(g->name_off, m * 8); g->name_end = realloc(g->name_end, m * 8); g->seq_off = realloc(g->seq_off, m * 8);
-			g->qual_off = realloc(g->qual_off, m * 8); g->seq_len = realloc(g->seq_len, m * 4); g->has_qual = realloc(g->has_qual, m);
-			if (!g->name_off || !g->name_end || !g->seq_off || !g->qual_off || !g->seq_len || !g->has_qual) { g->ok = 0; break; }
-			g->cap = m;
+		if (pos >= g->limit && last == 0) break;           /* (with a header character already consumed the record is read here) */
+		const char *base = g->t;
+		int rc = scan_record(g->t, pos, g->end, g->eof, last, 0, &r);
+		if (g->sequential) {
+			if (rc == -2) { g->n_bad++; pos = r.next; last = r.next_last; continue; }   /* read_reads (src/cly_mt.c:42-56) drops such a record and goes on behind it */
+			if (rc != 1) { if (rc == -1) { pos = g->end; last = 0; } else pos = r.next; break; }   /* -1: nothing but junk is left; 0: more text needed (r.next skips junk, if any) */
+			if (r.seq_len > 0xffffffffUL) die("[classify] a read longer than 4 Gbp");
+			if (!r.plain) {
+				/* sequence or quality in several lines: the text is not written to (it is the mapped file); the record is
+				 * copied and its pieces are joined in the copy */
+				const size_t len = r.next - pos; char *j = xmalloc(len + 1); rec_t r2;
+				memcpy(j, g->t + pos, len);
+				if (scan_record(j, 0, len, 1, last, 1, &r2) != 1 || r2.seq_len != r.seq_len) die("[classify] internal error: a copied record parses differently");
+				batch_own(g->b, j);
+				r2.next = r.next; r2.next_last = r.next_last; r = r2; base = j;
+			}
+		} else {
+			if (rc == 0 && g->limit == g->end) { pos = r.next; break; }               /* the rest continues in the next block */
+			if (rc == -1 && g->limit == g->end) { pos = g->end; break; }
+			if (rc != 1 || !r.plain || r.next_last != 0 || r.seq_len > 0xffffffffUL) { g->ok = 0; break; }
 		}
-		g->name_off[g->n] = r.name_off; g->name_end[g->n] = r.name_end; g->seq_off[g->n] = r.seq_off; g->qual_off[g->n] = r.qual_off;
-		g->seq_len[g->n] = (uint32_t)r.seq_len; g->has_qual[g->n] = (unsigned char)r.has_qual; g->n++;
-		pos = r.next;
+		seg_push(g, base, &r);
+		pos = r.next; last = r.next_last;
 	}
-	g->end_pos = pos;
+	g->end_pos = pos; g->last_out = last;
 	return NULL;
 }
-/* returns 1 and fills the batch (records of text[0, *pos_out)) if the parallel parse is valid, 0 otherwise (nothing changed) */
-static int parse_parallel(batch_t *b, size_t end, int eof, uint32_t *hist, size_t *pos_out)
+static void *emit_main(void *arg)
 {
-	static long pmin = -1; static seg_t seg[N_PARSE];
-	if (pmin < 0) { const char *e = getenv("DSB_CLI_PPARSE_MIN"); pmin = e ? atol(e) : (32L << 20); }
-	if (end < (size_t)pmin) return 0;
-	size_t start[N_PARSE + 1]; int np = 1; start[0] = 0;
-	for (int k = 1; k < N_PARSE; k++) {
-		size_t from = end / N_PARSE * (size_t)k; if (from <= start[np - 1]) continue;
-		size_t g = guess_record_start(b->text, from, end);
-		if (g == (size_t)-1) break;
-		if (g > start[np - 1]) start[np++] = g;
+	seg_t *g = arg; char *nm = g->names;
+	for (size_t i = 0; i < g->n; i++) {
+		const size_t nl = g->name_len[i];
+		memcpy(nm, g->name[i], nl); nm[nl] = 0;
+		dsb_read *o = &g->out[i];
+		o->name = nm; o->seq = g->seq[i]; o->qual = g->qual[i]; o->len = g->seq_len[i];
+		nm += nl + 1;
 	}
-	if (np < 2) return 0;
-	start[np] = end;
-	pthread_t th[N_PARSE];
-	for (int k = 0; k < np; k++) {
-		seg[k].t = b->text; seg[k].start = start[k]; seg[k].limit = start[k + 1]; seg[k].end = end; seg[k].eof = eof; seg[k].is_last = k == np - 1;
-		pthread_create(&th[k], NULL, parse_main, &seg[k]);
-	}
-	int ok = 1;
-	for (int k = 0; k < np; k++) { pthread_join(th[k], NULL); if (!seg[k].ok) ok = 0; }
-	/* each piece must end where the sequential parse would start the next record: only separators up to the guessed '@' */
-	for (int k = 0; ok && k + 1 < np; k++) {
-		if (seg[k].end_pos > start[k + 1]) { ok = 0; break; }
-		for (size_t p = seg[k].end_pos; p < start[k + 1]; p++) if (b->text[p] == '>' || b->text[p] == '@') { ok = 0; break; }
-	}
-	if (!ok) return 0;
-	size_t total = 0; for (int k = 0; k < np; k++) total += seg[k].n;
-	batch_reserve(b, total + 1);
-	size_t n = 0; uint32_t h = *hist;
-	for (int k = 0; k < np; k++)
-		for (size_t i = 0; i < seg[k].n; i++, n++) {
-			b->name_off[n] = seg[k].name_off[i]; b->seq_off[n] = seg[k].seq_off[i]; b->seq_len[n] = seg[k].seq_len[i];
-			b->qual_off[n] = seg[k].qual_off[i]; b->has_qual[n] = seg[k].has_qual[i];
-			b->text[seg[k].name_end[i]] = 0;
-			if (seg[k].seq_len[i] > h) h = seg[k].seq_len[i];
+	return NULL;
+}
+static seg_t g_seg[MAX_THREADS];
+/* Parses t[pos, ...) up to the first record boundary at or behind `soft_end` (text is valid up to `end`; eof: nothing follows
+ * it) and appends the records to the batch.  *last is kseq's look-ahead character.  Returns where the next wave starts. */
+static size_t parse_wave(app_t *a, batch_t *b, char *t, size_t pos, size_t soft_end, size_t end, int eof, int *last, uint32_t *hist)
+{
+	const double t0 = now();
+	seg_t *seg = g_seg; int np = 0, parallel = 0;
+	if (soft_end > end) soft_end = end;
+	if (*last == 0 && a->n_parse > 1 && soft_end - pos >= 2 * a->seg_min) {
+		size_t want = (soft_end - pos) / a->seg_min; if (want > (size_t)a->n_parse) want = (size_t)a->n_parse;
+		size_t start[MAX_THREADS + 1]; start[0] = pos; np = 1;
+		for (size_t k = 1; k < want; k++) {
+			size_t from = pos + (soft_end - pos) / want * k; if (from <= start[np - 1]) continue;
+			size_t g = guess_record_start(t, from, end);
+			if (g == (size_t)-1 || g >= soft_end) break;
+			if (g > start[np - 1]) start[np++] = g;
 		}
-	b->n = n; *hist = h; *pos_out = seg[np - 1].end_pos;
-	if (getenv("DSB_CLI_TRACE")) fprintf(stderr, "[reader] buffer of %zu bytes parsed in %d pieces, %zu records\n", end, np, n);
-	return 1;
+		size_t stop = soft_end >= end ? end : guess_record_start(t, soft_end, end);
+		if (stop != (size_t)-1 && np >= 2) {
+			start[np] = stop;
+			pthread_t th[MAX_THREADS];
+			for (int k = 0; k < np; k++) {
+				seg[k].t = t; seg[k].start = start[k]; seg[k].limit = start[k + 1]; seg[k].end = end; seg[k].eof = eof; seg[k].last_in = 0; seg[k].sequential = 0;
+				if (k) pthread_create(&th[k], NULL, parse_main, &seg[k]);
+			}
+			parse_main(&seg[0]);
+			parallel = 1;
+			for (int k = 1; k < np; k++) pthread_join(th[k], NULL);
+			for (int k = 0; k < np; k++) if (!seg[k].ok) parallel = 0;
+			/* each piece must end where the sequential parse would start the next record: only separators up to the guessed '@' */
+			for (int k = 0; parallel && k < np; k++) {
+				if (start[k + 1] == end && k == np - 1) break;           /* the last piece of the text ends where it ends */
+				if (seg[k].end_pos > start[k + 1]) { parallel = 0; break; }
+				for (size_t p = seg[k].end_pos; p < start[k + 1]; p++) if (t[p] == '>' || t[p] == '@') { parallel = 0; break; }
+				if (parallel && k == np - 1) seg[k].end_pos = start[k + 1];
+			}
+		}
+	}
+	if (!parallel) {
+		np = 1;
+		seg[0].t = t; seg[0].start = pos; seg[0].limit = soft_end; seg[0].end = end; seg[0].eof = eof; seg[0].last_in = *last; seg[0].sequential = 1; seg[0].b = b;
+		parse_main(&seg[0]);
+	}
+	/* second pass: names into one block of the batch, records into its dsb_read array; every piece writes its own part */
+	size_t n = 0, nb = 0; uint32_t h = *hist;
+	for (int k = 0; k < np; k++) { n += seg[k].n; nb += seg[k].name_bytes; a->n_badqual += seg[k].n_bad; if (seg[k].max_len > h) h = seg[k].max_len; }
+	if (n) {
+		batch_reserve(b, b->n + n);
+		char *names = xmalloc(nb); batch_own(b, names);
+		size_t o = b->n, no = 0; pthread_t th[MAX_THREADS]; int started[MAX_THREADS];
+		for (int k = 0; k < np; k++) {
+			seg[k].out = b->reads + o; seg[k].names = names + no; o += seg[k].n; no += seg[k].name_bytes;
+			started[k] = k && seg[k].n >= 4096 && pthread_create(&th[k], NULL, emit_main, &seg[k]) == 0;
+			if (!started[k]) emit_main(&seg[k]);
+		}
+		for (int k = 0; k < np; k++) if (started[k]) pthread_join(th[k], NULL);
+		b->n += n;
+	}
+	*hist = h; *last = seg[np - 1].last_out;
+	const size_t next = seg[np - 1].end_pos;
+	b->bytes += next - pos;
+	a->tr.parse_s += now() - t0; a->tr.bytes += next - pos; a->tr.waves++; a->tr.waves_parallel += (size_t)parallel;
+	return next;
 }
 
-typedef struct { app_t *a; batch_t *b; int n; } prefill_t;
-static void *prefill_main(void *arg)
+static int batch_full(const app_t *a, const batch_t *b)
 {
-	prefill_t *p = arg;
-	for (int i = 0; i < p->n; i++) {
-		p->b[i].text = dsb_host_alloc(p->a->batch_cap + 64);
-		if (!p->b[i].text) break;                      /* the reader tries again (and reports) when it needs the buffer */
-		p->b[i].cap = p->a->batch_cap;
-	}
-	return NULL;
+	return (b->n >= a->batch_reads && b->bytes >= a->batch_bytes) || b->bytes >= a->batch_max_bytes || b->n >= a->batch_max_reads;
 }
+
+/* ---------------------------------------------------------------- the reader */
+typedef struct { app_t *a; long seqno; uint32_t hist; batch_t *b; } rd_t;
+static void rd_open_batch(rd_t *r)
+{
+	if (r->b) return;
+	const double t0 = now();
+	r->b = q_pop(&r->a->free_q);
+	r->a->tr.wait_free_s += now() - t0;
+	r->b->n = 0; r->b->bytes = 0; r->b->hist_before = r->hist; r->b->seqno = r->seqno++;
+}
+static void rd_close_batch(rd_t *r)
+{
+	if (!r->b) return;
+	q_push(&r->a->parsed_q, r->b);                         /* empty batches keep the sequence numbers dense */
+	r->b = NULL;
+}
+
+static void read_plain(rd_t *r, int fd, size_t size)
+{
+	app_t *a = r->a;
+	if (!size) return;
+	/* shared and read-only: the page cache itself (a private writable mapping of a tmpfs file reads several times slower) */
+	char *t = mmap(NULL, size, PROT_READ, MAP_SHARED, fd, 0);
+	if (t == MAP_FAILED) die("[classify] cannot map the input file");
+	size_t pos = 0; int last = 0;
+	while (pos < size || last) {
+		rd_open_batch(r);
+		uint32_t hist = r->hist;
+		const size_t before = pos;
+		pos = parse_wave(a, r->b, t, pos, pos + a->wave_bytes, size, 1, &last, &hist);
+		r->hist = hist;
+		if (pos == before && !last) pos = size;               /* (cannot happen with eof set; never loop) */
+		if (batch_full(a, r->b)) rd_close_batch(r);
+	}
+	/* the mapping stays until the process ends: batches in flight point into it */
+}
+
+static void read_gz(rd_t *r, inflater_t *f)
+{
+	app_t *a = r->a;
+	char *carry = NULL; size_t carry_len = 0; int last = 0;
+	for (;;) {
+		const double t0 = now();
+		gzbuf_t *g = inflater_next(f);
+		a->tr.wait_text_s += now() - t0;
+		if (!g) break;
+		rd_open_batch(r);
+		batch_t *b = r->b;
+		batch_hold(b, g);
+		size_t pos = 0;
+		if (carry_len) {
+			/* the record that began in the previous block: joined with as much of this block as it needs, in a block of its own */
+			size_t x = carry_len + (64u << 10) < g->len ? carry_len + (64u << 10) : g->len; rec_t rec; int rc;
+			for (;;) {
+				char *j = xmalloc(carry_len + x + 1);
+				memcpy(j, carry, carry_len); memcpy(j + carry_len, g->p, x);
+				const int whole = x == g->len;
+				rc = scan_record(j, 0, carry_len + x, whole && g->eof, last, 0, &rec);
+				if (rc == 1 && !rec.plain) rc = scan_record(j, 0, carry_len + x, whole && g->eof, last, 1, &rec);   /* complete: join its pieces in place */
+				if (rc == 0 && !whole) { free(j); x = 2 * x < g->len ? 2 * x : g->len; continue; }
+				if (rc == 0) {                                /* longer than this whole block: carry on */
+					free(carry); carry = j; carry_len += x; pos = g->len; break;
+				}
+				if (rc == 1) {
+					if (rec.seq_len > 0xffffffffUL) die("[classify] a read longer than 4 Gbp");
+					batch_own(b, j); batch_reserve(b, b->n + 1);
+					j[rec.name_end] = 0;
+					dsb_read *o = &b->reads[b->n++]; o->name = j + rec.name_off; o->seq = j + rec.seq_off; o->qual = rec.has_qual ? j + rec.qual_off : NULL; o->len = (uint32_t)rec.seq_len;
+					if (rec.seq_len > r->hist) r->hist = (uint32_t)rec.seq_len;
+				} else free(j);
+				if (rc == -2) a->n_badqual++;
+				if (rc == -1) { pos = g->len; last = 0; }
+				else { pos = rec.next > carry_len ? rec.next - carry_len : 0; last = rec.next_last; }
+				carry_len = 0; break;
+			}
+		}
+		if (!carry_len || pos < g->len) {
+			while (pos < g->len || (last && g->eof)) {
+				uint32_t hist = r->hist; const size_t before = pos; const int last_before = last;
+				pos = parse_wave(a, b, g->p, pos, g->len, g->len, g->eof, &last, &hist);
+				r->hist = hist;
+				if (pos == before && last == last_before) break;      /* an incomplete record: it continues in the next block */
+			}
+			if (pos < g->len) {
+				carry_len = g->len - pos;
+				carry = xrealloc(carry, carry_len);
+				memcpy(carry, g->p + pos, carry_len);
+			}
+		}
+		if (batch_full(a, b)) rd_close_batch(r);
+		if (g->eof) break;
+	}
+	free(carry);
+}
+
+static int is_gzip(int fd) { unsigned char m[2] = {0, 0}; return pread(fd, m, 2, 0) == 2 && m[0] == 0x1f && m[1] == 0x8b; }
 
 static void *reader_main(void *arg)
 {
-	app_t *a = arg; long seqno = 0;
-	char *carry = NULL; size_t carry_cap = 0;
+	app_t *a = arg;
 	/* max_read_l (src/cly.c:2958) lives in the per-thread buffers that classify_main allocates once, before the loop
 	 * over the input files (src/cly_mt.c:538-556), and is never reset: the prefix maximum runs over ALL files */
-	uint32_t hist = 0;
-	for (int fi = a->first_file; fi < a->argc; fi++) {
-		src_t src;
-		if (src_open(&src, a->argv[fi]) != 0) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", a->argv[fi]); exit(1); }
-		fprintf(stderr, "Processing file: [%s].\n", a->argv[fi]);
-		int last = 0, eof = 0; size_t carry_len = 0;
-		while (!eof || carry_len) {
-			batch_t *b = q_pop(&a->free_q);
-			if (!b->text) { b->text = a->pageable ? malloc(a->batch_cap + 64) : dsb_host_alloc(a->batch_cap + 64); b->cap = a->batch_cap; if (!b->text) die("[classify] cannot allocate a pinned batch buffer"); }
-			if (carry_len > b->cap) die("[classify] one record is larger than the batch buffer (raise DSB_CLI_BATCH_MB)");
-			memcpy(b->text, carry, carry_len);
-			double t_r0 = now();
-			size_t got = eof ? 0 : src_read(&src, b->text + carry_len, b->cap - carry_len);
-			double t_r1 = now();
-			size_t end = carry_len + got;
-			if (!eof && end < b->cap) eof = 1;
-			b->n = 0; b->hist_before = hist; b->seqno = seqno++;
-			size_t pos = 0; rec_t r;
-			if (last == 0 && parse_parallel(b, end, eof, &hist, &pos)) goto parsed;
-			for (;;) {
-				int rc = scan_record(b->text, pos, end, eof, last, 0, &r);
-				if (rc == 1 && !r.plain) rc = scan_record(b->text, pos, end, eof, last, 1, &r);
-				if (rc == -2) { a->n_badqual++; pos = r.next; last = r.next_last; continue; }   /* read_reads (src/cly_mt.c:42-56) drops such a record and goes on behind it */
-				if (rc != 1) { pos = rc == -1 ? end : r.next; break; }       /* -1: nothing but junk is left; 0: r.next skips junk, if any */
-				if (r.seq_len > 0xffffffffUL) die("[classify] a read longer than 4 Gbp");
-				batch_reserve(b, b->n + 1);
-				b->name_off[b->n] = r.name_off; b->seq_off[b->n] = r.seq_off; b->seq_len[b->n] = (uint32_t)r.seq_len;
-				b->qual_off[b->n] = r.qual_off; b->has_qual[b->n] = (unsigned char)r.has_qual;
-				b->text[r.name_end] = 0;                                   /* the name becomes a C string in place */
-				if (r.seq_len > hist) hist = (uint32_t)r.seq_len;
-				b->n++; pos = r.next; last = r.next_last;
-				if (b->n >= MAX_BATCH_READS) break;
-			}
-		parsed:
-			if (getenv("DSB_CLI_TRACE")) fprintf(stderr, "[reader] batch %ld: %zu bytes, fill %.3f s, parse %.3f s, %zu reads\n", b->seqno, end, t_r1 - t_r0, now() - t_r1, b->n);
-			/* what is left is the beginning of a record that continues in the next buffer */
-			carry_len = end - pos;
-			if (eof && b->n == 0) carry_len = 0;                           /* trailing junk without a record */
-			if (carry_len) {
-				if (carry_len >= b->cap && b->n == 0) die("[classify] one record is larger than the batch buffer (raise DSB_CLI_BATCH_MB)");
-				if (carry_len > carry_cap) { carry_cap = carry_len * 2; carry = realloc(carry, carry_cap); if (!carry) die("[classify] out of memory"); }
-				memcpy(carry, b->text + pos, carry_len);
-			}
-			b->len = pos;
-			q_push(&a->parsed_q, b);                                       /* empty batches keep the sequence numbers dense */
+	rd_t r = { a, 0, 0, NULL };
+	const int nf = a->argc - a->first_file;
+	inflater_t *inf = calloc((size_t)(nf > 0 ? nf : 1), sizeof *inf);
+	int *fds = xmalloc((size_t)(nf > 0 ? nf : 1) * sizeof *fds); size_t *sizes = xmalloc((size_t)(nf > 0 ? nf : 1) * sizeof *sizes);
+	int ahead = a->n_inflate > 1 ? (a->n_inflate < 4 ? a->n_inflate : 4) : 1;   /* inflaters running before their file's turn */
+	for (int i = 0; i < nf; i++) {
+		const char *path = a->argv[a->first_file + i];
+		fds[i] = open(path, O_RDONLY); struct stat st;
+		if (fds[i] < 0 || fstat(fds[i], &st) != 0) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", path); exit(1); }
+		sizes[i] = (size_t)st.st_size;
+		inf[i].a = a; inf[i].path = path; inf[i].fd = fds[i];
+		pthread_mutex_init(&inf[i].mu, NULL); pthread_cond_init(&inf[i].cv, NULL);
+		if (!S_ISREG(st.st_mode)) inf[i].stream = 1;
+		else if (is_gzip(fds[i])) {
+			inf[i].zlen = sizes[i];
+			inf[i].z = mmap(NULL, sizes[i], PROT_READ, MAP_SHARED, fds[i], 0);
+			if (inf[i].z == MAP_FAILED) die("[classify] cannot map the input file");
 		}
-		src_close(&src);
 	}
-	free(carry);
+	libdeflate_find();
+	for (int i = 0; i < nf; i++) {
+		for (int j = i; j < nf && j < i + ahead; j++)
+			if ((inf[j].z || inf[j].stream) && !inf[j].started) { inf[j].started = 1; pthread_create(&inf[j].th, NULL, inflater_main, &inf[j]); }
+		fprintf(stderr, "Processing file: [%s].\n", a->argv[a->first_file + i]);
+		if (inf[i].started) { read_gz(&r, &inf[i]); pthread_join(inf[i].th, NULL); if (inf[i].z) munmap((void *)inf[i].z, inf[i].zlen); }
+		else read_plain(&r, fds[i], sizes[i]);
+		if (!inf[i].stream) close(fds[i]);                    /* (gzclose closed a stream's descriptor) */
+		/* the reference classifies what it has read when a file ends (its pipeline runs per file, src/cly_mt.c:551-558): a
+		 * batch may go on into the next file here -- same records, same order, same history */
+	}
+	rd_close_batch(&r);
+	free(inf); free(fds); free(sizes);
 	q_close(&a->parsed_q);
 	return NULL;
 }
@@ -321,26 +608,30 @@ typedef struct { app_t *a; int k; } gpu_arg_t;
 static void *gpu_main(void *arg)
 {
 	gpu_arg_t *g = arg; app_t *a = g->a; dsb_ctx *ctx = a->ctx[g->k];
-	batch_t *b;
+	batch_t *b; double t_idle = now();
 	while ((b = q_pop(&a->parsed_q)) != NULL) {
 		b->n_hits = 0;
 		if (b->n) {
 			dsb_result res; int rc;
-			double t0 = now(), t1, t2;
+			double t0 = now(), t1, t2, t3;
 			dsb_ctx_set_history(ctx, b->hist_before);
-			rc = dsb_batch_upload_text(ctx, b->text, b->len, b->seq_off, b->seq_len, b->n);
+			rc = dsb_batch_upload(ctx, b->reads, b->n);
 			t1 = now();
 			if (!rc) rc = dsb_batch_run(ctx);
 			t2 = now();
 			if (!rc || rc == DSB_ECAP) rc = dsb_batch_fetch(ctx, &res);
-			if (getenv("DSB_CLI_TRACE")) fprintf(stderr, "[gpu %d] batch %ld: upload %.3f s, run %.3f s, fetch %.3f s\n", g->k, b->seqno, t1 - t0, t2 - t1, now() - t2);
+			t3 = now();
+			if (a->trace) {
+				fprintf(stderr, "[gpu %d] batch %ld: %zu reads, upload %.3f s, run %.3f s, fetch %.3f s\n", g->k, b->seqno, b->n, t1 - t0, t2 - t1, t3 - t2);
+				a->tr.up_s[g->k] += t1 - t0; a->tr.run_s[g->k] += t2 - t1; a->tr.fetch_s[g->k] += t3 - t2; a->tr.idle_s[g->k] += t0 - t_idle; a->tr.batches[g->k]++;
+			}
 			if (rc && rc != DSB_ECAP) { fprintf(stderr, "[dsb_classify_batch] %s\n", dsb_strerror(rc)); exit(1); }
-			if (b->n > b->cap_rr) { b->cap_rr = b->n * 2; b->rr = realloc(b->rr, b->cap_rr * sizeof *b->rr); }
-			if (res.n_hits > b->cap_hits) { b->cap_hits = res.n_hits * 2; b->hits = realloc(b->hits, b->cap_hits * sizeof *b->hits); }
-			if (!b->rr || (res.n_hits && !b->hits)) die("[classify] out of memory");
+			if (b->n > b->cap_rr) { b->cap_rr = b->n * 2; b->rr = xrealloc(b->rr, b->cap_rr * sizeof *b->rr); }
+			if (res.n_hits > b->cap_hits) { b->cap_hits = res.n_hits * 2; b->hits = xrealloc(b->hits, b->cap_hits * sizeof *b->hits); }
 			memcpy(b->rr, res.reads, b->n * sizeof *b->rr);
 			if (res.n_hits) memcpy(b->hits, res.hits, res.n_hits * sizeof *b->hits);
 			b->n_hits = res.n_hits;
+			t_idle = now();
 		}
 		q_push(&a->done_q, b);
 	}
@@ -348,47 +639,60 @@ static void *gpu_main(void *arg)
 }
 
 /* SAM text of the reads [lo, hi) of a batch into one growing buffer (one formatter thread per slice) */
-#define N_FORMAT 8
-typedef struct { app_t *a; batch_t *b; size_t lo, hi; char *buf; size_t len, cap; } fmt_job_t;
+typedef struct { app_t *a; batch_t *b; size_t lo, hi; char *buf; size_t len, cap; unsigned long n_status; } fmt_job_t;
 static void *format_main(void *arg)
 {
 	fmt_job_t *j = arg; app_t *a = j->a; batch_t *b = j->b;
-	j->len = 0;
+	j->len = 0; j->n_status = 0;
 	for (size_t i = j->lo; i < j->hi; i++) {
 		const dsb_read_result *rr = &b->rr[i];
-		dsb_read rd; rd.name = b->text + b->name_off[i]; rd.seq = b->text + b->seq_off[i]; rd.len = b->seq_len[i];
-		rd.qual = b->has_qual[i] ? b->text + b->qual_off[i] : NULL;
-		if (rr->status) { fprintf(stderr, "[classify] read %s: device arena overflow (status %d)\n", rd.name, rr->status); exit(1); }
-		size_t need = 4096 + 800 * (size_t)rr->n + (a->full == 1 ? 2 * (size_t)rd.len : 0) + strlen(rd.name);
-		if (j->len + need > j->cap) { j->cap = (j->len + need) * 2; j->buf = realloc(j->buf, j->cap); if (!j->buf) die("[classify] out of memory"); }
-		long w = a->full >= 2 ? dsb_format_des(a->idx, &rd, rr, b->hits + rr->first, a->o.max_sec_N, a->full == 3, j->buf + j->len, j->cap - j->len)
-		                      : dsb_format_sam(a->idx, &rd, b->hits + rr->first, rr->n, a->o.max_sec_N, a->full, j->buf + j->len, j->cap - j->len);
+		const dsb_read *rd = &b->reads[i];
+		/* a read that outgrew a device capacity even in the second run: its records are written as far as they go, the
+		 * run goes on and ends with exit code 1 (the reference's vectors are unbounded; nothing is dropped silently) */
+		if (rr->status) { fprintf(stderr, "[classify] read %s: device arena overflow (status %d)\n", rd->name, rr->status); j->n_status++; }
+		size_t need = 4096 + 800 * (size_t)rr->n + (a->full == 1 ? 2 * (size_t)rd->len : 0) + strlen(rd->name);
+		if (j->len + need > j->cap) { j->cap = (j->len + need) * 2; j->buf = xrealloc(j->buf, j->cap); }
+		long w = a->full >= 2 ? dsb_format_des(a->idx, rd, rr, b->hits + rr->first, a->o.max_sec_N, a->full == 3, j->buf + j->len, j->cap - j->len)
+		                      : dsb_format_sam(a->idx, rd, b->hits + rr->first, rr->n, a->o.max_sec_N, a->full, j->buf + j->len, j->cap - j->len);
 		if (w < 0) die("[dsb_format_sam] buffer too small");
 		j->len += (size_t)w;
 	}
 	return NULL;
 }
 
+static void batch_release(app_t *a, batch_t *b)
+{
+	for (int i = 0; i < b->n_own; i++) free(b->own[i]);
+	b->n_own = 0;
+	for (int i = 0; i < b->n_gzb; i++) gzbuf_put(a, b->gzb[i]);
+	b->n_gzb = 0;
+}
+
 static void *writer_main(void *arg)
 {
 	app_t *a = arg; long next = 0; batch_t *held[N_BATCH + 2]; int n_held = 0;
-	static fmt_job_t job[N_FORMAT];
+	static fmt_job_t job[MAX_THREADS];
 	batch_t *b;
 	for (;;) {
 		b = NULL;
 		for (int i = 0; i < n_held; i++) if (held[i]->seqno == next) { b = held[i]; held[i] = held[--n_held]; break; }
 		if (!b) { b = q_pop(&a->done_q); if (!b) break; if (b->seqno != next) { held[n_held++] = b; continue; } }
-		int nt = b->n >= 4096 ? N_FORMAT : 1; pthread_t th[N_FORMAT]; size_t part = (b->n + (size_t)nt - 1) / (size_t)nt;
+		const double t0 = now();
+		int nt = b->n >= 4096 ? a->n_format : 1; pthread_t th[MAX_THREADS]; size_t part = (b->n + (size_t)nt - 1) / (size_t)nt;
 		for (int t = 0; t < nt; t++) {
 			job[t].a = a; job[t].b = b; job[t].lo = (size_t)t * part < b->n ? (size_t)t * part : b->n; job[t].hi = job[t].lo + part < b->n ? job[t].lo + part : b->n;
-			if (nt > 1) pthread_create(&th[t], NULL, format_main, &job[t]); else format_main(&job[t]);
+			if (t) pthread_create(&th[t], NULL, format_main, &job[t]);
 		}
-		for (int t = 0; t < nt; t++) { if (nt > 1) pthread_join(th[t], NULL); fwrite(job[t].buf, 1, job[t].len, a->out); }
+		format_main(&job[0]);
+		const double t1 = now();
+		for (int t = 0; t < nt; t++) { if (t) pthread_join(th[t], NULL); fwrite(job[t].buf, 1, job[t].len, a->out); a->tr.out_bytes += job[t].len; a->n_status += job[t].n_status; }
+		a->tr.fmt_s += t1 - t0; a->tr.write_s += now() - t1;
 		a->total += b->n;
 		next++;
+		batch_release(a, b);
 		q_push(&a->free_q, b);
 	}
-	for (int t = 0; t < N_FORMAT; t++) free(job[t].buf);
+	for (int t = 0; t < MAX_THREADS; t++) free(job[t].buf);
 	return NULL;
 }
 
@@ -410,6 +714,39 @@ static void usage(void)
 
 static double now(void) { struct timeval tv; gettimeofday(&tv, NULL); return tv.tv_sec + tv.tv_usec * 1e-6; }
 static double cputime(void) { struct rusage r; getrusage(RUSAGE_SELF, &r); return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec); }
+static size_t env_size(const char *name, size_t dflt, int shift) { const char *e = getenv(name); return e && atol(e) > 0 ? (size_t)atol(e) << shift : dflt; }
+
+/* sizes and thread counts of the host pipeline (also used by the parser test harness) */
+static void app_defaults(app_t *a)
+{
+	const int cpus = dsb_host_cpus();
+	a->n_parse = cpus > MAX_THREADS ? MAX_THREADS : cpus; a->n_format = cpus > 16 ? 16 : cpus; a->n_inflate = cpus > 32 ? 32 : cpus;
+	if (getenv("DSB_CLI_THREADS")) { int t = atoi(getenv("DSB_CLI_THREADS")); if (t < 1) t = 1; if (t > MAX_THREADS) t = MAX_THREADS; a->n_parse = a->n_format = a->n_inflate = t; }
+	/* A batch closes when it holds >= 65536 reads and >= 1 GiB of text (short reads: millions per batch), or 8 GiB of
+	 * text, or 4 M reads: the device wants >= 64 k long reads per call (a call lasts as long as its heaviest read).
+	 * DSB_CLI_BATCH_MB caps the text of a batch; DSB_CLI_BATCH_KB (tests) makes every wave of that size a batch. */
+	a->wave_bytes = env_size("DSB_CLI_WAVE_MB", (size_t)256 << 20, 20);
+	a->batch_reads = env_size("DSB_CLI_BATCH_READS", 65536, 0); a->batch_bytes = (size_t)1 << 30;
+	a->batch_max_bytes = env_size("DSB_CLI_BATCH_MB", (size_t)8 << 30, 20); a->batch_max_reads = env_size("DSB_CLI_BATCH_MAX_READS", (size_t)4 << 20, 0);
+	if (a->batch_bytes > a->batch_max_bytes) a->batch_bytes = a->batch_max_bytes;
+	if (getenv("DSB_CLI_BATCH_KB")) { a->wave_bytes = env_size("DSB_CLI_BATCH_KB", 0, 10); a->batch_reads = 1; a->batch_bytes = 1; }
+	if (a->wave_bytes < 64) a->wave_bytes = 64;
+	a->seg_min = env_size("DSB_CLI_SEG_KB", (size_t)2 << 20, 10);
+	a->trace = getenv("DSB_CLI_TRACE") != NULL;
+	pthread_mutex_init(&a->tr_mu, NULL); pthread_mutex_init(&a->gz_mu, NULL);
+}
+
+static void trace_summary(const app_t *a, double sec)
+{
+	const trace_t *t = &a->tr;
+	fprintf(stderr, "[trace] reader: %.2f GB of text in %zu waves (%zu parsed in parallel on %d threads), parsing %.3f s = %.1f GB/s while it runs; waited %.3f s for a free batch, %.3f s for inflated text\n",
+	        t->bytes / 1e9, t->waves, t->waves_parallel, a->n_parse, t->parse_s, t->parse_s > 0 ? t->bytes / 1e9 / t->parse_s : 0.0, t->wait_free_s, t->wait_text_s);
+	if (t->inflate_out) fprintf(stderr, "[trace] inflate: %.2f GB of text, %.3f s of inflater time (%d threads per BGZF file, %s)\n", t->inflate_out / 1e9, t->inflate_s, a->n_inflate, ld_alloc ? "libdeflate" : "zlib");
+	fprintf(stderr, "[trace] writer: %.3f GB written, formatting %.3f s = %.2f GB/s while it runs (%d threads), fwrite %.3f s\n", t->out_bytes / 1e9, t->fmt_s, t->fmt_s > 0 ? t->out_bytes / 1e9 / t->fmt_s : 0.0, a->n_format, t->write_s);
+	for (int k = 0; k < a->n_ctx; k++)
+		fprintf(stderr, "[trace] worker %d: %ld batches, upload %.3f s, kernels (incl. waiting for the device's turn) %.3f s, fetch %.3f s, idle %.3f s of %.3f s: busy %.0f %%\n", k, t->batches[k], t->up_s[k],
+		        t->run_s[k], t->fetch_s[k], t->idle_s[k], sec, 100.0 * (t->up_s[k] + t->run_s[k] + t->fetch_s[k]) / (sec > 0 ? sec : 1));
+}
 
 static int classify_main(int argc, char **argv)
 {
@@ -445,29 +782,18 @@ static int classify_main(int argc, char **argv)
 	if (optind + 2 > argc) { usage(); return 0; }
 	const char *index_dir = argv[optind++];
 	a.argc = argc; a.argv = argv; a.first_file = optind;
-	/* batch buffer: DSB_CLI_BATCH_MB of raw text (default 1536), but not more than the input needs */
-	size_t want = 0;
 	for (int i = optind; i < argc; i++) {
-		struct stat st; unsigned char m[2] = {0, 0}; int fd = open(argv[i], O_RDONLY);
+		int fd = open(argv[i], O_RDONLY);
 		if (fd < 0) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", argv[i]); exit(1); }
-		int gz = pread(fd, m, 2, 0) == 2 && m[0] == 0x1f && m[1] == 0x8b;
-		if (fstat(fd, &st) == 0 && (size_t)st.st_size * (gz ? 8 : 1) > want) want = (size_t)st.st_size * (gz ? 8 : 1);
 		close(fd);
 	}
-	const char *mb = getenv("DSB_CLI_BATCH_MB"), *kb = getenv("DSB_CLI_BATCH_KB");     /* KB: tests */
-	a.batch_cap = kb ? (size_t)atol(kb) << 10 : (size_t)(mb ? atol(mb) : 1536) << 20;
-	if (want + (1 << 20) < a.batch_cap) a.batch_cap = want + (1 << 20);
-	if (a.batch_cap < (1 << 16)) a.batch_cap = 1 << 16;
+	app_defaults(&a);
 	setvbuf(a.out, NULL, _IOFBF, 8 << 20);
 
 	/* CTX_PER_DEV contexts per listed device; the contexts of one device share its staged index */
 	int ids[MAX_CTX]; a.n_ctx = 0;
 	for (int k = 0; k < CTX_PER_DEV; k++) for (int d = 0; d < n_dev; d++) ids[a.n_ctx++] = dev[d];
-	/* the pinned text buffers of the batches are made while the index loads (pinning 1.5 GB takes a few tenths of a
-	 * second, and HIP calls of the GPU threads would wait behind it) */
 	static batch_t batches[N_BATCH];
-	prefill_t pf = { &a, batches, a.n_ctx + 2 };
-	pthread_t th_pf; int have_pf = !a.pageable && pthread_create(&th_pf, NULL, prefill_main, &pf) == 0;
 	fprintf(stderr, "loading index\t");
 	int rc = dsb_index_open(index_dir, &a.idx);
 	if (rc) { fprintf(stderr, "\n[load_idx] %s\n", dsb_strerror(rc)); exit(1); }
@@ -477,7 +803,6 @@ static int classify_main(int argc, char **argv)
 	double t0 = now(), cpu0 = cputime();
 	fprintf(stderr, "Start classify\n");
 	q_init(&a.free_q); q_init(&a.parsed_q); q_init(&a.done_q);
-	if (have_pf) pthread_join(th_pf, NULL);
 	for (int i = 0; i < a.n_ctx + 2; i++) q_push(&a.free_q, &batches[i]);
 	pthread_t th_r, th_w, th_g[MAX_CTX]; gpu_arg_t ga[MAX_CTX];
 	pthread_create(&th_r, NULL, reader_main, &a);
@@ -492,8 +817,8 @@ static int classify_main(int argc, char **argv)
 	fprintf(stderr, "Classify CPU: %.3f sec\n", cputime() - cpu0);
 	if (a.n_badqual) fprintf(stderr, "[read_reads] %lu record(s) with a quality string of the wrong length were skipped\n", a.n_badqual);
 	if (a.n_status) fprintf(stderr, "[classify] %lu read(s) exceeded a device capacity even in the second run; their records may be incomplete\n", a.n_status);
+	if (a.trace) trace_summary(&a, sec);
 	if (a.out != stdout) fclose(a.out); else fflush(stdout);
-	for (int i = 0; i < N_BATCH; i++) { if (a.pageable) free(batches[i].text); else dsb_host_free(batches[i].text); }
 	dsb_multi_destroy(a.multi);
 	dsb_index_close(a.idx);
 	return a.n_status ? 1 : 0;

@@ -750,6 +750,9 @@ struct InSlot {
 	bool ragged = false;
 };
 
+// pinned staging of dsb_batch_upload: one per gather thread, two chunks each (one is filled while the other is on its way)
+struct UpStage { char *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool used[2] = {false, false}; hipStream_t st = nullptr; };
+
 struct dsb_ctx {
 	dsb_index *idx = nullptr; int device = 0; hipStream_t stream = nullptr;
 	DsbStaged *staged = nullptr; DsbDevIndex dx;
@@ -774,6 +777,7 @@ struct dsb_ctx {
 	hipStream_t stream3 = nullptr; hipEvent_t ev_heavy3 = nullptr;    // k_classify_heavy: several wavefronts on each of the very heaviest reads
 	hipStream_t stream2 = nullptr; hipEvent_t ev_order = nullptr, ev_heavy = nullptr, ev_hprobe = nullptr, ev_cls = nullptr;   // the heaviest reads run beside the seed probe
 	uint32_t *dbg_host = nullptr, *dbg_dev = nullptr;
+	std::vector<UpStage> up; size_t up_chunk = 0;     // pinned staging of dsb_batch_upload (upload_gather)
 	dsb_opts opts;
 	dsb_ctx() { memset(&dx, 0, sizeof dx); memset(&arena, 0, sizeof arena); memset(&arena_big, 0, sizeof arena_big); memset(&timing, 0, sizeof timing); memset(&opts, 0, sizeof opts); }
 };
@@ -796,6 +800,7 @@ extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 	hipFree(c->d_wd); hipFree(c->d_bin); hipFree(c->d_pk); hipFree(c->d_bits);
 	hipFree(c->d_rout); hipFree(c->d_hout); hipFree(c->d_counters); hipFree(c->arena.base); hipFree(c->arena_big.base); hipFree(c->d_score); hipFree(c->d_order); hipFree(c->d_heavy); hipFree(c->d_seeds); hipFree(c->d_sinfo); hipFree(c->syn0); hipFree(c->syn1);
 	if (c->dbg_host) hipHostFree(c->dbg_host);
+	for (UpStage &u : c->up) { if (u.st) { hipStreamSynchronize(u.st); hipStreamDestroy(u.st); } for (int k = 0; k < 2; k++) { if (u.ev[k]) hipEventDestroy(u.ev[k]); if (u.buf[k]) hipHostFree(u.buf[k]); } }
 	for (int i = 0; i < 4; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	if (c->ev_order) hipEventDestroy(c->ev_order);
 	if (c->ev_cls) hipEventDestroy(c->ev_cls);
@@ -1047,6 +1052,75 @@ static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_b
 }
 
 struct SeqView { const char *p; uint32_t len; };
+
+// Host threads worth starting: the CPUs this process may run on, capped by the CPU quota of its control group
+// (a container that sees 256 CPUs may be allowed the time of 16 of them: more runnable threads than that only take turns).
+extern "C" int dsb_host_cpus(void)
+{
+	static int cached = 0;
+	if (cached) return cached;
+	cpu_set_t set; int n = 1;
+	if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+	FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+	if (f) {
+		char q[64] = {0}; long period = 0;
+		if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) { long v = (atol(q) + period - 1) / period; if (v >= 1 && v < n) n = (int)v; }
+		fclose(f);
+	}
+	if (n < 1) n = 1;
+	return cached = n;
+}
+
+// The sequences of a batch lie wherever the caller keeps its reads (the kseq_t of the reference's batch, src/cly_mt.c:42-56;
+// the mapped input file of the CLI).  The device wants them back to back: destination chunk by destination chunk, a few
+// host threads copy the pieces of the reads that fall into a chunk into pinned memory and send the chunk on a stream of
+// their own -- the gather runs at memory speed on several cores and overlaps the transfers.
+#include <atomic>
+static int upload_gather(dsb_ctx *c, InSlot &s, const SeqView *reads, size_t n, uint64_t total)
+{
+	if (!total) return DSB_OK;
+	if (!c->up_chunk) { const char *e = getenv("DSB_UPLOAD_CHUNK_KB"); c->up_chunk = e && atol(e) > 0 ? (size_t)atol(e) << 10 : (size_t)8 << 20; }
+	const size_t CB = c->up_chunk, n_chunks = (size_t)((total + CB - 1) / CB);
+	int T = dsb_host_cpus() / 2; if (T > 8) T = 8;
+	if (const char *e = getenv("DSB_UPLOAD_THREADS")) T = atoi(e);
+	if ((size_t)T > n_chunks) T = (int)n_chunks;
+	if (T < 1) T = 1;
+	while (c->up.size() < (size_t)T) {
+		UpStage u;
+		for (int k = 0; k < 2; k++) { u.buf[k] = (char *)dsb_host_alloc(CB); if (!u.buf[k] || hipEventCreateWithFlags(&u.ev[k], hipEventDisableTiming) != hipSuccess) { for (int j = 0; j <= k; j++) { if (u.buf[j]) hipHostFree(u.buf[j]); if (u.ev[j]) hipEventDestroy(u.ev[j]); } return DSB_ENOMEM; } }
+		if (hipStreamCreateWithFlags(&u.st, hipStreamNonBlocking) != hipSuccess) { for (int k = 0; k < 2; k++) { hipHostFree(u.buf[k]); hipEventDestroy(u.ev[k]); } return DSB_ENODEV; }
+		c->up.push_back(u);
+	}
+	std::atomic<size_t> next(0); std::atomic<int> err(0);
+	const DsbReadDesc *rd = s.h_rd.data();
+	auto work = [&](int t) {
+		if (hipSetDevice(c->device) != hipSuccess) { err = 1; return; }
+		UpStage &u = c->up[t]; int par = 0;
+		for (;;) {
+			const size_t ch = next.fetch_add(1);
+			if (ch >= n_chunks || err.load()) break;
+			if (u.used[par] && hipEventSynchronize(u.ev[par]) != hipSuccess) { err = 1; break; }
+			const uint64_t lo = (uint64_t)ch * CB, hi = lo + CB < total ? lo + CB : total;
+			size_t a = 0, b = n;                               // first read that ends beyond lo
+			while (a < b) { const size_t m = (a + b) / 2; if (rd[m].seq_off + rd[m].len > lo) b = m; else a = m + 1; }
+			char *dst = u.buf[par];
+			for (size_t i = a; i < n && rd[i].seq_off < hi; i++) {
+				const uint64_t p = rd[i].seq_off > lo ? rd[i].seq_off : lo, q = rd[i].seq_off + rd[i].len < hi ? rd[i].seq_off + rd[i].len : hi;
+				if (q > p) memcpy(dst + (p - lo), reads[i].p + (p - rd[i].seq_off), (size_t)(q - p));
+			}
+			if (hipMemcpyAsync(s.d_ascii + lo, dst, (size_t)(hi - lo), hipMemcpyHostToDevice, u.st) != hipSuccess || hipEventRecord(u.ev[par], u.st) != hipSuccess) { err = 1; break; }
+			u.used[par] = true; par ^= 1;
+		}
+		if (hipStreamSynchronize(u.st) != hipSuccess) err = 1;
+		u.used[0] = u.used[1] = false;
+	};
+	std::vector<std::thread> th;
+	for (int t = 1; t < T; t++) th.emplace_back(work, t);
+	work(0);
+	for (std::thread &x : th) x.join();
+	if (err.load()) { fprintf(stderr, "[desamba_amd] HIP error %s in upload_gather\n", hipGetErrorString(hipGetLastError())); return DSB_ENODEV; }
+	return DSB_OK;
+}
 // `ext_text` != nullptr: the sequences already lie in one host blob (read i at ext_text + ext_off[i]); the blob is copied
 // to the device as it is (no per-read gather) and the descriptors point into it
 static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *ext_text = nullptr, size_t ext_len = 0, const uint64_t *ext_off = nullptr)
@@ -1088,11 +1162,8 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 		}
 		if (ext_text) HIPCHK(hipMemcpyAsync(s.d_ascii, ext_text, ext_len, hipMemcpyHostToDevice, c->stream));
 		else {
-			// sequences: copied read by read out of the caller's buffers (caller owns read memory)
-			std::vector<char> stage((size_t)seq_off);
-			for (size_t i = 0; i < n; i++) memcpy(stage.data() + s.h_rd[i].seq_off, reads[i].p, reads[i].len);
-			HIPCHK(hipMemcpyAsync(s.d_ascii, stage.data(), (size_t)seq_off, hipMemcpyHostToDevice, c->stream));
-			HIPCHK(hipStreamSynchronize(c->stream));       // `stage` goes out of scope
+			// sequences: gathered out of the caller's buffers (caller owns read memory) through pinned chunks
+			if ((rc = upload_gather(c, s, reads, n, seq_off))) return rc;
 		}
 	}
 	HIPCHK(hipStreamSynchronize(c->stream));               // the caller's buffers are free again when this returns
@@ -1111,7 +1182,7 @@ extern "C" int dsb_batch_upload_text(dsb_ctx *c, const char *text, size_t text_l
 {
 	if (!c || ((!text || !seq_off || !seq_len) && n)) return DSB_EINVAL;
 	std::vector<SeqView> v(n);
-	for (size_t i = 0; i < n; i++) { if (seq_off[i] + seq_len[i] > text_len) return DSB_EINVAL; v[i].p = text + seq_off[i]; v[i].len = seq_len[i]; }
+	for (size_t i = 0; i < n; i++) { if (seq_off[i] > text_len || seq_len[i] > text_len - seq_off[i]) return DSB_EINVAL; v[i].p = text + seq_off[i]; v[i].len = seq_len[i]; }
 	return upload_views(c, v.data(), n, text, text_len, seq_off);
 }
 

@@ -168,12 +168,17 @@ int  dsb_shard_plan(const uint32_t *lengths, size_t n, int world, uint64_t chunk
 int  dsb_classify_batch(dsb_ctx *ctx, const dsb_read *reads, size_t n, dsb_result *out);
 
 /* the same, split so that a benchmark can time the device part with inputs resident in HBM */
+/* (the sequences are gathered out of the caller's buffers by a few host threads through pinned chunks, each chunk
+ * travelling as soon as it is full: reads may lie anywhere, e.g. in a mapped input file) */
 int  dsb_batch_upload(dsb_ctx *ctx, const dsb_read *reads, size_t n);
 /* the same for sequences that already lie in one host blob (a parsed FASTQ buffer): read i = text[seq_off[i] .. +seq_len[i]);
  * the blob goes to the device in one copy, at PCIe speed if it came from dsb_host_alloc (pinned memory) */
 int  dsb_batch_upload_text(dsb_ctx *ctx, const char *text, size_t text_len, const uint64_t *seq_off, const uint32_t *seq_len, size_t n);
 void *dsb_host_alloc(size_t bytes);
 void  dsb_host_free(void *p);
+/* host threads worth starting (the T of kt_for, src/cly_mt.c:389, for the host-side stages): CPUs the process may run on,
+ * capped by the CPU quota of its control group */
+int   dsb_host_cpus(void);
 /* read_reads (src/cly_mt.c:42-56) for a plain-text FASTQ/FASTA file: stage records [skip, skip+max_reads) of the
  * file into HBM without per-read host copies; returns the number of reads staged, or a negative DSB_E* code */
 long dsb_batch_upload_fastq(dsb_ctx *ctx, const char *path, size_t skip, size_t max_reads);

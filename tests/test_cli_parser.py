@@ -6,6 +6,7 @@ restatement to the compiled reference.  No GPU."""
 import gzip
 import os
 import random
+import re
 import subprocess
 
 import pytest
@@ -83,7 +84,7 @@ def harness(built, tmp_path_factory):
     exe = tmp_path_factory.mktemp("cli") / "parse_harness"
     subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-I" + os.path.join(ROOT, "include"), "-o", str(exe),
                            os.path.join(ROOT, "tests", "cli", "parse_harness.c"), "-L" + os.path.join(ROOT, "desamba_amd"), "-ldesamba_amd",
-                           "-Wl,-rpath," + os.path.join(ROOT, "desamba_amd"), "-lpthread", "-lz"])
+                           "-Wl,-rpath," + os.path.join(ROOT, "desamba_amd"), "-lpthread", "-lz", "-ldl"])
     return str(exe)
 
 
@@ -154,30 +155,95 @@ def test_history_runs_over_all_files(harness, tmp_path):
     assert [int(l.split(b"\t")[3]) for l in out] == [0, 500, 500]  # both reads of the second file share a batch
 
 
-def test_parallel_pread_path(harness, tmp_path, monkeypatch):
-    """big plain files are filled by several pread threads; force that path on a small file"""
-    data = make_inputs()["four"] * 40
-    path = tmp_path / "big.fq"; path.write_bytes(data)
-    exp = [(n, s, q) for n, s, q in kseq_records(data)]
-    monkeypatch.setenv("DSB_CLI_PREAD_MIN", "1024")
-    for cap in (5000, 100000, 1 << 22):
-        got = run_harness(harness, cap, str(path))
-        assert exp == [(n, s, q) for n, s, q, _ in got], cap
+def bgzf_bytes(data: bytes, block=0xff00, level=6, eof_marker=True) -> bytes:
+    """a BGZF file (bgzip's format: gzip members of <= 64 KB of text each, their compressed size in a 'BC' extra field)"""
+    import struct
+    import zlib
+    out = bytearray()
+    chunks = [data[i:i + block] for i in range(0, len(data), block)] + ([b""] if eof_marker else [])
+    for ch in chunks:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(ch) + co.flush()
+        bsize = 12 + 6 + len(body) + 8
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += body + struct.pack("<II", zlib.crc32(ch) & 0xffffffff, len(ch))
+    return bytes(out)
 
 
 @pytest.mark.parametrize("name", ["four", "mixed", "multi_fq", "junk", "no_nl", "crlf"])
 def test_parallel_parse_path(harness, tmp_path, monkeypatch, name):
-    """buffers above a threshold are cut at guessed record starts and parsed by several threads; the result must be the
+    """a wave of text is cut at guessed record starts and parsed by several threads; the result must be the
     sequential one whether the guess holds (4-line FASTQ) or the code has to fall back (anything else)"""
     data = make_inputs()[name] * 25
     path = tmp_path / "p.fq"; path.write_bytes(data)
     exp = [(n, s, q if q is not None else b"") for n, s, q in kseq_records(data)]
-    monkeypatch.setenv("DSB_CLI_PPARSE_MIN", "2000")
+    monkeypatch.setenv("DSB_CLI_SEG_KB", "1")
+    monkeypatch.setenv("DSB_CLI_THREADS", "7")
+    monkeypatch.setenv("DSB_HARNESS_STATS", "1")
     longest = max(len(n) + 2 * len(s) for n, s, _ in exp) + 700
     for cap in (longest * 12, 60000, 1 << 23):
+        p = subprocess.run([harness, str(cap), str(path)], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if name == "four":     # the guess holds on 4-line FASTQ: the pieces must actually have been parsed side by side
+            assert int(re.search(rb"parallel (\d+)", p.stderr).group(1)) > 0, p.stderr
         got = run_harness(harness, cap, str(path))
         assert exp == [(n, s, q) for n, s, q, _ in got], (name, cap)
         run_max = 0
         for (n, s, q, h) in got:
             assert h <= run_max
             run_max = max(run_max, len(s))
+
+
+@pytest.mark.parametrize("name", ["four", "mixed", "crlf"])
+@pytest.mark.parametrize("nolib", [False, True])
+def test_bgzf_and_multi_member_gzip(harness, tmp_path, monkeypatch, name, nolib):
+    """BGZF input is inflated block-parallel (libdeflate if the system has it, zlib otherwise), concatenated gzip members
+    are one text, bytes behind the last member are ignored (gzread's rules, src/lib/utils.c:841-905), and a BGZF file
+    that turns into plain gzip half way is read to its end"""
+    data = make_inputs()[name] * 9
+    exp = [(n, s, q if q is not None else b"") for n, s, q in kseq_records(data)]
+    if nolib:
+        monkeypatch.setenv("DSB_CLI_NO_LIBDEFLATE", "1")
+    monkeypatch.setenv("DSB_CLI_THREADS", "5")
+    monkeypatch.setenv("DSB_CLI_SEG_KB", "1")
+    half = len(data) // 2
+    files = {"bgzf": bgzf_bytes(data, block=3000), "bgzf_big": bgzf_bytes(data), "members": gzip.compress(data[:half]) + gzip.compress(data[half:]),
+             "trailing": gzip.compress(data) + b"\0\0garbage", "bgzf_then_gzip": bgzf_bytes(data[:half], block=2000, eof_marker=False) + gzip.compress(data[half:])}
+    for kind, blob in files.items():
+        path = tmp_path / (kind + ".fq.gz"); path.write_bytes(blob)
+        assert gzip.decompress(blob if kind != "trailing" else blob[:-9]) == data
+        for cap in (5000, 70000, 1 << 22):
+            got = run_harness(harness, cap, str(path))
+            assert exp == [(n, s, q) for n, s, q, _ in got], (name, kind, cap)
+
+
+def test_several_gzip_files_are_inflated_ahead(harness, tmp_path, monkeypatch):
+    """every upcoming .gz file has an inflater of its own; the records still arrive in file order"""
+    monkeypatch.setenv("DSB_CLI_THREADS", "4")
+    inputs = make_inputs(); exp = []; paths = []
+    for i, name in enumerate(["four", "multi_fq", "crlf", "junk", "four", "mixed"]):
+        data = inputs[name] * (i + 1)
+        exp += [(n, s, q if q is not None else b"") for n, s, q in kseq_records(data)]
+        p = tmp_path / ("f%d.fq%s" % (i, ".gz" if i != 2 else "")); paths.append(str(p))
+        p.write_bytes(gzip.compress(data) if i != 2 else data)
+    for cap in (3000, 1 << 20):
+        out = subprocess.run([harness, str(cap)] + paths, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        got = [tuple(f.replace(b"\\n", b"\n").replace(b"\\r", b"\r") for f in l.split(b"\t")[:3]) for l in out.split(b"\n")[:-1]]
+        assert got == exp, cap
+
+
+def test_pipe_input(harness, tmp_path):
+    """a FIFO (or /dev/stdin) is read through gzread like every input of the reference, plain or compressed"""
+    data = make_inputs()["four"] * 3
+    exp = [(n, s, q) for n, s, q in kseq_records(data)]
+    for blob in (data, gzip.compress(data)):
+        fifo = tmp_path / "in.fifo"
+        if fifo.exists():
+            fifo.unlink()
+        os.mkfifo(fifo)
+        w = subprocess.Popen(["sh", "-c", "cat > '%s'" % fifo], stdin=subprocess.PIPE)
+        h = subprocess.Popen([harness, "4096", str(fifo)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        w.stdin.write(blob); w.stdin.close(); w.wait()
+        out = h.communicate()[0]
+        assert h.returncode == 0
+        got = [tuple(l.split(b"\t")[:3]) for l in out.split(b"\n")[:-1]]
+        assert got == exp
