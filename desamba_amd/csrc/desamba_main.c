@@ -121,11 +121,12 @@ typedef struct {
 	size_t batch_bytes, batch_reads, batch_max_bytes, batch_max_reads;   /* a batch closes once it has batch_reads reads AND batch_bytes of text, or either maximum */
 	size_t seg_min;                                   /* smallest piece worth a parse thread of its own */
 	int n_parse, n_format, n_inflate;
+	int ramp, every_wave;                             /* batches of growing size at the start (2 = a quarter, a half, full); tests: every wave closes a batch */
 	unsigned long total;
 	unsigned long n_badqual;                          /* records dropped because their quality string had the wrong length */
 	unsigned long n_status;                           /* reads whose device status stayed non-zero after the second run */
 	int n_ctx;
-	int trace; trace_t tr; pthread_mutex_t tr_mu;
+	int trace; trace_t tr; pthread_mutex_t tr_mu; long thr0;
 	/* recycled inflated blocks */
 	gzbuf_t *gz_free; pthread_mutex_t gz_mu;
 } app_t;
@@ -461,13 +462,13 @@ static size_t parse_wave(app_t *a, batch_t *b, char *t, size_t pos, size_t soft_
 	return next;
 }
 
-static int batch_full(const app_t *a, const batch_t *b)
-{
-	return (b->n >= a->batch_reads && b->bytes >= a->batch_bytes) || b->bytes >= a->batch_max_bytes || b->n >= a->batch_max_reads;
-}
-
 /* ---------------------------------------------------------------- the reader */
-typedef struct { app_t *a; long seqno; uint32_t hist; batch_t *b; } rd_t;
+typedef struct { app_t *a; long seqno; uint32_t hist; batch_t *b; int ramp; } rd_t;   /* ramp: the current batch closes at 1 / 2^ramp of the thresholds */
+static int batch_full(const rd_t *r)
+{
+	const app_t *a = r->a; const batch_t *b = r->b;
+	return (b->n >= (a->batch_reads >> r->ramp) && b->bytes >= (a->batch_bytes >> r->ramp)) || b->bytes >= a->batch_max_bytes || b->n >= a->batch_max_reads;
+}
 static void rd_open_batch(rd_t *r)
 {
 	if (r->b) return;
@@ -475,6 +476,9 @@ static void rd_open_batch(rd_t *r)
 	r->b = q_pop(&r->a->free_q);
 	r->a->tr.wait_free_s += now() - t0;
 	r->b->n = 0; r->b->bytes = 0; r->b->hist_before = r->hist; r->b->seqno = r->seqno++;
+	/* the device idles until the first batch has been parsed and uploaded: the first batches are a quarter and a half
+	 * of the full size (a small batch costs the device more per read -- a call lasts as long as its heaviest read) */
+	r->ramp = r->b->seqno < r->a->ramp ? r->a->ramp - (int)r->b->seqno : 0;
 }
 static void rd_close_batch(rd_t *r)
 {
@@ -498,7 +502,9 @@ static void read_plain(rd_t *r, int fd, size_t size)
 		pos = parse_wave(a, r->b, t, pos, pos + a->wave_bytes, size, 1, &last, &hist);
 		r->hist = hist;
 		if (pos == before && !last) pos = size;               /* (cannot happen with eof set; never loop) */
-		if (batch_full(a, r->b)) rd_close_batch(r);
+		/* what is left of the file would make a batch of less than half this one: it joins this one */
+		const size_t left = size - pos;
+		if (batch_full(r) && !(left && left < r->b->bytes / 2 && r->b->bytes + left <= a->batch_max_bytes && !r->ramp && !a->every_wave)) rd_close_batch(r);
 	}
 	/* the mapping stays until the process ends: batches in flight point into it */
 }
@@ -555,7 +561,7 @@ static void read_gz(rd_t *r, inflater_t *f)
 				memcpy(carry, g->p + pos, carry_len);
 			}
 		}
-		if (batch_full(a, b)) rd_close_batch(r);
+		if (batch_full(r)) rd_close_batch(r);
 		if (g->eof) break;
 	}
 	free(carry);
@@ -568,7 +574,7 @@ static void *reader_main(void *arg)
 	app_t *a = arg;
 	/* max_read_l (src/cly.c:2958) lives in the per-thread buffers that classify_main allocates once, before the loop
 	 * over the input files (src/cly_mt.c:538-556), and is never reset: the prefix maximum runs over ALL files */
-	rd_t r = { a, 0, 0, NULL };
+	rd_t r = { a, 0, 0, NULL, 0 };
 	const int nf = a->argc - a->first_file;
 	inflater_t *inf = calloc((size_t)(nf > 0 ? nf : 1), sizeof *inf);
 	int *fds = xmalloc((size_t)(nf > 0 ? nf : 1) * sizeof *fds); size_t *sizes = xmalloc((size_t)(nf > 0 ? nf : 1) * sizeof *sizes);
@@ -729,16 +735,27 @@ static void app_defaults(app_t *a)
 	a->batch_reads = env_size("DSB_CLI_BATCH_READS", 65536, 0); a->batch_bytes = (size_t)1 << 30;
 	a->batch_max_bytes = env_size("DSB_CLI_BATCH_MB", (size_t)8 << 30, 20); a->batch_max_reads = env_size("DSB_CLI_BATCH_MAX_READS", (size_t)4 << 20, 0);
 	if (a->batch_bytes > a->batch_max_bytes) a->batch_bytes = a->batch_max_bytes;
-	if (getenv("DSB_CLI_BATCH_KB")) { a->wave_bytes = env_size("DSB_CLI_BATCH_KB", 0, 10); a->batch_reads = 1; a->batch_bytes = 1; }
+	a->ramp = getenv("DSB_CLI_RAMP") ? atoi(getenv("DSB_CLI_RAMP")) : 2; if (a->ramp < 0 || a->ramp > 8) a->ramp = 0;
+	if (getenv("DSB_CLI_BATCH_KB")) { a->wave_bytes = env_size("DSB_CLI_BATCH_KB", 0, 10); a->batch_reads = 1; a->batch_bytes = 1; a->ramp = 0; a->every_wave = 1; }
 	if (a->wave_bytes < 64) a->wave_bytes = 64;
 	a->seg_min = env_size("DSB_CLI_SEG_KB", (size_t)2 << 20, 10);
 	a->trace = getenv("DSB_CLI_TRACE") != NULL;
 	pthread_mutex_init(&a->tr_mu, NULL); pthread_mutex_init(&a->gz_mu, NULL);
 }
 
+/* CPU time the control group was denied so far (cgroup v2 cpu.stat), microseconds; -1 if unknown */
+static long throttled_usec(void)
+{
+	FILE *f = fopen("/sys/fs/cgroup/cpu.stat", "r"); if (!f) return -1;
+	char k[64]; long v, r = -1;
+	while (fscanf(f, "%63s %ld", k, &v) == 2) if (!strcmp(k, "throttled_usec")) r = v;
+	fclose(f);
+	return r;
+}
 static void trace_summary(const app_t *a, double sec)
 {
 	const trace_t *t = &a->tr;
+	if (a->thr0 >= 0) fprintf(stderr, "[trace] host: %d usable CPUs (dsb_host_cpus), the control group was throttled for %.3f s of thread time during the run\n", dsb_host_cpus(), (throttled_usec() - a->thr0) / 1e6);
 	fprintf(stderr, "[trace] reader: %.2f GB of text in %zu waves (%zu parsed in parallel on %d threads), parsing %.3f s = %.1f GB/s while it runs; waited %.3f s for a free batch, %.3f s for inflated text\n",
 	        t->bytes / 1e9, t->waves, t->waves_parallel, a->n_parse, t->parse_s, t->parse_s > 0 ? t->bytes / 1e9 / t->parse_s : 0.0, t->wait_free_s, t->wait_text_s);
 	if (t->inflate_out) fprintf(stderr, "[trace] inflate: %.2f GB of text, %.3f s of inflater time (%d threads per BGZF file, %s)\n", t->inflate_out / 1e9, t->inflate_s, a->n_inflate, ld_alloc ? "libdeflate" : "zlib");
@@ -801,6 +818,7 @@ static int classify_main(int argc, char **argv)
 	if (rc) { fprintf(stderr, "\n[dsb_ctx_create] %s\n", dsb_strerror(rc)); exit(1); }
 	for (int k = 0; k < a.n_ctx; k++) a.ctx[k] = dsb_multi_ctx(a.multi, k);
 	double t0 = now(), cpu0 = cputime();
+	a.thr0 = a.trace ? throttled_usec() : -1;
 	fprintf(stderr, "Start classify\n");
 	q_init(&a.free_q); q_init(&a.parsed_q); q_init(&a.done_q);
 	for (int i = 0; i < a.n_ctx + 2; i++) q_push(&a.free_q, &batches[i]);

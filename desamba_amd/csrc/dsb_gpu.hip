@@ -831,7 +831,8 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	// every failure from here on goes through dsb_ctx_destroy: nothing allocated so far is leaked
 #define CK(e) do { if (rc == DSB_OK && (e) != hipSuccess) { fprintf(stderr, "[desamba_amd] HIP error %s at %s:%d\n", hipGetErrorString(hipGetLastError()), __FILE__, __LINE__); rc = DSB_ENODEV; } } while (0)
 	CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));   // contexts on one device overlap each other's copies and kernels
-	for (int i = 0; i < 4; i++) CK(hipEventCreate(&c->ev[i]));
+	for (int i = 0; i < 3; i++) CK(hipEventCreate(&c->ev[i]));
+	CK(hipEventCreateWithFlags(&c->ev[3], hipEventBlockingSync));     // the end of a batch is waited for asleep (a spinning host thread per context costs a CPU of the quota)
 	CK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)); CK(hipEventCreate(&c->ev_order)); CK(hipEventCreate(&c->ev_cls));
 	CK(hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&c->ev_hprobe, hipEventDisableTiming));
 	CK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)); CK(hipEventCreateWithFlags(&c->ev_heavy3, hipEventDisableTiming));
@@ -1076,12 +1077,13 @@ extern "C" int dsb_host_cpus(void)
 // host threads copy the pieces of the reads that fall into a chunk into pinned memory and send the chunk on a stream of
 // their own -- the gather runs at memory speed on several cores and overlaps the transfers.
 #include <atomic>
+#include <time.h>
 static int upload_gather(dsb_ctx *c, InSlot &s, const SeqView *reads, size_t n, uint64_t total)
 {
 	if (!total) return DSB_OK;
 	if (!c->up_chunk) { const char *e = getenv("DSB_UPLOAD_CHUNK_KB"); c->up_chunk = e && atol(e) > 0 ? (size_t)atol(e) << 10 : (size_t)8 << 20; }
 	const size_t CB = c->up_chunk, n_chunks = (size_t)((total + CB - 1) / CB);
-	int T = dsb_host_cpus() / 2; if (T > 8) T = 8;
+	int T = dsb_host_cpus() / 2; if (T > 16) T = 16;
 	if (const char *e = getenv("DSB_UPLOAD_THREADS")) T = atoi(e);
 	if ((size_t)T > n_chunks) T = (int)n_chunks;
 	if (T < 1) T = 1;
@@ -1093,13 +1095,19 @@ static int upload_gather(dsb_ctx *c, InSlot &s, const SeqView *reads, size_t n, 
 	}
 	std::atomic<size_t> next(0); std::atomic<int> err(0);
 	const DsbReadDesc *rd = s.h_rd.data();
+	const bool trace = getenv("DSB_UPLOAD_TRACE") != nullptr;
+	std::vector<double> t_wait(T, 0.0), t_copy(T, 0.0), t_sub(T, 0.0);
+	auto clk = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+	const double t_begin = clk();
 	auto work = [&](int t) {
 		if (hipSetDevice(c->device) != hipSuccess) { err = 1; return; }
 		UpStage &u = c->up[t]; int par = 0;
 		for (;;) {
 			const size_t ch = next.fetch_add(1);
 			if (ch >= n_chunks || err.load()) break;
+			const double w0 = trace ? clk() : 0;
 			if (u.used[par] && hipEventSynchronize(u.ev[par]) != hipSuccess) { err = 1; break; }
+			const double w1 = trace ? clk() : 0;
 			const uint64_t lo = (uint64_t)ch * CB, hi = lo + CB < total ? lo + CB : total;
 			size_t a = 0, b = n;                               // first read that ends beyond lo
 			while (a < b) { const size_t m = (a + b) / 2; if (rd[m].seq_off + rd[m].len > lo) b = m; else a = m + 1; }
@@ -1108,16 +1116,25 @@ static int upload_gather(dsb_ctx *c, InSlot &s, const SeqView *reads, size_t n, 
 				const uint64_t p = rd[i].seq_off > lo ? rd[i].seq_off : lo, q = rd[i].seq_off + rd[i].len < hi ? rd[i].seq_off + rd[i].len : hi;
 				if (q > p) memcpy(dst + (p - lo), reads[i].p + (p - rd[i].seq_off), (size_t)(q - p));
 			}
+			const double w2 = trace ? clk() : 0;
 			if (hipMemcpyAsync(s.d_ascii + lo, dst, (size_t)(hi - lo), hipMemcpyHostToDevice, u.st) != hipSuccess || hipEventRecord(u.ev[par], u.st) != hipSuccess) { err = 1; break; }
+			if (trace) { const double w3 = clk(); t_wait[t] += w1 - w0; t_copy[t] += w2 - w1; t_sub[t] += w3 - w2; }
 			u.used[par] = true; par ^= 1;
 		}
+		const double w0 = trace ? clk() : 0;
 		if (hipStreamSynchronize(u.st) != hipSuccess) err = 1;
+		if (trace) t_wait[t] += clk() - w0;
 		u.used[0] = u.used[1] = false;
 	};
 	std::vector<std::thread> th;
 	for (int t = 1; t < T; t++) th.emplace_back(work, t);
 	work(0);
 	for (std::thread &x : th) x.join();
+	if (trace) {
+		double a = 0, b = 0, d = 0; for (int t = 0; t < T; t++) { a += t_wait[t]; b += t_copy[t]; d += t_sub[t]; }
+		fprintf(stderr, "[upload] %.2f GB in %zu chunks on %d threads: %.3f s wall = %.1f GB/s; per thread: gather %.3f s, waiting for a chunk's transfer %.3f s, submitting %.3f s\n", total / 1e9, n_chunks, T,
+		        clk() - t_begin, total / 1e9 / (clk() - t_begin), b / T, a / T, d / T);
+	}
 	if (err.load()) { fprintf(stderr, "[desamba_amd] HIP error %s in upload_gather\n", hipGetErrorString(hipGetLastError())); return DSB_ENODEV; }
 	return DSB_OK;
 }
@@ -1378,7 +1395,7 @@ static int batch_run_locked(dsb_ctx *c)
 	hipLaunchKernelGGL(k_collect_retry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const DsbReadOut *)c->d_rout, (uint32_t)n, c->d_score, c->d_counters + 6, retry_mask, 0);
 	launch_classify(k_classify_second, c, c->stream, (unsigned)c->n_slots_big, dx2, s, 0u, (const unsigned int *)(c->d_counters + 6), (const uint32_t *)c->d_score, c->arena_big, c->d_counters + 7, nullptr, 0u, 0u, 2, use_scan);
 	HIPCHK(hipEventRecord(c->ev[3], c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
+	HIPCHK(hipEventSynchronize(c->ev[3]));
 	{
 		// The hit buffer holds 16 n + 4096 records (the reference's lists are unbounded).  The device counts every
 		// hit it wanted to write; if that is more than the buffer holds, the buffer is regrown (contents kept) and

@@ -19,7 +19,7 @@ int main(int argc, char **argv)
 	a.argc = argc; a.argv = argv; a.first_file = 2;
 	app_defaults(&a);
 	a.wave_bytes = (size_t)atol(argv[1]); if (a.wave_bytes < 64) a.wave_bytes = 64;
-	a.batch_reads = 1; a.batch_bytes = 1;
+	a.batch_reads = 1; a.batch_bytes = 1; a.ramp = 0; a.every_wave = 1;
 	q_init(&a.free_q); q_init(&a.parsed_q); q_init(&a.done_q);
 	for (int i = 0; i < N_BATCH; i++) q_push(&a.free_q, &batches[i]);
 	pthread_t th; pthread_create(&th, NULL, reader_main, &a);
