@@ -15,7 +15,7 @@ DSB_OK, DSB_EIO, DSB_ENODEV, DSB_ENOMEM, DSB_EINVAL, DSB_ECAP = 0, -1, -2, -3, -
 
 class DsbOpts(C.Structure):
     _fields_ = [("L_min_matching", C.c_int), ("min_score", C.c_int), ("max_sec_N", C.c_int), ("n_slots", C.c_int),
-                ("max_read_len", C.c_uint32), ("max_batch_reads", C.c_uint32), ("input_slots", C.c_int), ("reserved", C.c_int)]
+                ("max_read_len", C.c_uint32), ("max_batch_reads", C.c_uint32), ("input_slots", C.c_int), ("reserved", C.c_int), ("max_batch_bases", C.c_uint64)]
 
 
 class DsbRead(C.Structure):
@@ -191,9 +191,9 @@ def make_reads(records):
 class Ctx:
     """classify_main's set-up (src/cly_mt.c:518-550) on one GPU."""
 
-    def __init__(self, index, device=0, L_min_matching=170, min_score=64, max_sec_N=5, n_slots=0, max_read_len=0, max_batch_reads=0, input_slots=1):
+    def __init__(self, index, device=0, L_min_matching=170, min_score=64, max_sec_N=5, n_slots=0, max_read_len=0, max_batch_reads=0, input_slots=1, max_batch_bases=0):
         self.index = index
-        self.opts = DsbOpts(L_min_matching, min_score, max_sec_N, n_slots, max_read_len, max_batch_reads, input_slots, 0)
+        self.opts = DsbOpts(L_min_matching, min_score, max_sec_N, n_slots, max_read_len, max_batch_reads, input_slots, 0, max_batch_bases)
         self.h = C.c_void_p()
         rc = lib().dsb_ctx_create(index.h, device, C.byref(self.opts), C.byref(self.h))
         if rc != 0:

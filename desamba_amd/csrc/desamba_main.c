@@ -462,6 +462,8 @@ static size_t parse_wave(app_t *a, batch_t *b, char *t, size_t pos, size_t soft_
 	return next;
 }
 
+static int is_gzip(int fd);
+static void batch_release(app_t *a, batch_t *b);
 /* ---------------------------------------------------------------- the reader */
 typedef struct { app_t *a; long seqno; uint32_t hist; batch_t *b; int ramp; } rd_t;   /* ramp: the current batch closes at 1 / 2^ramp of the thresholds */
 static int batch_full(const rd_t *r)
@@ -502,9 +504,9 @@ static void read_plain(rd_t *r, int fd, size_t size)
 		pos = parse_wave(a, r->b, t, pos, pos + a->wave_bytes, size, 1, &last, &hist);
 		r->hist = hist;
 		if (pos == before && !last) pos = size;               /* (cannot happen with eof set; never loop) */
-		/* what is left of the file would make a batch of less than half this one: it joins this one */
+		/* what is left of the file would make a batch of less than a quarter of this one: it joins this one */
 		const size_t left = size - pos;
-		if (batch_full(r) && !(left && left < r->b->bytes / 2 && r->b->bytes + left <= a->batch_max_bytes && !r->ramp && !a->every_wave)) rd_close_batch(r);
+		if (batch_full(r) && !(left && left < r->b->bytes / 4 && r->b->bytes + left <= a->batch_max_bytes && !r->ramp && !a->every_wave)) rd_close_batch(r);
 	}
 	/* the mapping stays until the process ends: batches in flight point into it */
 }
@@ -565,6 +567,58 @@ static void read_gz(rd_t *r, inflater_t *f)
 		if (g->eof) break;
 	}
 	free(carry);
+}
+
+/* A look at the beginning of the input before the device contexts are made (classify_main's set-up, src/cly_mt.c:536-550:
+ * the reference allocates its batch buffers before its timer starts): the first wave of the first file is parsed, and
+ * from the reads found there -- bytes of text per read, bases per read, the longest -- follow the hints that let
+ * dsb_ctx_create allocate arenas and batch buffers for full-size batches once, instead of growing them batch by batch
+ * (a hipFree waits for the device, i.e. for the other context's kernels). */
+static void peek_input(app_t *a)
+{
+	const char *path = a->argv[a->first_file];
+	int fd = open(path, O_RDONLY); struct stat st;
+	if (fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) { if (fd >= 0) close(fd); return; }
+	static batch_t pb; int last = 0; uint32_t hist = 0; size_t used = 0, total = 0; int gz = is_gzip(fd);
+	char *t = NULL, *buf = NULL; size_t len = 0;
+	if (!gz) {
+		t = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+		if (t == MAP_FAILED) { close(fd); return; }
+		len = (size_t)st.st_size;
+		used = parse_wave(a, &pb, t, 0, a->wave_bytes < (64u << 20) ? a->wave_bytes : (64u << 20), len, 1, &last, &hist);
+	} else {
+		const size_t zn = (size_t)st.st_size < (8u << 20) ? (size_t)st.st_size : (8u << 20), cap = 64u << 20;
+		unsigned char *z = xmalloc(zn); buf = xmalloc(cap);
+		if (pread(fd, z, zn, 0) == (ssize_t)zn) {
+			z_stream zs; memset(&zs, 0, sizeof zs);
+			if (inflateInit2(&zs, 15 + 16) == Z_OK) {
+				zs.next_in = z; zs.avail_in = (uInt)zn; zs.next_out = (Bytef *)buf; zs.avail_out = (uInt)cap;
+				for (;;) { const int rc = inflate(&zs, Z_NO_FLUSH); if (rc == Z_STREAM_END && zs.avail_in > 18 && zs.avail_out) { inflateReset(&zs); continue; } if (rc != Z_OK || !zs.avail_out || !zs.avail_in) break; }
+				len = cap - zs.avail_out; inflateEnd(&zs);
+			}
+		}
+		free(z);
+		if (len) used = parse_wave(a, &pb, buf, 0, len, len, 0, &last, &hist);
+	}
+	size_t bases = 0; for (size_t i = 0; i < pb.n; i++) bases += pb.reads[i].len;
+	for (int i = a->first_file; i < a->argc; i++) { struct stat s2; if (stat(a->argv[i], &s2) == 0) total += (size_t)s2.st_size * (size_t)(gz ? 8 : 1); }
+	if (pb.n && used) {
+		const double bpr = (double)used / (double)pb.n, bases_pr = (double)bases / (double)pb.n;
+		double nf = (double)a->batch_reads; if (nf * bpr < (double)a->batch_bytes) nf = (double)a->batch_bytes / bpr;
+		if (nf * bpr > (double)a->batch_max_bytes) nf = (double)a->batch_max_bytes / bpr;
+		if (nf > (double)a->batch_max_reads) nf = (double)a->batch_max_reads;
+		nf = nf * 1.3 + (double)a->wave_bytes / bpr + 16;                 /* the last batch of a file may take a quarter more; a batch ends with a whole wave */
+		if (nf > (double)total / bpr * 1.05 + 16) nf = (double)total / bpr * 1.05 + 16;
+		if (nf < 4294967295.0 && hist * 1.25 < 4294967295.0) {
+			a->o.max_batch_reads = (uint32_t)nf; a->o.max_batch_bases = (uint64_t)(nf * bases_pr * 1.1) + 4096; a->o.max_read_len = (uint32_t)(hist * 1.25) + 64;
+		}
+		if (a->trace) fprintf(stderr, "[trace] input: %.0f bytes of text and %.0f bases per read, longest %u (first %zu reads) -> buffers for batches of %u reads, %.2f Gbases\n", bpr, bases_pr, hist, pb.n,
+		                      a->o.max_batch_reads, a->o.max_batch_bases / 1e9);
+	}
+	batch_release(a, &pb); free(pb.reads); pb.reads = NULL; pb.cap_n = 0; pb.n = 0;
+	if (t) munmap(t, len);
+	free(buf); close(fd);
+	memset(&a->tr, 0, sizeof a->tr);
 }
 
 static int is_gzip(int fd) { unsigned char m[2] = {0, 0}; return pread(fd, m, 2, 0) == 2 && m[0] == 0x1f && m[1] == 0x8b; }
@@ -811,6 +865,7 @@ static int classify_main(int argc, char **argv)
 	int ids[MAX_CTX]; a.n_ctx = 0;
 	for (int k = 0; k < CTX_PER_DEV; k++) for (int d = 0; d < n_dev; d++) ids[a.n_ctx++] = dev[d];
 	static batch_t batches[N_BATCH];
+	if (!getenv("DSB_CLI_NO_PEEK")) peek_input(&a);
 	fprintf(stderr, "loading index\t");
 	int rc = dsb_index_open(index_dir, &a.idx);
 	if (rc) { fprintf(stderr, "\n[load_idx] %s\n", dsb_strerror(rc)); exit(1); }

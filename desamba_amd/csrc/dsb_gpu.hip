@@ -789,6 +789,7 @@ extern "C" int dsb_device_count(void)
 }
 
 static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_bytes, uint64_t pk_words, uint64_t bit_words, uint64_t seed_entries);
+template <class T> static int grow(T **p, size_t *cap, size_t need);
 
 extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 {
@@ -853,6 +854,12 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 		if (c->opts.max_read_len && c->opts.max_batch_reads) {
 			const uint32_t L = c->opts.max_read_len; const size_t n = c->opts.max_batch_reads; const int k = c->dx.ek_len;
 			const uint64_t nwin = L >= 40 ? L - k + 1 : 0;
+			if (c->opts.max_batch_bases) {
+				// a batch of n reads with B bases in all, the longest of L: upper bounds of the sums upload_views forms read by read
+				const uint64_t B = c->opts.max_batch_bases;
+				rc = ensure_buffers(c, n, L, 2 * B + n * (uint64_t)(DSB_QPAD_L + DSB_QPAD_R + 256), B / 16 + 4 * (uint64_t)n, B / 32 + 4 * (uint64_t)n, B / 2 + 64 * (uint64_t)n);
+				for (InSlot &s : c->in) { if (!rc) rc = grow(&s.d_rd, &s.cap_rd, n + 1); if (!rc) rc = grow(&s.d_ascii, &s.cap_ascii, (size_t)B + 64); }
+			} else
 			rc = ensure_buffers(c, n, L, n * ((DSB_QPAD_L + 2 * (uint64_t)L + DSB_QPAD_R + 255) & ~(uint64_t)255), n * 2 * ((L + 31) / 32 + 1), n * 2 * ((nwin + 63) / 64), n * (((uint64_t)L >> 1) + 64));
 		}
 	}

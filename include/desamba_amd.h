@@ -42,6 +42,7 @@ typedef struct {
 	uint32_t max_batch_reads;  /*   for batches of that many reads of up to that length, instead of inside the first batch */
 	int input_slots;      /* batches a ctx can hold staged in HBM at once (dsb_ctx_select_slot); 0 or 1 = one */
 	int reserved;         /* 0 */
+	uint64_t max_batch_bases;  /* with the two hints above: bases of the largest batch (0 = max_batch_reads x max_read_len: all reads of full length) */
 } dsb_opts;
 
 /* replaces kseq_t as consumed by classify_seq (src/cly.c:3064): only seq/len reach the kernel */
