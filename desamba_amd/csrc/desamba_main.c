@@ -56,7 +56,7 @@ typedef struct {
 	dsb_read *reads; size_t n, cap_n;                 /* pointers into mapped files, inflated blocks, name blocks */
 	size_t bytes;                                     /* text the batch was parsed from */
 	uint32_t hist_before;                             /* longest read of the run before this batch */
-	long seqno;
+	long seqno; double t_parsed;
 	void **own; int n_own, cap_own;                   /* malloc'd blocks the reads point into: names, records joined across blocks */
 	gzbuf_t **gzb; int n_gzb, cap_gzb;                /* inflated blocks the reads point into */
 	dsb_read_result *rr; dsb_hit *hits; size_t cap_rr, cap_hits, n_hits;
@@ -126,7 +126,7 @@ typedef struct {
 	unsigned long n_badqual;                          /* records dropped because their quality string had the wrong length */
 	unsigned long n_status;                           /* reads whose device status stayed non-zero after the second run */
 	int n_ctx;
-	int trace; trace_t tr; pthread_mutex_t tr_mu; long thr0;
+	int trace; trace_t tr; pthread_mutex_t tr_mu; long thr0; double t0;
 	/* recycled inflated blocks */
 	gzbuf_t *gz_free; pthread_mutex_t gz_mu;
 } app_t;
@@ -485,6 +485,7 @@ static void rd_open_batch(rd_t *r)
 static void rd_close_batch(rd_t *r)
 {
 	if (!r->b) return;
+	r->b->t_parsed = now();
 	q_push(&r->a->parsed_q, r->b);                         /* empty batches keep the sequence numbers dense */
 	r->b = NULL;
 }
@@ -682,7 +683,9 @@ static void *gpu_main(void *arg)
 			if (!rc || rc == DSB_ECAP) rc = dsb_batch_fetch(ctx, &res);
 			t3 = now();
 			if (a->trace) {
-				fprintf(stderr, "[gpu %d] batch %ld: %zu reads, upload %.3f s, run %.3f s, fetch %.3f s\n", g->k, b->seqno, b->n, t1 - t0, t2 - t1, t3 - t2);
+				dsb_timing tm; memset(&tm, 0, sizeof tm); dsb_batch_timing(ctx, &tm);
+				fprintf(stderr, "[gpu %d] batch %ld: %zu reads, parsed at %.3f s, upload %.3f - %.3f s, run (turn + kernels) until %.3f s of which kernels %.3f s, fetched at %.3f s\n", g->k, b->seqno, b->n,
+				        b->t_parsed - a->t0, t0 - a->t0, t1 - a->t0, t2 - a->t0, tm.total_ms / 1e3, t3 - a->t0);
 				a->tr.up_s[g->k] += t1 - t0; a->tr.run_s[g->k] += t2 - t1; a->tr.fetch_s[g->k] += t3 - t2; a->tr.idle_s[g->k] += t0 - t_idle; a->tr.batches[g->k]++;
 			}
 			if (rc && rc != DSB_ECAP) { fprintf(stderr, "[dsb_classify_batch] %s\n", dsb_strerror(rc)); exit(1); }
@@ -747,6 +750,7 @@ static void *writer_main(void *arg)
 		const double t1 = now();
 		for (int t = 0; t < nt; t++) { if (t) pthread_join(th[t], NULL); fwrite(job[t].buf, 1, job[t].len, a->out); a->tr.out_bytes += job[t].len; a->n_status += job[t].n_status; }
 		a->tr.fmt_s += t1 - t0; a->tr.write_s += now() - t1;
+		if (a->trace) fprintf(stderr, "[writer] batch %ld written at %.3f s\n", b->seqno, now() - a->t0);
 		a->total += b->n;
 		next++;
 		batch_release(a, b);
@@ -872,7 +876,7 @@ static int classify_main(int argc, char **argv)
 	rc = dsb_ctx_create_multi(a.idx, ids, a.n_ctx, &a.o, &a.multi);
 	if (rc) { fprintf(stderr, "\n[dsb_ctx_create] %s\n", dsb_strerror(rc)); exit(1); }
 	for (int k = 0; k < a.n_ctx; k++) a.ctx[k] = dsb_multi_ctx(a.multi, k);
-	double t0 = now(), cpu0 = cputime();
+	double t0 = now(), cpu0 = cputime(); a.t0 = t0;
 	a.thr0 = a.trace ? throttled_usec() : -1;
 	fprintf(stderr, "Start classify\n");
 	q_init(&a.free_q); q_init(&a.parsed_q); q_init(&a.done_q);
