@@ -1488,6 +1488,48 @@ DN void wtab_build(lds_u32 *tab, int lane, P8 q_str, uint32_t q_bg, uint32_t n_q
 	wave_sync();
 }
 
+// The same table from the 2-bit packed strand (32 bases per word, first base in the top bits): a lane takes a run of
+// consecutive window positions, whose 9-mers all lie in three packed words -- three loads per lane issued together instead
+// of two byte-strand loads per position in eight dependent rounds (the table is rebuilt for every 600-base step of the
+// right / left extensions).  The order of insertion differs from wtab_build's; lookups collect all entries of a 9-mer
+// and visit them in ascending position whatever their slots.  Positions q_bg .. q_bg + n_q - 1 lie inside the strand
+// (sdp_nq), where packed words and strand bytes hold the same bases.
+DN void wtab_build_pk(lds_u32 *tab, int lane, const uint64_t *P, uint32_t n_words, uint32_t q_bg, uint32_t n_q)
+{
+	const uint32_t slots = wtab_size(n_q);
+	for (uint32_t i = lane; i < slots; i += DSB_WAVE) tab[i] = DSB_WTAB_EMPTY;
+	const uint32_t C = (n_q + DSB_WAVE - 1) / DSB_WAVE;                 // <= 32 positions per lane (n_q <= DSB_WTAB_MAXQ)
+	const uint32_t r0 = (uint32_t)lane * C, r1 = MINV(n_q, r0 + C);
+	uint64_t W0 = 0, W1 = 0, W2 = 0; uint32_t wi = 0;
+	if (r0 < r1) {
+		wi = (q_bg + r0) >> 5;
+		W0 = DSB_G64(P, wi); W1 = wi + 1 < n_words ? DSB_G64(P, wi + 1) : 0; W2 = wi + 2 < n_words ? DSB_G64(P, wi + 2) : 0;
+	}
+	wave_sync();
+	for (uint32_t r = r0; r < r1; r++) {
+		uint32_t rel = q_bg + r - (wi << 5);                                  // < 32 + 32 with 64 lanes: the 9-mer ends before base 96
+		if (rel >= 64) {                                                      // (narrower groups -- the 1-lane host emulation -- move on word by word)
+			wi += 2; rel -= 64; W0 = W2; W1 = wi + 1 < n_words ? DSB_G64(P, wi + 1) : 0; W2 = wi + 2 < n_words ? DSB_G64(P, wi + 2) : 0;
+		}
+		const uint32_t sh = (rel & 31u) * 2;
+		const uint64_t a = rel < 32 ? W0 : W1, b = rel < 32 ? W1 : W2;
+		const uint64_t hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
+		const uint32_t k = (uint32_t)(hi >> 46);
+		uint32_t e = (k << 12) | r, sl = wtab_slot(k, slots);
+		for (;;) {
+#ifdef DSB_HOST_EMU
+			uint32_t old = tab[sl]; if (old == DSB_WTAB_EMPTY) tab[sl] = e;
+#else
+			uint32_t old = DSB_WTAB_EMPTY;
+			__hip_atomic_compare_exchange_strong(tab + sl, &old, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+			if (old == DSB_WTAB_EMPTY) break;
+			sl = sl + 1 == slots ? 0 : sl + 1;
+		}
+	}
+	wave_sync();
+}
+
 // MEM_search (src/cly.c:1810-1818): length of the exact match, at most max, walking forward from (q,t)
 // or backward.  Eight bases per step; every buffer it is used on has >= 8 readable bytes past the
 // compared range on either side (pads), and bytes beyond `max` are ignored.
@@ -1666,7 +1708,8 @@ DV uint32_t sdp_nq(uint32_t L, uint32_t q_bg, uint32_t q_ed)
 
 // appends the nodes to w.sms[n_sms...] and returns the new count (w.n_sms is not touched)
 template <class P8>
-DV uint32_t sdp_match_p(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, P8 q_base, int32_t q_lo, P8 t_str, uint32_t t_len, uint32_t t_st, bool isForward, uint4 *lnodes)
+DV uint32_t sdp_match_p(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, P8 q_base, int32_t q_lo, P8 t_str, uint32_t t_len, uint32_t t_st, bool isForward, uint4 *lnodes,
+                        const uint64_t *qpk = nullptr)
 {
 	SdpArgsT<P8> a; a.lnodes = lnodes; a.q_bg = q_bg; a.q_ed = q_ed; a.q_base = q_base; a.q_lo = q_lo; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st;
 	a.tab = (const lds_u32 *)w.wtab; a.bm = reinterpret_cast<uint32_t *>(w.sortkey) + w.lane;
@@ -1674,14 +1717,15 @@ DV uint32_t sdp_match_p(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, P
 	if (a.n_q > DSB_WTAB_MAXQ) { w.status |= DSB_ST_SMS_OVF; return n_sms; }     // cannot happen: windows are <= 2001 wide
 	uint32_t t_kmer_num = t_len - 9 + 1;
 	if (a.n_q == 0 || t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return n_sms;
-	wtab_build<P8>((lds_u32 *)w.wtab, w.lane, q_base + ((int32_t)q_bg - q_lo), 0u, a.n_q);
+	if (qpk) wtab_build_pk((lds_u32 *)w.wtab, w.lane, qpk, (w.L + 31) / 32 + 1, q_bg, a.n_q);
+	else wtab_build<P8>((lds_u32 *)w.wtab, w.lane, q_base + ((int32_t)q_bg - q_lo), 0u, a.n_q);
 	return isForward ? sdp_match_t<true, P8>(w, a, n_sms) : sdp_match_t<false, P8>(w, a, n_sms);
 }
 // windows in global memory (q_str = the read strand) ...
 DN uint32_t sdp_match_n(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len,
-                        uint32_t t_st, bool isForward, uint4 *lnodes)
+                        uint32_t t_st, bool isForward, uint4 *lnodes, const uint64_t *qpk)
 {
-	return sdp_match_p<gp8>(w, n_sms, q_bg, q_ed, q_str, 0, t_str, t_len, t_st, isForward, lnodes);
+	return sdp_match_p<gp8>(w, n_sms, q_bg, q_ed, q_str, 0, t_str, t_len, t_st, isForward, lnodes, qpk);
 }
 // ... or staged in LDS by sdp_middle_M2: lq holds the read from position q_lo on, lt the reference window
 DN uint32_t sdp_match_lds(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *lq, int32_t q_lo, const uint8_t *lt, uint32_t t_len,
@@ -1692,8 +1736,8 @@ DN uint32_t sdp_match_lds(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed,
 DV void sdp_match(WCtx &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len, int key_len,
                   int tbl, uint32_t t_st, bool isForward)
 {
-	(void)key_len; (void)tbl;
-	w.n_sms = sdp_match_n(w, w.n_sms, q_bg, q_ed, q_str, t_str, t_len, t_st, isForward, nullptr) & 0x7fffffffu;
+	(void)key_len;
+	w.n_sms = sdp_match_n(w, w.n_sms, q_bg, q_ed, q_str, t_str, t_len, t_st, isForward, nullptr, w.pk[tbl]) & 0x7fffffffu;
 }
 
 // the ring lives in LDS: typed accesses (ds_read_b128 / ds_write_b128)
@@ -1888,7 +1932,10 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 		if (hi - DSB_DP_UNROLL * DSB_WAVE >= 0) { DSB_FETCH_PREDS(nx, hi - DSB_DP_UNROLL * DSB_WAVE) }
 		// Chunks without wrapped coordinates (all but a few) are first judged straight through, with no test for the
 		// distance cut between the groups; only a node that meets its cut in this pass is judged again in order.
-		const bool plain = wnm == 0 && !(wrapped[0] | wrapped[1] | wrapped[2] | wrapped[3]);
+		// (The newest chunk of a batch holds the distance cut of nearly every node -- an extension has left all but its last
+		// few dozen nodes more than 600 bases behind -- so it goes straight to the ordered pass; the straight pass pays
+		// from the second chunk on, i.e. in repeats, where hundreds of predecessors lie within reach.)
+		const bool plain = wnm == 0 && !(wrapped[0] | wrapped[1] | wrapped[2] | wrapped[3]) && hi != n0 - 1;
 		uint32_t redo = ~stopm & ((1u << DSB_DPB) - 1u);
 		if (plain) {
 #pragma unroll
@@ -2377,7 +2424,7 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 			for (int k = total_ref_len + lane; k < total_ref_len + 64; k += DSB_WAVE) ref[k] = DSB_TPAD_VAL;   // reads reach <= 58 past the window
 			wave_sync();
 			n_sms = lq_st ? sdp_match_lds(w, n_sms, q_bg, q_ed, lq_st, q_lo, ref, total_ref_len, pre_refoffset + pre_mch, lnodes)
-			              : sdp_match_n(w, n_sms, q_bg, q_ed, qs, ref, total_ref_len, pre_refoffset + pre_mch, true, lnodes);
+			              : sdp_match_n(w, n_sms, q_bg, q_ed, qs, ref, total_ref_len, pre_refoffset + pre_mch, true, lnodes, w.pk[tbl]);
 			mirror = lnodes != nullptr && !(n_sms >> 31); n_sms &= 0x7fffffffu;
 		}
 		n_sms++;                                                     // the last node
