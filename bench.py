@@ -423,6 +423,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=50000)
     ap.add_argument("--batches", type=int, default=0, help="distinct batches per GPU (0 = 4, fewer if host memory is short)")
     ap.add_argument("--index-mbp", type=int, default=320, help="size of the synthetic strain collection of the headline index")
+    ap.add_argument("--headline", choices=["strain", "demo"], default="strain", help="profiling runs: `demo` puts the reference's demo index in the headline position (nothing is built)")
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--t1-sample", type=int, default=384, help="reads of the stock reference's -t 1 vs -t N self-comparison (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -510,7 +511,10 @@ def main():
     B = a.batches or max(1, min(4, int(mem_limit() * 0.3 / world / (R * rec_bytes))))
 
     # ---- the headline: a viral-RefSeq-sized index built here, B batches per GPU simulated from it ----------------------
-    index_dir, build_info = strain_index(a, D, rank, local, barrier)
+    if a.headline == "demo":
+        index_dir, build_info = demo_dir, {"bases": 11476226, "sequences": 463, "kmers_31": 10982489, "index_files_bytes": 828e6, "seconds": 0.0}
+    else:
+        index_dir, build_info = strain_index(a, D, rank, local, barrier)
     idx = D.Index(index_dir)
     t0 = time.perf_counter()
     m = Measure(D, L, idx, index_dir, local, a, R, Lr, B, 1000 * (rank + 1), gen_threads)
@@ -520,7 +524,7 @@ def main():
     out = None
     if rank == 0:
         steps = max(a.steps, 1)
-        roof_cls, roof_seed, dom_is_cls = m.rooflines("strain")
+        roof_cls, roof_seed, dom_is_cls = m.rooflines(a.headline)
         idx_desc = "%.0f-Mbp synthetic strain collection (%d sequences, %d M 31-mers, %.2f GB of index files, exist-k-mer length %d) indexed here by dsb_index_build in %.1f s" % (
             build_info["bases"] / 1e6, build_info["sequences"], build_info["kmers_31"] / 1e6, build_info["index_files_bytes"] / 1e9, L.dsb_index_ek_len(idx.h), build_info["seconds"])
         out = {
