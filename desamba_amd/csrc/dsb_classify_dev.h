@@ -59,6 +59,8 @@
 #define TICK(w, k) do { if ((w).dbg) { uint64_t _t = DSB_CLOCK(); (w).tacc[k] += _t - (w).tlast; (w).tlast = _t; } } while (0)
 #define SUB0(w) do { if ((w).dbg) (w).tsub = DSB_CLOCK(); } while (0)
 #define SUB1(w, k) do { if ((w).dbg) (w).tacc[k] += DSB_CLOCK() - (w).tsub; } while (0)
+#define TX0(w, v) uint64_t v = (w).dbg ? DSB_CLOCK() : 0
+#define TX1(w, k, v) do { if ((w).dbg) (w).tx[k] += DSB_CLOCK() - (v); } while (0)
 #define MARK(w, code) do { if ((w).dbg && (w).lane == 0) { (w).dbg[0] = (code); (w).dbg[1] = (w).steps; } } while (0)
 #define DSB_WTAB_SLOTS 3072u     /* 12 KB of LDS: <= 2048 window positions, load factor <= 0.67 */
 #define DSB_WTAB_MAXQ 2048u
@@ -222,7 +224,7 @@ struct WCtx {
 	int status; int max_read_l;
 	int stage; int boosted; uint32_t sp_gen;   // generation of the visited-row sets (monotonic within a launch)
 	Cnt k;                     // work counters (LDS)
-	uint32_t steps, lsteps; volatile uint32_t *dbg; uint64_t tacc[14], tlast, tsub;   // optional host-visible progress words (DSB_DEBUG)
+	uint32_t steps, lsteps; volatile uint32_t *dbg; uint64_t tacc[14], tlast, tsub, tx[10];   // optional host-visible progress words (DSB_DEBUG)
             // loop-iteration budget: every unbounded loop charges it and bails when exhausted
 	SDir sd[2];
 };
@@ -1497,7 +1499,17 @@ DN void wtab_build(lds_u32 *tab, int lane, P8 q_str, uint32_t q_bg, uint32_t n_q
 DN void wtab_build_pk(lds_u32 *tab, int lane, const uint64_t *P, uint32_t n_words, uint32_t q_bg, uint32_t n_q)
 {
 	const uint32_t slots = wtab_size(n_q);
+#ifdef DSB_HOST_EMU
 	for (uint32_t i = lane; i < slots; i += DSB_WAVE) tab[i] = DSB_WTAB_EMPTY;
+#else
+	{	// (the table is 16-byte aligned and its size a multiple of four words)
+		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+		const u32x4 e4 = {DSB_WTAB_EMPTY, DSB_WTAB_EMPTY, DSB_WTAB_EMPTY, DSB_WTAB_EMPTY};
+		const uint32_t s4 = slots & ~3u;
+		for (uint32_t i = 4 * lane; i < s4; i += 4 * DSB_WAVE) *(__attribute__((address_space(3))) u32x4 *)(tab + i) = e4;
+		if ((uint32_t)lane < slots - s4) tab[s4 + lane] = DSB_WTAB_EMPTY;
+	}
+#endif
 	const uint32_t C = (n_q + DSB_WAVE - 1) / DSB_WAVE;                 // <= 32 positions per lane (n_q <= DSB_WTAB_MAXQ)
 	const uint32_t r0 = (uint32_t)lane * C, r1 = MINV(n_q, r0 + C);
 	uint64_t W0 = 0, W1 = 0, W2 = 0; uint32_t wi = 0;
@@ -1506,25 +1518,40 @@ DN void wtab_build_pk(lds_u32 *tab, int lane, const uint64_t *P, uint32_t n_word
 		W0 = DSB_G64(P, wi); W1 = wi + 1 < n_words ? DSB_G64(P, wi + 1) : 0; W2 = wi + 2 < n_words ? DSB_G64(P, wi + 2) : 0;
 	}
 	wave_sync();
-	for (uint32_t r = r0; r < r1; r++) {
-		uint32_t rel = q_bg + r - (wi << 5);                                  // < 32 + 32 with 64 lanes: the 9-mer ends before base 96
-		if (rel >= 64) {                                                      // (narrower groups -- the 1-lane host emulation -- move on word by word)
-			wi += 2; rel -= 64; W0 = W2; W1 = wi + 1 < n_words ? DSB_G64(P, wi + 1) : 0; W2 = wi + 2 < n_words ? DSB_G64(P, wi + 2) : 0;
+	// four inserts of a lane at a time: their compare-and-swaps are issued together (an insert is a chain of LDS round trips)
+	for (uint32_t rb = r0; rb < r1; rb += 4) {
+		uint32_t e[4], sl[4]; bool pend[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			const uint32_t r = rb + (uint32_t)u; pend[u] = r < r1; e[u] = 0; sl[u] = 0;
+			if (!pend[u]) continue;
+			uint32_t rel = q_bg + r - (wi << 5);                              // < 32 + 32 with 64 lanes: the 9-mer ends before base 96
+			if (rel >= 64) {                                                  // (narrower groups -- the 1-lane host emulation -- move on word by word)
+				wi += 2; rel -= 64; W0 = W2; W1 = wi + 1 < n_words ? DSB_G64(P, wi + 1) : 0; W2 = wi + 2 < n_words ? DSB_G64(P, wi + 2) : 0;
+			}
+			const uint32_t sh = (rel & 31u) * 2;
+			const uint64_t a = rel < 32 ? W0 : W1, b = rel < 32 ? W1 : W2;
+			const uint64_t hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
+			const uint32_t k = (uint32_t)(hi >> 46);
+			e[u] = (k << 12) | r; sl[u] = wtab_slot(k, slots);
 		}
-		const uint32_t sh = (rel & 31u) * 2;
-		const uint64_t a = rel < 32 ? W0 : W1, b = rel < 32 ? W1 : W2;
-		const uint64_t hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
-		const uint32_t k = (uint32_t)(hi >> 46);
-		uint32_t e = (k << 12) | r, sl = wtab_slot(k, slots);
-		for (;;) {
+		while (pend[0] | pend[1] | pend[2] | pend[3]) {
+			uint32_t old[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				old[u] = DSB_WTAB_EMPTY;
+				if (!pend[u]) continue;
 #ifdef DSB_HOST_EMU
-			uint32_t old = tab[sl]; if (old == DSB_WTAB_EMPTY) tab[sl] = e;
+				old[u] = tab[sl[u]]; if (old[u] == DSB_WTAB_EMPTY) tab[sl[u]] = e[u];
 #else
-			uint32_t old = DSB_WTAB_EMPTY;
-			__hip_atomic_compare_exchange_strong(tab + sl, &old, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				__hip_atomic_compare_exchange_strong(tab + sl[u], &old[u], e[u], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-			if (old == DSB_WTAB_EMPTY) break;
-			sl = sl + 1 == slots ? 0 : sl + 1;
+			}
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				if (!pend[u]) continue;
+				if (old[u] == DSB_WTAB_EMPTY) pend[u] = false; else sl[u] = sl[u] + 1 == slots ? 0 : sl[u] + 1;
+			}
 		}
 	}
 	wave_sync();
@@ -1717,9 +1744,14 @@ DV uint32_t sdp_match_p(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, P
 	if (a.n_q > DSB_WTAB_MAXQ) { w.status |= DSB_ST_SMS_OVF; return n_sms; }     // cannot happen: windows are <= 2001 wide
 	uint32_t t_kmer_num = t_len - 9 + 1;
 	if (a.n_q == 0 || t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return n_sms;
+	TX0(w, t_b);
 	if (qpk) wtab_build_pk((lds_u32 *)w.wtab, w.lane, qpk, (w.L + 31) / 32 + 1, q_bg, a.n_q);
 	else wtab_build<P8>((lds_u32 *)w.wtab, w.lane, q_base + ((int32_t)q_bg - q_lo), 0u, a.n_q);
-	return isForward ? sdp_match_t<true, P8>(w, a, n_sms) : sdp_match_t<false, P8>(w, a, n_sms);
+	TX1(w, 0, t_b);
+	TX0(w, t_p);
+	const uint32_t rv = isForward ? sdp_match_t<true, P8>(w, a, n_sms) : sdp_match_t<false, P8>(w, a, n_sms);
+	TX1(w, 1, t_p);
+	return rv;
 }
 // windows in global memory (q_str = the read strand) ...
 DN uint32_t sdp_match_n(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len,
@@ -1906,21 +1938,28 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 	const int32_t n0 = (int32_t)b.n0;
 	// predecessors are fetched one iteration ahead (4 x 64 nodes in flight while the previous 4 x 64 are judged)
 	DsbSms nx[DSB_DP_UNROLL];
-#define DSB_FETCH_PREDS(dst, hi_)                                                                               \
+#define DSB_FETCH_PREDS(dst, hi_, ng_)                                                                          \
 	_Pragma("unroll") for (int u = 0; u < DSB_DP_UNROLL; u++) {                                                 \
+		if (u >= (ng_)) break;                                                                                   \
 		int32_t pi = (hi_) - u * DSB_WAVE - w.lane;                                                              \
 		if (pi < 0) { dst[u].t_pos = 0; dst[u].q_pos = (MODE == 2) ? 0u : 0xfffffff0u; dst[u].len = 0; dst[u].score = 0; } \
 		else if (pi > n0 - DSB_RING) { uint4 r = ring_ld(w.ring, pi & (DSB_RING - 1)); dst[u].t_pos = r.x; dst[u].q_pos = r.y; dst[u].len = r.z; dst[u].score = r.w; } \
 		else dst[u] = w.sms[pi];                                                                                 \
 	}
-	if (n0 > 0) { DSB_FETCH_PREDS(nx, n0 - 1) }
-	for (int32_t hi = n0 - 1; hi >= 0; hi -= DSB_DP_UNROLL * DSB_WAVE) {
+	// The newest group of 64 predecessors goes first and alone: an extension leaves all but its last few dozen nodes more than
+	// 600 bases behind, so the distance cut of (nearly) every node of the batch lies in it and the pass ends there.  What is
+	// left (repeats: hundreds of predecessors within reach) goes on in chunks of DSB_DP_UNROLL groups, fetched one chunk ahead.
+	int ng = 1;
+	if (n0 > 0) { DSB_FETCH_PREDS(nx, n0 - 1, ng) }
+	for (int32_t hi = n0 - 1; hi >= 0;) {
 		// per predecessor (one per lane and unrolled group), shared by all nodes of the batch:
 		//   MODE 1: A = q_pos+len+8, B = t_pos+len+8, C = t_pos+600;  MODE 2: A = q_pos, B = t_pos, C = t_pos
 		//   D = q_pos - t_pos, S = score.  Lanes past the start of the list carry values that fail the first test.
 		uint32_t A[DSB_DP_UNROLL], B[DSB_DP_UNROLL], C[DSB_DP_UNROLL], D[DSB_DP_UNROLL], S[DSB_DP_UNROLL]; bool wrapped[DSB_DP_UNROLL];
 #pragma unroll
 		for (int u = 0; u < DSB_DP_UNROLL; u++) {
+			wrapped[u] = false; A[u] = B[u] = C[u] = D[u] = S[u] = 0;
+			if (u >= ng) continue;
 			int32_t pi = hi - u * DSB_WAVE - w.lane;
 			DsbSms ps = nx[u];
 			if (MODE == 2) { A[u] = ps.q_pos; B[u] = ps.t_pos; C[u] = ps.t_pos; }
@@ -1929,13 +1968,14 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 			if (pi < 0 && MODE != 2) A[u] = 0x7fffffffu;        // fails the first test (signed distance past the node start)
 			wrapped[u] = dsb_ballot64((int)(A[u] | B[u] | C[u]) < 0) != 0;
 		}
-		if (hi - DSB_DP_UNROLL * DSB_WAVE >= 0) { DSB_FETCH_PREDS(nx, hi - DSB_DP_UNROLL * DSB_WAVE) }
+		const int32_t hi_next = hi - ng * DSB_WAVE;
+		if (ng == DSB_DP_UNROLL && hi_next >= 0) { DSB_FETCH_PREDS(nx, hi_next, DSB_DP_UNROLL) }
 		// Chunks without wrapped coordinates (all but a few) are first judged straight through, with no test for the
 		// distance cut between the groups; only a node that meets its cut in this pass is judged again in order.
 		// (The newest chunk of a batch holds the distance cut of nearly every node -- an extension has left all but its last
 		// few dozen nodes more than 600 bases behind -- so it goes straight to the ordered pass; the straight pass pays
 		// from the second chunk on, i.e. in repeats, where hundreds of predecessors lie within reach.)
-		const bool plain = wnm == 0 && !(wrapped[0] | wrapped[1] | wrapped[2] | wrapped[3]) && hi != n0 - 1;
+		const bool plain = wnm == 0 && !(wrapped[0] | wrapped[1] | wrapped[2] | wrapped[3]) && ng == DSB_DP_UNROLL;
 		uint32_t redo = ~stopm & ((1u << DSB_DPB) - 1u);
 		if (plain) {
 #pragma unroll
@@ -1957,13 +1997,14 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 				if (dsb_ballot64(anyb) == 0) { if (tb > best[j]) best[j] = tb; redo &= ~(1u << j); }
 			}
 		}
-		preds += DSB_DP_UNROLL * DSB_WAVE * (uint32_t)__builtin_popcount(~stopm & ((1u << DSB_DPB) - 1u));
+		preds += (uint32_t)ng * DSB_WAVE * (uint32_t)__builtin_popcount(~stopm & ((1u << DSB_DPB) - 1u));
 		if (redo)
 #pragma unroll
 		for (int j = 0; j < DSB_DPB; j++) {
 			if (!((redo >> j) & 1u)) continue;
 #pragma unroll
 			for (int u = 0; u < DSB_DP_UNROLL; u++) {
+				if (u >= ng) break;
 				if ((stopm >> j) & 1u) break;
 				// sdp_judge with the common subexpressions folded: the limits are the node position + 6, so with
 				// oq/ot = how far the predecessor's end runs past the node's start, skip <=> max(oq, ot) > 6 and the
@@ -1996,6 +2037,8 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 			}
 		}
 		if (stopm == (1u << DSB_DPB) - 1u) break;
+		if (ng != DSB_DP_UNROLL && hi_next >= 0) { DSB_FETCH_PREDS(nx, hi_next, DSB_DP_UNROLL) }       // (nothing is fetched ahead of the first group: it usually is the last)
+		hi = hi_next; ng = DSB_DP_UNROLL;
 	}
 	w.dp_preds += preds;
 	DSB_HEAVY_CHECK(w);
@@ -2130,11 +2173,22 @@ DN void sdp_batch_old_mw(DsbMw *mw, uint4 *ring, uint32_t *red, const int lane, 
 #endif
 // best predecessor score of node `cur` (right/left extension), through the batch
 template <int MODE>
-DV int sdp_best_pred_b(WCtx &w, DpBatch &b, const DsbSms &cs, int32_t cur)
+DV int sdp_best_pred_b(WCtx &w, DpBatch &b, const DsbSms &cs, int32_t cur, const NodeBlock &nb)
 {
 	if ((uint32_t)cur < b.n0 || (uint32_t)cur >= b.n0 + b.K) {
 		b.n0 = (uint32_t)cur; b.K = MINV((uint32_t)DSB_DPB, w.n_sms - (uint32_t)cur);
-		for (uint32_t j = 0; j < b.K; j++) { b.nd[j] = w.sms[cur + j]; b.nd[j].score = 0; }
+		for (uint32_t j = 0; j < b.K; j++) {
+#if DSB_GROUP == 64 && !defined(DSB_HOST_EMU)
+			// the block of 64 nodes the caller holds in its lanes (node_get) has most of them: no load
+			const uint32_t idx = (uint32_t)cur + j;
+			if (idx >= nb.base && idx < nb.base + nb.valid) {
+				const int src = (int)(idx - nb.base);
+				b.nd[j].t_pos = dsb_shfl(nb.mine.t_pos, src); b.nd[j].q_pos = dsb_shfl(nb.mine.q_pos, src); b.nd[j].len = dsb_shfl(nb.mine.len, src); b.nd[j].score = 0;
+				continue;
+			}
+#endif
+			b.nd[j] = w.sms[cur + j]; b.nd[j].score = 0;
+		}
 #ifndef DSB_HOST_EMU
 		if (w.mw && b.n0 >= DSB_MW_MIN_PREDS) {
 			// several wavefronts on this read: wake the helpers for the pass over the old predecessors
@@ -2148,16 +2202,25 @@ DV int sdp_best_pred_b(WCtx &w, DpBatch &b, const DsbSms &cs, int32_t cur)
 			for (uint32_t j = 0; j < DSB_DPB; j++) { int m = -2147483647 - 1; for (int u = 0; u < w.n_waves; u++) m = MAXV(m, mw->best[u][j]); b.old_best[j] = j < b.K ? m : 0; }
 		} else
 #endif
-		sdp_batch_old<MODE>(w, b);
+		{ TX0(w, t_o); sdp_batch_old<MODE>(w, b); TX1(w, 2, t_o); if (w.dbg) w.tx[6] += 1; }
 	}
 	int best = (int)cs.len; bool cut = false;
 	uint32_t lim_q, lim_t; sdp_limits<MODE>(cs, lim_q, lim_t);
-	for (int32_t pi = cur - 1; pi >= (int32_t)b.n0; pi--) {      // in-batch predecessors, newest first
-		uint4 r = ring_ld(w.ring, pi & (DSB_RING - 1)); DsbSms ps; ps.t_pos = r.x; ps.q_pos = r.y; ps.len = r.z; ps.score = r.w;
-		bool skip, brk; int ns;
-		sdp_judge<MODE>(cs, ps, lim_q, lim_t, skip, brk, ns);
-		if (!skip && brk) { cut = true; break; }
-		if (!skip && ns > best) best = ns;
+	// in-batch predecessors (at most DSB_DPB - 1, all in the ring), newest first: one per lane; the newest that meets the
+	// distance cut ends the scan -- lanes beyond it do not count
+	const int32_t m = cur - (int32_t)b.n0;
+	for (int32_t base = 0; base < m && !cut; base += DSB_WAVE) {
+		const int32_t l = base + w.lane; const bool valid = l < m;
+		bool skip = true, brk = false; int ns = 0;
+		if (valid) {
+			uint4 r = ring_ld(w.ring, (uint32_t)(cur - 1 - l) & (DSB_RING - 1)); DsbSms ps; ps.t_pos = r.x; ps.q_pos = r.y; ps.len = r.z; ps.score = r.w;
+			sdp_judge<MODE>(cs, ps, lim_q, lim_t, skip, brk, ns);
+		}
+		const int fb = grp_first(w.red, w.lane, valid && !skip && brk);
+		const int mine = (valid && !skip && !brk && w.lane < fb) ? ns : (-2147483647 - 1);
+		const int mx = grp_max_i(w.red, w.lane, mine);
+		if (mx > best) best = mx;
+		if (fb < DSB_WAVE) cut = true;
 	}
 	int ob = b.old_best[cur - (int32_t)b.n0];
 	if (!cut && ob > best) best = ob;
@@ -2514,8 +2577,10 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 				max_search_ref = l_read - c_h->q_ed + 60;
 			} else max_search_ref = t_length - c_t_offset;
 			max_search_ref = MINV(600u, max_search_ref);
+			TX0(w, t_r);
 			get_ref_wave(x->refbin, x->ref_bases, w.lane, ref, c_t_offset + t_offset_global, max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50);
 			wave_sync();
+			TX1(w, 3, t_r); if (w.dbg) w.tx[7] += 1;
 			int search_q_ed = (int)best_q + 1000;
 			search_q_ed = MINV((uint32_t)search_q_ed, l_read);
 			int search_q_st = MAXV((uint32_t)(search_q_ed - 2000), c_h->q_st - 8);
@@ -2528,12 +2593,17 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 			if (node_get(w, nb, current_sms).t_pos > best_t + 1000) break;
 		}
 		DsbSms *c_sms = w.sms + current_sms;
+		TX0(w, t_g);
 		DsbSms cs = node_get(w, nb, current_sms); current_sms++;
+		TX1(w, 5, t_g);
 		SUB0(w);
-		int max_score = sdp_best_pred_b<1>(w, db, cs, (int32_t)current_sms - 1);
+		int max_score = sdp_best_pred_b<1>(w, db, cs, (int32_t)current_sms - 1, nb);
 		SUB1(w, 11);
+		if (w.dbg) w.tx[8] += 1;
+		TX0(w, t_s);
 		c_sms->score = max_score;
 		ring_put(w, current_sms - 1, cs.t_pos, cs.q_pos, cs.len, (uint32_t)max_score);
+		TX1(w, 4, t_s);
 		SUB0(w);
 		bool comb = (int)cs.len >= 8 && combine_chain(c_st, chain_ID, sc_hash, cs.t_pos - cs.q_pos, false, cs.q_pos, &combined) == true;
 		SUB1(w, 12);
@@ -2611,7 +2681,7 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 		DsbSms *c_sms = w.sms + current_sms;
 		DsbSms cs = node_get(w, nb, current_sms); current_sms++;
 		SUB0(w);
-		int max_score = sdp_best_pred_b<2>(w, db, cs, (int32_t)current_sms - 1);
+		int max_score = sdp_best_pred_b<2>(w, db, cs, (int32_t)current_sms - 1, nb);
 		SUB1(w, 11);
 		c_sms->score = max_score;
 		ring_put(w, current_sms - 1, cs.t_pos, cs.q_pos, cs.len, (uint32_t)max_score);

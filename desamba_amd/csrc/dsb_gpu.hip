@@ -433,6 +433,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	w.ring = lds_ring; w.red = lds_red; w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1;                                                                               \
 	w.x = (NS::DsbXP)&sx; w.lane = lane; w.dbg = dbg ? dbg + 4 * slot_id : nullptr;                                             \
 	for (int i = 0; i < 14; i++) w.tacc[i] = 0;                                                                         \
+	for (int i = 0; i < 10; i++) w.tx[i] = 0;                                                                           \
 	w.seeds = (DsbSeed *)(slot + ar.off_seeds);                                                                         \
 	w.anc = (DsbAnchor *)(slot + ar.off_anc); w.anc_tmp = (DsbAnchor *)(slot + ar.off_anc_tmp);                         \
 	w.hit = (DsbChain *)(slot + ar.off_hit); w.hit_tmp = (DsbChain *)(slot + ar.off_hit_tmp);                           \
@@ -468,7 +469,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 		__syncthreads();                                                                                                \
 		if (k >= n_items) {   /* every group reaches this: the grid always drains */                                   \
 			if (lane < 4 && lds_cnt[lane]) atomicAdd(work_cnt + lane, (unsigned long long)lds_cnt[lane]);               \
-			if (w.dbg && lane == 0) { w.dbg[0] = 999; for (int i = 0; i < 14; i++) dbg[4 * 65536 + 14 * slot_id + i] += (uint32_t)(w.tacc[i] / 100); } \
+			if (w.dbg && lane == 0) { w.dbg[0] = 999; for (int i = 0; i < 14; i++) dbg[4 * 65536 + 14 * slot_id + i] += (uint32_t)(w.tacc[i] / 100); for (int i = 0; i < 10; i++) dbg[8 * 65536 + 10 * slot_id + i] += (uint32_t)(i < 6 ? w.tx[i] / 100 : w.tx[i]); } \
 			break;                                                                                                      \
 		}                                                                                                               \
 		uint32_t g_nanc = 0, g_ovf = 0;                                                                                 \
@@ -566,6 +567,7 @@ __global__ void __launch_bounds__(64 * MWW, DSB_WAVES_PER_EU) k_classify_heavy(D
 		w.ring = lds_ring; w.red = lds_red; w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1;
 		w.x = (dsb_g64::DsbXP)&sx; w.lane = lane; w.dbg = nullptr;
 		for (int i = 0; i < 14; i++) w.tacc[i] = 0;
+		for (int i = 0; i < 10; i++) w.tx[i] = 0;
 		w.seeds = (DsbSeed *)(slot + ar.off_seeds);
 		w.anc = (DsbAnchor *)(slot + ar.off_anc); w.anc_tmp = (DsbAnchor *)(slot + ar.off_anc_tmp);
 		w.hit = (DsbChain *)(slot + ar.off_hit); w.hit_tmp = (DsbChain *)(slot + ar.off_hit_tmp);
@@ -1465,6 +1467,9 @@ static int batch_run_locked(dsb_ctx *c)
 		double sub[4] = {0};
 		for (unsigned sI = 0; sI < sl; sI++) { for (int i = 0; i < 10; i++) { tot[i] += c->dbg_host[4 * 65536 + 14 * sI + i]; all += c->dbg_host[4 * 65536 + 14 * sI + i]; } for (int i = 0; i < 4; i++) sub[i] += c->dbg_host[4 * 65536 + 14 * sI + 10 + i]; }
 		fprintf(stderr, "[dsb] inside sdp_right/left (ms): sdp_match %.1f  dp %.1f  combine %.1f | fast_classify commit phase %.1f\n", sub[0] / 1e3, sub[1] / 1e3, sub[2] / 1e3, sub[3] / 1e3);
+		{ double tx[10] = {0}; for (unsigned sI = 0; sI < sl; sI++) for (int i = 0; i < 10; i++) tx[i] += c->dbg_host[8 * 65536 + 10 * sI + i];
+		  fprintf(stderr, "[dsb] fine (ms): table build %.1f  probe %.1f  dp old pass %.1f  window fetch(right) %.1f  score store(right) %.1f  node_get(right) %.1f | counts: dp batches %.0f  windows(right) %.0f  nodes(right) %.0f\n",
+		          tx[0] / 1e3, tx[1] / 1e3, tx[2] / 1e3, tx[3] / 1e3, tx[4] / 1e3, tx[5] / 1e3, tx[6], tx[7], tx[8]); }
 		{	// stage split of the slowest read of the batch (as it ran, i.e. under load)
 			size_t worst = 0; uint64_t wsum = 0;
 			for (size_t r = 0; r < n && r < 65536; r++) { uint64_t sm = 0; for (int i = 0; i < 10; i++) sm += c->dbg_host[16 * 65536 + 14 * r + i]; if (sm > wsum) { wsum = sm; worst = r; } }
