@@ -194,6 +194,16 @@ struct DsbMw {
 	int32_t best[DSB_MW_MAXW][8];
 };
 
+#define DSB_DPB 8
+struct DpBatch { uint32_t n0, K; int old_best[DSB_DPB]; uint32_t nd_t[DSB_DPB], nd_q[DSB_DPB], nd_l[DSB_DPB]; };
+// (one per wavefront, in LDS: it is read and written per node of the extension loops, and as a local of a function that hands
+// it to non-inlined callees it would live in scratch memory, a global-memory round trip per access)
+#ifdef DSB_HOST_EMU
+typedef DpBatch DpBatchL;
+#else
+typedef __attribute__((address_space(3))) DpBatch DpBatchL;
+#endif
+
 struct SDir { DsbSeed *seed_v; uint32_t l_seed_v; uint8_t *bin_read; const uint64_t *bits; uint32_t direction, total_score; };
 
 struct WCtx {
@@ -220,6 +230,7 @@ struct WCtx {
 	uint32_t *round_info;      // per top island of fast_classify: lane | start<<6 | n<<16 | flag<<26 | ovf<<27
 	uint32_t dp_preds;         // predecessors scanned by the sparse DP of this read (heavy-read detection)
 	uint32_t heavy_limit;      // single-wavefront launches: give the read up for k_classify_heavy beyond this many (0: never)
+	DpBatchL *dpb;             // LDS: the batch of extension nodes being scored (sdp_best_pred_b)
 	uint4 *ring;               // LDS: the most recent DSB_RING sparse-DP nodes of sdp_right/left ({t_pos,q_pos,len,score})
 	int status; int max_read_l;
 	int stage; int boosted; uint32_t sp_gen;   // generation of the visited-row sets (monotonic within a launch)
@@ -1518,40 +1529,25 @@ DN void wtab_build_pk(lds_u32 *tab, int lane, const uint64_t *P, uint32_t n_word
 		W0 = DSB_G64(P, wi); W1 = wi + 1 < n_words ? DSB_G64(P, wi + 1) : 0; W2 = wi + 2 < n_words ? DSB_G64(P, wi + 2) : 0;
 	}
 	wave_sync();
-	// four inserts of a lane at a time: their compare-and-swaps are issued together (an insert is a chain of LDS round trips)
-	for (uint32_t rb = r0; rb < r1; rb += 4) {
-		uint32_t e[4], sl[4]; bool pend[4];
-#pragma unroll
-		for (int u = 0; u < 4; u++) {
-			const uint32_t r = rb + (uint32_t)u; pend[u] = r < r1; e[u] = 0; sl[u] = 0;
-			if (!pend[u]) continue;
-			uint32_t rel = q_bg + r - (wi << 5);                              // < 32 + 32 with 64 lanes: the 9-mer ends before base 96
-			if (rel >= 64) {                                                  // (narrower groups -- the 1-lane host emulation -- move on word by word)
-				wi += 2; rel -= 64; W0 = W2; W1 = wi + 1 < n_words ? DSB_G64(P, wi + 1) : 0; W2 = wi + 2 < n_words ? DSB_G64(P, wi + 2) : 0;
-			}
-			const uint32_t sh = (rel & 31u) * 2;
-			const uint64_t a = rel < 32 ? W0 : W1, b = rel < 32 ? W1 : W2;
-			const uint64_t hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
-			const uint32_t k = (uint32_t)(hi >> 46);
-			e[u] = (k << 12) | r; sl[u] = wtab_slot(k, slots);
+	for (uint32_t r = r0; r < r1; r++) {
+		uint32_t rel = q_bg + r - (wi << 5);                                  // < 32 + 32 with 64 lanes: the 9-mer ends before base 96
+		if (rel >= 64) {                                                      // (narrower groups -- the 1-lane host emulation -- move on word by word)
+			wi += 2; rel -= 64; W0 = W2; W1 = wi + 1 < n_words ? DSB_G64(P, wi + 1) : 0; W2 = wi + 2 < n_words ? DSB_G64(P, wi + 2) : 0;
 		}
-		while (pend[0] | pend[1] | pend[2] | pend[3]) {
-			uint32_t old[4];
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				old[u] = DSB_WTAB_EMPTY;
-				if (!pend[u]) continue;
+		const uint32_t sh = (rel & 31u) * 2;
+		const uint64_t a = rel < 32 ? W0 : W1, b = rel < 32 ? W1 : W2;
+		const uint64_t hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
+		const uint32_t k = (uint32_t)(hi >> 46);
+		uint32_t e = (k << 12) | r, sl = wtab_slot(k, slots);
+		for (;;) {
 #ifdef DSB_HOST_EMU
-				old[u] = tab[sl[u]]; if (old[u] == DSB_WTAB_EMPTY) tab[sl[u]] = e[u];
+			uint32_t old = tab[sl]; if (old == DSB_WTAB_EMPTY) tab[sl] = e;
 #else
-				__hip_atomic_compare_exchange_strong(tab + sl[u], &old[u], e[u], __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			uint32_t old = DSB_WTAB_EMPTY;
+			__hip_atomic_compare_exchange_strong(tab + sl, &old, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-			}
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				if (!pend[u]) continue;
-				if (old[u] == DSB_WTAB_EMPTY) pend[u] = false; else sl[u] = sl[u] + 1 == slots ? 0 : sl[u] + 1;
-			}
+			if (old == DSB_WTAB_EMPTY) break;
+			sl = sl + 1 == slots ? 0 : sl + 1;
 		}
 	}
 	wave_sync();
@@ -1877,8 +1873,6 @@ DV int sdp_best_pred(WCtx &w, const DsbSms &cs, int32_t cur)
 // once their scores are final.  The reference scans newest first and stops at the first predecessor that
 // meets the distance cut; in-batch predecessors are newer than all old ones, so a cut found among them
 // discards the old-pass result for that node.  Same maxima, 1/DSB_DPB of the memory traffic.
-#define DSB_DPB 8
-struct DpBatch { uint32_t n0, K; int old_best[DSB_DPB]; DsbSms nd[DSB_DPB]; };
 
 template <int MODE>
 DV void sdp_limits(const DsbSms &cs, uint32_t &lim_q, uint32_t &lim_t)
@@ -1918,7 +1912,7 @@ DV void sdp_judge(const DsbSms &cs, const DsbSms &ps, uint32_t lim_q, uint32_t l
 }
 
 template <int MODE>
-DN void sdp_batch_old(WCtx &w, DpBatch &b)
+DN void sdp_batch_old(WCtx &w, DpBatchL &b)
 {
 	// per node of the batch (group-uniform, kept in scalar registers): limits and the terms of sdp_judge that do
 	// not depend on the predecessor
@@ -1926,10 +1920,11 @@ DN void sdp_batch_old(WCtx &w, DpBatch &b)
 	uint32_t stopm = 0, preds = 0, wnm = 0;
 #pragma unroll
 	for (int j = 0; j < DSB_DPB; j++) {
-		uint32_t q_, t_; sdp_limits<MODE>(b.nd[j], q_, t_);
+		DsbSms ndj; ndj.t_pos = b.nd_t[j]; ndj.q_pos = b.nd_q[j]; ndj.len = b.nd_l[j]; ndj.score = 0;
+		uint32_t q_, t_; sdp_limits<MODE>(ndj, q_, t_);
 		lq[j] = DSB_RFL(q_); lt[j] = DSB_RFL(t_);
-		dl[j] = lq[j] - lt[j]; nl[j] = DSB_RFL(b.nd[j].len);
-		if (MODE == 2) { nq[j] = lq[j] + 6; nt[j] = lt[j] + 6; } else { nq[j] = DSB_RFL(b.nd[j].q_pos); nt[j] = DSB_RFL(b.nd[j].t_pos); }
+		dl[j] = lq[j] - lt[j]; nl[j] = DSB_RFL(ndj.len);
+		if (MODE == 2) { nq[j] = lq[j] + 6; nt[j] = lt[j] + 6; } else { nq[j] = DSB_RFL(ndj.q_pos); nt[j] = DSB_RFL(ndj.t_pos); }
 		best[j] = -2147483647 - 1;
 		if ((uint32_t)j >= b.K) stopm |= 1u << j;
 		if ((int)(lq[j] | lt[j] | nq[j] | nt[j] | (lt[j] + 600)) < 0) wnm |= 1u << j;     // wrapped (negative) node coordinates
@@ -2173,7 +2168,7 @@ DN void sdp_batch_old_mw(DsbMw *mw, uint4 *ring, uint32_t *red, const int lane, 
 #endif
 // best predecessor score of node `cur` (right/left extension), through the batch
 template <int MODE>
-DV int sdp_best_pred_b(WCtx &w, DpBatch &b, const DsbSms &cs, int32_t cur, const NodeBlock &nb)
+DV int sdp_best_pred_b(WCtx &w, DpBatchL &b, const DsbSms &cs, int32_t cur, const NodeBlock &nb)
 {
 	if ((uint32_t)cur < b.n0 || (uint32_t)cur >= b.n0 + b.K) {
 		b.n0 = (uint32_t)cur; b.K = MINV((uint32_t)DSB_DPB, w.n_sms - (uint32_t)cur);
@@ -2183,17 +2178,18 @@ DV int sdp_best_pred_b(WCtx &w, DpBatch &b, const DsbSms &cs, int32_t cur, const
 			const uint32_t idx = (uint32_t)cur + j;
 			if (idx >= nb.base && idx < nb.base + nb.valid) {
 				const int src = (int)(idx - nb.base);
-				b.nd[j].t_pos = dsb_shfl(nb.mine.t_pos, src); b.nd[j].q_pos = dsb_shfl(nb.mine.q_pos, src); b.nd[j].len = dsb_shfl(nb.mine.len, src); b.nd[j].score = 0;
+				b.nd_t[j] = dsb_shfl(nb.mine.t_pos, src); b.nd_q[j] = dsb_shfl(nb.mine.q_pos, src); b.nd_l[j] = dsb_shfl(nb.mine.len, src);
 				continue;
 			}
 #endif
-			b.nd[j] = w.sms[cur + j]; b.nd[j].score = 0;
+			const DsbSms g_ = w.sms[cur + j];
+			b.nd_t[j] = g_.t_pos; b.nd_q[j] = g_.q_pos; b.nd_l[j] = g_.len;
 		}
 #ifndef DSB_HOST_EMU
 		if (w.mw && b.n0 >= DSB_MW_MIN_PREDS) {
 			// several wavefronts on this read: wake the helpers for the pass over the old predecessors
 			DsbMw *mw = w.mw;
-			if (w.lane < DSB_DPB) { const DsbSms nd = (uint32_t)w.lane < b.K ? b.nd[w.lane] : b.nd[0]; mw->nd_t[w.lane] = nd.t_pos; mw->nd_q[w.lane] = nd.q_pos; mw->nd_l[w.lane] = nd.len; }
+			if (w.lane < DSB_DPB) { const int sj = (uint32_t)w.lane < b.K ? w.lane : 0; mw->nd_t[w.lane] = b.nd_t[sj]; mw->nd_q[w.lane] = b.nd_q[sj]; mw->nd_l[w.lane] = b.nd_l[sj]; }
 			if (w.lane == 0) { mw->cmd = (uint32_t)MODE; mw->n0 = b.n0; mw->K = b.K; mw->sms = w.sms; }
 			__syncthreads();
 			uint32_t preds = 0;
@@ -2559,7 +2555,7 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 	ring_put(w, 0, p->t_pos, p->q_pos, p->len, p->score);
 	uint32_t best_t = c_h->t_ed, best_q = c_h->q_ed, best_len = (uint32_t)(1 - 9);     // fields of node max_sms_id
 	NodeBlock nb; nb.base = 0; nb.valid = 0;
-	DpBatch db; db.n0 = 0; db.K = 0;
+	DpBatchL &db = *w.dpb; db.n0 = 0; db.K = 0;
 	uint32_t current_sms = 1;
 	uint64_t t_offset_global = x->refinfo[c_h->ref_ID].seq_offset, t_length = x->refinfo[c_h->ref_ID].seq_l;
 	uint32_t c_t_offset = c_h->t_ed - 3;
@@ -2644,7 +2640,7 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 	ring_put(w, 0, p->t_pos, p->q_pos, 0, p->score);                       // a[0].len is never read by the left DP
 	uint32_t best_t = c_h->t_st, best_q = c_h->q_st;                       // fields of node max_sms_id
 	NodeBlock nb; nb.base = 0; nb.valid = 0;
-	DpBatch db; db.n0 = 0; db.K = 0;
+	DpBatchL &db = *w.dpb; db.n0 = 0; db.K = 0;
 	uint32_t current_sms = 1;
 	uint64_t t_offset_global = x->refinfo[c_h->ref_ID].seq_offset;
 	uint32_t c_t_offset = c_h->t_st + 3;

@@ -426,11 +426,12 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	__shared__ uint32_t lds_red[THREADS / 64 + 1];                                                                      \
 	__shared__ unsigned int s_word;                                                                                     \
 	__shared__ uint32_t lds_cnt[4];                                                                                     \
+	__shared__ dsb_g64::DpBatch lds_dpb;                                                                                \
 	if (lane < 4) lds_cnt[lane] = 0;                                                                                    \
 	if (lane == 0) sx = x;                                                                                              \
 	__syncthreads();                                                                                                    \
 	NS::WCtx w;                                                                                                         \
-	w.ring = lds_ring; w.red = lds_red; w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1;                                                                               \
+	w.ring = lds_ring; w.dpb = (NS::DpBatchL *)&lds_dpb; w.red = lds_red; w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1;                                                                               \
 	w.x = (NS::DsbXP)&sx; w.lane = lane; w.dbg = dbg ? dbg + 4 * slot_id : nullptr;                                             \
 	for (int i = 0; i < 14; i++) w.tacc[i] = 0;                                                                         \
 	for (int i = 0; i < 10; i++) w.tx[i] = 0;                                                                           \
@@ -558,13 +559,14 @@ __global__ void __launch_bounds__(64 * MWW, DSB_WAVES_PER_EU) k_classify_heavy(D
 	__shared__ uint32_t lds_red[MWW + 1];
 	__shared__ unsigned int s_word;
 	__shared__ uint32_t lds_cnt[4];
+	__shared__ dsb_g64::DpBatch lds_dpb;
 	__shared__ dsb_g64::DsbMw mw;
 	if (threadIdx.x < 4) lds_cnt[threadIdx.x] = 0;
 	if (threadIdx.x == 0) { sx = x; mw.cmd = 0; }
 	__syncthreads();
 	dsb_g64::WCtx w;
 	if (wv == 0) {
-		w.ring = lds_ring; w.red = lds_red; w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1;
+		w.ring = lds_ring; w.dpb = (dsb_g64::DpBatchL *)&lds_dpb; w.red = lds_red; w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1;
 		w.x = (dsb_g64::DsbXP)&sx; w.lane = lane; w.dbg = nullptr;
 		for (int i = 0; i < 14; i++) w.tacc[i] = 0;
 		for (int i = 0; i < 10; i++) w.tx[i] = 0;

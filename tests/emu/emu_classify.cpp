@@ -66,7 +66,7 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	w.sc = (DsbScHash *)(s + off[7]); w.mem_slow = (DsbMem *)(s + off[8]); w.spset = (uint64_t *)(s + off[9]); w.score_v = (int *)(s + off[10]);
 	w.sortkey = (uint64_t *)(s + off[11]); w.sortidx = (uint32_t *)(s + off[12]);
 	w.win_mid = s + off[13]; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
-	static uint4 emu_ring[DSB_RING]; w.ring = emu_ring;
+	static uint4 emu_ring[DSB_RING]; w.ring = emu_ring; static DpBatch emu_dpb; w.dpb = &emu_dpb;
 	static uint32_t emu_red[4]; w.red = emu_red; w.round_info = (uint32_t *)(s + off[17]);
 	w.lane_anc = (DsbAnchor *)(s + off[14]); w.lane_spset = (uint64_t *)(s + off[15]); w.top_idx = (uint32_t *)(s + off[16]); w.anc_cap = DSB_ANC_CAP;
 	w.heavy_limit = 0;
