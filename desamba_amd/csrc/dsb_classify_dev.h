@@ -49,7 +49,7 @@
 #define D_REVERSE 0u
 #define D_U64MAX 0xffffffffffffffffULL
 #define SPENT(w) (++(w).steps > (w).step_limit)        /* group-uniform code only */
-#define LSPENT(w) (++(w).lsteps > (w).step_limit)      /* per-thread code (fast_island, sdp_visit) */
+#define LSPENT(l) (++(l).lsteps > (l).step_limit)      /* per-lane code (fast_island): l is an LCtx */
 #ifdef DSB_HOST_EMU
 #define DSB_CLOCK() 0ULL
 #else
@@ -61,7 +61,7 @@
 #define SUB1(w, k) do { if ((w).dbg) (w).tacc[k] += DSB_CLOCK() - (w).tsub; } while (0)
 #define TX0(w, v) uint64_t v = (w).dbg ? DSB_CLOCK() : 0
 #define TX1(w, k, v) do { if ((w).dbg) (w).tx[k] += DSB_CLOCK() - (v); } while (0)
-#define MARK(w, code) do { if ((w).dbg && (w).lane == 0) { (w).dbg[0] = (code); (w).dbg[1] = (w).steps; } } while (0)
+#define MARK(w, code) do { if ((w).dbg && DSB_LANE == 0) { (w).dbg[0] = (code); (w).dbg[1] = (w).steps; } } while (0)
 #define DSB_WTAB_SLOTS 3072u     /* 12 KB of LDS: <= 2048 window positions, load factor <= 0.67 */
 #define DSB_WTAB_MAXQ 2048u
 #define DSB_WTAB_EMPTY 0xffffffffu
@@ -205,10 +205,17 @@ typedef __attribute__((address_space(3))) DpBatch DpBatchL;
 #endif
 
 struct SDir { DsbSeed *seed_v; uint32_t l_seed_v; uint8_t *bin_read; const uint64_t *bits; uint32_t direction, total_score; };
+// what one island walk needs of a strand (fast_island): by value, whether the strand record lies in LDS (the read of the
+// wavefront) or in a lane's own registers (fast_classify_lane: a read per lane)
+struct SDirV { DsbSeed *seed_v; uint8_t *bin_read; uint32_t direction; };
 
+// The context of the read a wavefront works on.  It lives in LDS (one per wavefront; WCtxL below): every field is
+// wave-uniform, the per-read logic reads and writes it from non-inlined functions all the time, and as a local of the kernel
+// handed on by reference it would live in scratch memory -- a global-memory round trip for every w.field (rounds 1-2:
+// 1.9 KB of scratch per lane, 63 % of the wave cycles waiting).  What differs from lane to lane while lanes walk islands of
+// their own (fast_classify, fast_classify_lane) is in LCtx.
 struct WCtx {
 	DsbXP x;
-	int lane;
 	uint8_t *bin; uint32_t L;
 	DsbSeed *seeds;
 	DsbMw *mw; int n_waves;    // k_classify_heavy: the workgroup's shared block and its number of wavefronts (null / 1 otherwise)
@@ -239,21 +246,47 @@ struct WCtx {
             // loop-iteration budget: every unbounded loop charges it and bails when exhausted
 	SDir sd[2];
 };
+#ifdef DSB_HOST_EMU
+#define DSB_LDS_AS
+#define DSB_LANE 0
+#else
+#define DSB_LDS_AS __attribute__((address_space(3)))
+#define DSB_LANE ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
+#endif
+typedef DSB_LDS_AS WCtx WCtxL;
+typedef DSB_LDS_AS SDir SDirL;
+DV void sdir_set(SDirL *d, DsbSeed *seed_v, uint32_t l_seed_v, uint8_t *bin_read, const uint64_t *bits, uint32_t direction, uint32_t total_score)
+{
+	d->seed_v = seed_v; d->l_seed_v = l_seed_v; d->bin_read = bin_read; d->bits = bits; d->direction = direction; d->total_score = total_score;
+}
+DV void sdir_swap(SDirL *a, SDirL *b)
+{
+	DsbSeed *sv = a->seed_v; const uint32_t n = a->l_seed_v; uint8_t *br = a->bin_read; const uint64_t *bi = a->bits; const uint32_t di = a->direction, ts = a->total_score;
+	sdir_set(a, b->seed_v, b->l_seed_v, b->bin_read, b->bits, b->direction, b->total_score);
+	sdir_set(b, sv, n, br, bi, di, ts);
+}
+#define WK(w) (Cnt{(w).k.c, (w).k.uni})
+// Per-lane state of the island walks (fast_island / map_seed / the FM search): the anchor list being appended to, the set
+// of visited BWT rows, status bits and the loop budget.  In wave-uniform code (slow_classify, an island walked again at
+// commit) every lane holds the same values: lctx_main() / lctx_done() take them from and give them back to the context.
+struct LCtx { DsbAnchor *anc; uint32_t n_anc, anc_cap; uint64_t *spset; int status; uint32_t lsteps, step_limit, sp_gen; Cnt k; };
+DV LCtx lctx_main(WCtxL &w)
+{
+	LCtx l; l.anc = w.anc; l.n_anc = w.n_anc; l.anc_cap = w.anc_cap; l.spset = w.spset; l.status = w.status; l.lsteps = w.lsteps; l.step_limit = w.step_limit;
+	l.sp_gen = w.sp_gen; l.k.c = w.k.c; l.k.uni = w.k.uni;
+	return l;
+}
+DV void lctx_done(WCtxL &w, const LCtx &l) { w.n_anc = l.n_anc; w.status = l.status; w.lsteps = l.lsteps; w.sp_gen = l.sp_gen; }
 
 // Serial sections: stretches of the per-read logic with no lane-level parallelism run on lane 0 alone, so that
 // their loads and stores are one-address memory instructions instead of 64 copies of the same address going
 // through the CU's address pipeline; serial_end() broadcasts the scalars such a section may change.
 #ifdef DSB_HOST_EMU
 #define DSB_SERIAL(w) if (true)
-DV void serial_end(WCtx &) {}
+DV void serial_end(WCtxL &) {}
 #else
-#define DSB_SERIAL(w) if ((w).lane == 0)
-DV void serial_end(WCtx &w)
-{
-	w.n_hit = dsb_shfl(w.n_hit, 0); w.status = dsb_shfl(w.status, 0); w.max_read_l = dsb_shfl(w.max_read_l, 0);
-	w.steps = dsb_shfl(w.steps, 0);
-	wave_sync();
-}
+#define DSB_SERIAL(w) if (DSB_LANE == 0)
+DV void serial_end(WCtxL &) { wave_sync(); }      // (the context is in LDS: what lane 0 wrote is what every lane reads)
 #endif
 
 // ---- hashes (src/lib/utils.c:1067-1091) ---------------------------------------------------
@@ -620,22 +653,21 @@ DV void get_new_ed(DsbXP x, const Cnt &k, uint32_t *e_d, uint32_t *len_, uint32_
 	*len_ = len;
 }
 
-DV DsbAnchor *push_anchor(WCtx &w)
+DV DsbAnchor *push_anchor(LCtx &w)
 {
 	if (w.n_anc >= w.anc_cap) { w.status |= DSB_ST_ANC_OVF; return w.anc + w.anc_cap - 1; }
 	return w.anc + w.n_anc++;
 }
 
 // map_seed (src/cly.c:706-939)
-DN int32_t map_seed(WCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, uint16_t seed_ID, uint8_t direction)
+DN int32_t map_seed(DsbXP x, LCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t read_L, uint16_t seed_ID, uint8_t direction)
 {
-	DsbXP x = w.x;
 	uint64_t b_p = m_r.sp; int32_t q_off = m_r.read_offset; uint32_t l_m = m_r.match_len;
 	const uint8_t *t_b = x->refbin;
 	int64_t uni = -1; uint32_t u_off = 0; uint64_t t_off = 0;
 	uint32_t l_pre, l_suf = 0, d_pre, d_suf = 0; int32_t s = 0, max_s = 0;
 	const int *Q_MEM = x->qmem; const int *Q_LV = x->qlv;
-	const Cnt k = w.k; uint32_t n_occ = 0, n_rw = 0;
+	const Cnt k = WK(w); uint32_t n_occ = 0, n_rw = 0;
 	do {
 		LvBuf qpre, tpre, qsuf, tsuf;
 		lvbuf_init(qpre, LVPAD_Q); lvbuf_init(tpre, LVPAD_T); lvbuf_init(tsuf, LVPAD_T);
@@ -841,7 +873,7 @@ DN void seed_vector_scan(BP bits_, uint32_t n_, DsbSeed *sv_, uint32_t direction
 	total += max_length;
 	*ns_out = ns; *total_out = total;
 }
-DV void seed_vector(WCtx &w, uint8_t *bin, const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t direction, SDir *out)
+DV void seed_vector(WCtxL &w, uint8_t *bin, const uint64_t *bits, uint32_t n, DsbSeed *sv, uint32_t direction, SDirL *out)
 {
 	uint32_t ns = 0, total = 0;
 	// the scan is a chain of dependent loads of the hit-bit words: stage them in LDS (the window table is idle
@@ -849,29 +881,28 @@ DV void seed_vector(WCtx &w, uint8_t *bin, const uint64_t *bits, uint32_t n, Dsb
 	const uint32_t n_words = (n + 63) >> 6;
 	if (w.wtab && n_words + 1 <= DSB_WTAB_SLOTS / 2) {
 		uint64_t *l = reinterpret_cast<uint64_t *>(w.wtab);
-		for (uint32_t i = w.lane; i < n_words; i += DSB_WAVE) l[i] = bits[i];
-		if (w.lane == 0) l[n_words] = 0;
+		for (uint32_t i = DSB_LANE; i < n_words; i += DSB_WAVE) l[i] = bits[i];
+		if (DSB_LANE == 0) l[n_words] = 0;
 		wave_sync();
 		DSB_SERIAL(w) seed_vector_scan<lds_bits_p>((lds_bits_p)l, n, sv, direction, &ns, &total);
 	} else
 		DSB_SERIAL(w) seed_vector_scan<const uint64_t *>(bits, n, sv, direction, &ns, &total);
 	ns = dsb_shfl(ns, 0); total = dsb_shfl(total, 0);
 	wave_sync();
-	out->seed_v = sv; out->l_seed_v = ns; out->bin_read = bin; out->bits = bits; out->direction = direction; out->total_score = total;
+	sdir_set(out, sv, ns, bin, bits, direction, total);
 }
 
 // One top island of fast_classify (src/cly.c:1494-1543): the backward MEM walk over the island, the
 // anchors of each MEM, and the "useless" marking among this island's anchors.  Appends to w.anc.
 // Returns 1 when the reference would also skip the following seed (max_score > 512, src/cly.c:1530-1531).
-DV int fast_island(WCtx &w, SDir *s_d, uint32_t read_len, uint32_t seed_idx)
+DV int fast_island(DsbXP x, LCtx &w, const SDirV s_d, uint32_t read_len, uint32_t seed_idx)
 {
-	DsbXP x = w.x;
 	int l_ek = x->ek_len, min_index = 21 - l_ek;
-	uint8_t *bin_read = s_d->bin_read;
+	uint8_t *bin_read = s_d.bin_read;
 	SpSet sp_set = {w.spset, 0, DSB_SPSET_CAP, &w.sp_gen};
 	sp_set_reset(sp_set);
 	DsbMem m_r[2];
-	DsbSeed sv = s_d->seed_v[seed_idx];
+	DsbSeed sv = s_d.seed_v[seed_idx];
 	int skip_next = 0;
 	uint32_t a_b_idx = w.n_anc;
 	for (int j = (int)sv.len - 1; j >= min_index;) {
@@ -892,7 +923,7 @@ DV int fast_island(WCtx &w, SDir *s_d, uint32_t read_len, uint32_t seed_idx)
 		int max_score = 0;
 		for (int q = 0; q < n; ++q) {
 			m_r[q].read_offset = string_index - m_r[q].match_len;
-			int sc = map_seed(w, m_r[q], bin_read, read_len, (uint16_t)seed_idx, (uint8_t)s_d->direction);
+			int sc = map_seed(x, w, m_r[q], bin_read, read_len, (uint16_t)seed_idx, (uint8_t)s_d.direction);
 			max_score = MAXV(sc, max_score);
 		}
 		if (max_score > 35) j -= 7;
@@ -912,10 +943,12 @@ DV int fast_island(WCtx &w, SDir *s_d, uint32_t read_len, uint32_t seed_idx)
 #ifndef DSB_LANE_ANC_CAP
 #define DSB_LANE_ANC_CAP 192       /* < 1024: the island records hold start and count in 10 bits each */
 #endif
-DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
+DN void fast_classify(WCtxL &w, SDirL *s_d_, uint32_t read_len)
 {
-	DsbSeed *sv_b = s_d->seed_v; uint32_t n_seed = s_d->l_seed_v;
-	const int lane = w.lane; uint32_t *const top_idx = w.top_idx; uint32_t *const info = w.round_info;
+	DsbXP x = w.x;
+	const SDirV s_d = {s_d_->seed_v, s_d_->bin_read, s_d_->direction};
+	DsbSeed *sv_b = s_d.seed_v; uint32_t n_seed = s_d_->l_seed_v;
+	const int lane = DSB_LANE; uint32_t *const top_idx = w.top_idx; uint32_t *const info = w.round_info;
 	// indices of the top seeds, in order (lanes over seeds, ballot compaction)
 	uint32_t n_top = 0;
 	for (uint32_t b0 = 0; b0 < n_seed; b0 += DSB_WAVE) {
@@ -927,34 +960,38 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 	if (lane == 0) w.red[0] = 0;
 	wave_sync();
 	if (n_top == 0) return;
-	DsbAnchor *const main_anc = w.anc; uint64_t *const main_sp = w.spset; const uint32_t main_n0 = w.n_anc;
+	DsbAnchor *const main_anc = w.anc; uint32_t *const red = w.red; DsbAnchor *const lane_anc = w.lane_anc;
 	// Phase 1: every lane walks islands into its own scratch (anchors, visited-row set), taking the next unwalked
 	// island from a counter in LDS when it is done with one -- island walks differ widely in length, and fixed
 	// rounds of 64 would wait for the longest of each round.  Per island: which lane, where in its scratch, how
 	// many anchors, the skip flag, and whether the scratch overflowed (then the island is redone at commit).
-	w.k.uni = 0;                                                   // lanes walk different islands: every lane counts its own work
-	w.anc = w.lane_anc + (size_t)lane * DSB_LANE_ANC_CAP; w.n_anc = 0; w.anc_cap = DSB_LANE_ANC_CAP;
-	w.spset = w.lane_spset + (size_t)lane * DSB_SPHASH;
-	for (;;) {
+	{
+		LCtx l = lctx_main(w);
+		l.k.uni = 0;                                               // lanes walk different islands: every lane counts its own work
+		l.anc = lane_anc + (size_t)lane * DSB_LANE_ANC_CAP; l.n_anc = 0; l.anc_cap = DSB_LANE_ANC_CAP;
+		l.spset = w.lane_spset + (size_t)lane * DSB_SPHASH;
+		const int st0 = l.status;
+		for (;;) {
 #ifdef DSB_HOST_EMU
-		const uint32_t t = w.red[0]++;
+			const uint32_t t = red[0]++;
 #else
-		const uint32_t t = __hip_atomic_fetch_add((lds_u32 *)w.red, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			const uint32_t t = __hip_atomic_fetch_add((lds_u32 *)red, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-		if (t >= n_top) break;
-		const uint32_t start = w.n_anc; const int st_before = w.status;
-		// a full scratch: an overflowing walk would overwrite its last slot, which belongs to an earlier island
-		if (start >= DSB_LANE_ANC_CAP) { info[t] = (uint32_t)lane | (start << 6) | (1u << 27); continue; }
-		int flag = fast_island(w, s_d, read_len, top_idx[t]);
-		int ovf = ((w.status & DSB_ST_ANC_OVF) && !(st_before & DSB_ST_ANC_OVF)) ? 1 : 0;
-		if (ovf) { w.status &= ~DSB_ST_ANC_OVF; w.n_anc = start; }
-		info[t] = (uint32_t)lane | (start << 6) | ((w.n_anc - start) << 16) | ((uint32_t)flag << 26) | ((uint32_t)ovf << 27);
+			if (t >= n_top) break;
+			const uint32_t start = l.n_anc; const int st_before = l.status;
+			// a full scratch: an overflowing walk would overwrite its last slot, which belongs to an earlier island
+			if (start >= DSB_LANE_ANC_CAP) { info[t] = (uint32_t)lane | (start << 6) | (1u << 27); continue; }
+			int flag = fast_island(x, l, s_d, read_len, top_idx[t]);
+			int ovf = ((l.status & DSB_ST_ANC_OVF) && !(st_before & DSB_ST_ANC_OVF)) ? 1 : 0;
+			if (ovf) { l.status &= ~DSB_ST_ANC_OVF; l.n_anc = start; }
+			info[t] = (uint32_t)lane | (start << 6) | ((l.n_anc - start) << 16) | ((uint32_t)flag << 26) | ((uint32_t)ovf << 27);
+		}
+		// each lane bumped its own copy of the set generation: continue from the largest so that no lane's stale
+		// entries can look current; a lane that ran out of its loop budget marks the read (the reference has no budget)
+		const uint32_t gen = (uint32_t)grp_max_i(red, lane, (int)l.sp_gen), ls = (uint32_t)grp_max_i(red, lane, (int)(l.lsteps >> 1));
+		const bool spent = dsb_ballot64((l.status & DSB_ST_TIMEOUT) != 0) != 0;
+		w.sp_gen = gen; w.lsteps = ls << 1; w.status = st0 | (spent ? DSB_ST_TIMEOUT : 0);
 	}
-	w.k.uni = 1;
-	w.anc = main_anc; w.n_anc = main_n0; w.anc_cap = w.anc_cap_main; w.spset = main_sp;
-	// each lane bumped its own copy of the set generation: continue from the largest so that no lane's stale
-	// entries can look current, and the group-uniform code below sees one value
-	w.sp_gen = (uint32_t)grp_max_i(w.red, lane, (int)w.sp_gen);
 	wave_sync();
 	// Phase 2: commit in island order, 64 islands at a time.  A seed is skipped iff it directly follows (index + 1)
 	// a committed seed whose island raised the skip flag (src/cly.c:1530-1531) -- a bit recurrence over the
@@ -979,9 +1016,9 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 				const uint64_t C = ADJ & (F << 1) & ~1ULL;
 				for (int l = 1; l < 64; l++) if (((C >> l) & 1ULL) && !((S >> (l - 1)) & 1ULL)) S |= 1ULL << l;
 				const bool keep = valid && !((S >> lane) & 1ULL);
-				uint32_t total, off = grp_excl_scan_u(w.red, lane, keep ? my_n : 0u, &total);
+				uint32_t total, off = grp_excl_scan_u(red, lane, keep ? my_n : 0u, &total);
 				if (main_n + total <= w.anc_cap_main) {
-					const DsbAnchor *src = w.lane_anc + (size_t)(ri & 0x3fu) * DSB_LANE_ANC_CAP + ((ri >> 6) & 0x3ffu);
+					const DsbAnchor *src = lane_anc + (size_t)(ri & 0x3fu) * DSB_LANE_ANC_CAP + ((ri >> 6) & 0x3ffu);
 					if (keep) for (uint32_t k = 0; k < my_n; k++) main_anc[main_n + off + k] = src[k];
 					w.n_anc = main_n + total;
 					const uint64_t KF = F & V & ~S;                             // committed seeds that raise the skip flag
@@ -996,10 +1033,10 @@ DN void fast_classify(WCtx &w, SDir *s_d, uint32_t read_len)
 				const uint32_t sidx = top_idx[base + l], ri_l = info[base + l];
 				uint32_t n_l = (ri_l >> 16) & 0x3ffu; int f_l = (ri_l >> 26) & 1; const int ovf_l = (ri_l >> 27) & 1;
 				if (sidx == skip_seed) continue;
-				if (ovf_l) f_l = fast_island(w, s_d, read_len, sidx);
+				if (ovf_l) { LCtx l = lctx_main(w); l.anc_cap = w.anc_cap_main; f_l = fast_island(x, l, s_d, read_len, sidx); lctx_done(w, l); }
 				else {
 					if (w.n_anc + n_l > w.anc_cap_main) { w.status |= DSB_ST_ANC_OVF; n_l = 0; }
-					const DsbAnchor *src = w.lane_anc + (size_t)(ri_l & 0x3fu) * DSB_LANE_ANC_CAP + ((ri_l >> 6) & 0x3ffu);
+					const DsbAnchor *src = lane_anc + (size_t)(ri_l & 0x3fu) * DSB_LANE_ANC_CAP + ((ri_l >> 6) & 0x3ffu);
 					for (uint32_t k = lane; k < n_l; k += DSB_WAVE) main_anc[w.n_anc + k] = src[k];
 					w.n_anc += n_l;
 				}
@@ -1023,18 +1060,20 @@ DV void sort_mems(DsbMem *m, int n)
 }
 
 // slow_classify (src/cly.c:1550-1611)
-DN void slow_classify(WCtx &w, SDir *sd, uint32_t read_len)
+DN void slow_classify(WCtxL &w_, SDirL *sd, uint32_t read_len)
 {
-	DsbXP x = w.x;
-	int l_ek = x->ek_len; uint8_t *bin_read = sd->bin_read; DsbSeed *sv_f = sd->seed_v;
+	DsbXP x = w_.x;
+	LCtx w = lctx_main(w_);                       // (wave-uniform here: every lane runs the same walk)
+	uint32_t steps = w_.steps; const uint32_t step_limit = w_.step_limit;
+	int l_ek = x->ek_len; uint8_t *bin_read = sd->bin_read; DsbSeed *sv_f = sd->seed_v; DsbMem *const mem_slow = w_.mem_slow; const uint32_t dirn = sd->direction, n_seed = sd->l_seed_v;
 	SpSet sp_set = {w.spset, 0, DSB_SPSET_CAP, &w.sp_gen};
-	DsbMem *mem_rst = w.mem_slow; int mem_rst_num;
-	for (uint32_t i = 0; i < sd->l_seed_v; i++) {
+	DsbMem *mem_rst = mem_slow; int mem_rst_num;
+	for (uint32_t i = 0; i < n_seed; i++) {
 		if ((int)(sv_f[i].len) < 3 && sv_f->top == 0) continue;
 		int min_match_len = MINV(20 - 1, l_ek + 1);
 		sp_set_reset(sp_set); mem_rst_num = 0;
 		for (int j = (int)sv_f[i].len - 1; j >= 1; j -= 2) {
-			if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; return; }
+			if (++steps > step_limit) { w.status |= DSB_ST_TIMEOUT; w_.steps = steps; lctx_done(w_, w); return; }
 			int k_idx = sv_f[i].offset + j;
 			int s_idx = k_idx + l_ek - 1;
 			uint64_t pre_v = prefix13(bin_read, s_idx);
@@ -1046,22 +1085,23 @@ DN void slow_classify(WCtx &w, SDir *sd, uint32_t read_len)
 		if (mem_rst_num > 1) sort_mems(mem_rst, mem_rst_num);
 		uint32_t a_b_idx = w.n_anc;
 		int max_search = MINV(mem_rst_num, 8);
-		for (int q = 0; q < max_search; ++q) map_seed(w, mem_rst[q], bin_read, read_len, (uint16_t)i, (uint8_t)sd->direction);
+		for (int q = 0; q < max_search; ++q) map_seed(x, w, mem_rst[q], bin_read, read_len, (uint16_t)i, (uint8_t)dirn);
 		int top_score = 35;
 		for (uint32_t q = a_b_idx; q < w.n_anc; q++) top_score = MAXV(top_score, w.anc[q].score);
 		for (uint32_t q = a_b_idx; q < w.n_anc; q++) w.anc[q].useless = (w.anc[q].score < top_score) ? 1 : 0;
 	}
+	w_.steps = steps; lctx_done(w_, w);
 }
 
 // ---- chaining (src/cly.c:72-112,201-349) ------------------------------------------------------
-DV DsbChain *push_hit(WCtx &w)
+DV DsbChain *push_hit(WCtxL &w)
 {
 	if (w.n_hit >= w.hit_cap) { w.status |= DSB_ST_HIT_OVF; return w.hit + w.hit_cap - 1; }
 	DsbChain *h = w.hit + w.n_hit++;
 	h->primary = 0; h->pri_index = 0;
 	return h;
 }
-DV void chain_insert_meta(WCtx &w, int32_t ai, DsbChain *c, bool new_chain, int dis_minus)
+DV void chain_insert_meta(WCtxL &w, int32_t ai, DsbChain *c, bool new_chain, int dis_minus)
 {
 	DsbAnchor *anchor = w.anc + ai;
 	uint32_t ref_l = anchor->ref_offset, ref_r = ref_l + anchor->mtch_len;
@@ -1085,7 +1125,7 @@ DV void chain_insert_meta(WCtx &w, int32_t ai, DsbChain *c, bool new_chain, int 
 		c->sum_score += (anchor->duplicate) ? 1 : anchor->score;
 	}
 }
-DV void chain_insert_M2(WCtx &w, int32_t ai)
+DV void chain_insert_M2(WCtxL &w, int32_t ai)
 {
 	DsbAnchor *anchor = w.anc + ai;
 	uint8_t direction = anchor->direction; uint32_t ref_ID = anchor->ref_ID;
@@ -1102,14 +1142,14 @@ DV void chain_insert_M2(WCtx &w, int32_t ai)
 
 // stable ascending sort of n (key, idx) pairs, bottom-up merge; result index order in the returned buffer.
 // Any stable sort equals glibc's merge sort for a consistent comparator.
-DN uint32_t *stable_sort_keys(WCtx &w, uint32_t n)
+DN uint32_t *stable_sort_keys(WCtxL &w, uint32_t n)
 {
 	uint64_t *ka = w.sortkey, *kb = w.sortkey + w.anc_cap_main;
 	uint32_t *ia = w.sortidx, *ib = w.sortidx + w.anc_cap_main;
 	for (uint32_t width = 1; width < n; width <<= 1) {
 		// lanes take whole merges; each merge is independent
 		uint32_t n_merge = (n + 2 * width - 1) / (2 * width);
-		for (uint32_t mi = w.lane; mi < n_merge; mi += DSB_WAVE) {
+		for (uint32_t mi = DSB_LANE; mi < n_merge; mi += DSB_WAVE) {
 			uint32_t lo = mi * 2 * width, mid = MINV(lo + width, n), hi = MINV(lo + 2 * width, n);
 			uint32_t i = lo, j = mid, o = lo;
 			while (i < mid && j < hi) {
@@ -1127,9 +1167,9 @@ DN uint32_t *stable_sort_keys(WCtx &w, uint32_t n)
 
 // chain_insert_M3 (src/cly.c:238-323): stable sort by (ref_ID, direction, ref_offset), then sparse DP per group
 #define DSB_RANKSORT_MAX (DSB_WTAB_SLOTS / 4)            /* 8-byte keys in the window table's LDS, at most half of it */
-DN void chain_sort_M3(WCtx &w)
+DN void chain_sort_M3(WCtxL &w)
 {
-	DsbAnchor *A = w.anc, *T = w.anc_tmp; const int32_t n = w.n_anc; const int lane = w.lane;
+	DsbAnchor *A = w.anc, *T = w.anc_tmp; const int32_t n = w.n_anc; const int lane = DSB_LANE;
 	if (n <= DSB_RANKSORT_MAX && w.wtab) {
 		// the usual size: keys in LDS (the window table is idle), every lane ranks its own anchors against all keys
 		// (stable: ties by index) and moves them straight to their sorted place; the two anchor arrays swap roles
@@ -1178,9 +1218,9 @@ typedef __attribute__((address_space(3))) uint32_t lds_w32;
 // (P32: lds_w32 * for the arrays in LDS, uint32_t * for larger anchor sets whose arrays lie in the idle half of the
 // anchor arena -- global memory, same code, the loads of a chunk of predecessors are coalesced; C = array stride)
 template <class P32>
-DN void chain_stage_M3(WCtx &w, P32 L, const uint32_t C)
+DN void chain_stage_M3(WCtxL &w, P32 L, const uint32_t C)
 {
-	const DsbAnchor *A = w.anc; const int32_t n = w.n_anc; const int lane = w.lane;
+	const DsbAnchor *A = w.anc; const int32_t n = w.n_anc; const int lane = DSB_LANE;
 	for (int32_t i = lane; i < n; i += DSB_WAVE) {
 		const DsbAnchor a = A[i];
 		L[i] = a.index_in_read; L[C + i] = a.ref_offset; L[2 * C + i] = (uint32_t)a.mtch_len | ((uint32_t)(uint16_t)a.score << 16);
@@ -1189,9 +1229,9 @@ DN void chain_stage_M3(WCtx &w, P32 L, const uint32_t C)
 	wave_sync();
 }
 template <class P32>
-DN void chain_unstage_M3(WCtx &w, P32 L, const uint32_t C)
+DN void chain_unstage_M3(WCtxL &w, P32 L, const uint32_t C)
 {
-	DsbAnchor *A = w.anc; const int32_t n = w.n_anc; const int lane = w.lane;
+	DsbAnchor *A = w.anc; const int32_t n = w.n_anc; const int lane = DSB_LANE;
 	wave_sync();
 	for (int32_t i = lane; i < n; i += DSB_WAVE) A[i].pre = (int32_t)L[5 * C + i];
 	wave_sync();
@@ -1201,9 +1241,9 @@ DN void chain_unstage_M3(WCtx &w, P32 L, const uint32_t C)
 // first predecessor that strictly improves the running best: lane l takes predecessor hi - l of a chunk of 64, a ballot
 // finds the stop, a wave maximum the best score, and among equal scores the nearest predecessor (lowest lane) wins.
 template <class P32>
-DN void chain_dp_M3_wave(WCtx &w, P32 LQ, const uint32_t C)
+DN void chain_dp_M3_wave(WCtxL &w, P32 LQ, const uint32_t C)
 {
-	const int32_t n = w.n_anc; const int lane = w.lane;
+	const int32_t n = w.n_anc; const int lane = DSB_LANE;
 	P32 LT = LQ + C, LMS = LQ + 2 * C, LK = LQ + 3 * C, LS = LQ + 4 * C, LP = LQ + 5 * C;
 	for (int32_t st = 0; st < n;) {
 		int32_t ed = st + 1;
@@ -1259,7 +1299,7 @@ DN void chain_dp_M3_wave(WCtx &w, P32 LQ, const uint32_t C)
 	wave_sync();
 }
 template <bool LDSMODE>
-DN void chain_dp_M3(WCtx &w)
+DN void chain_dp_M3(WCtxL &w)
 {
 	DsbAnchor *A = w.anc; int32_t n = w.n_anc;
 	int *score_v = w.score_v;
@@ -1348,7 +1388,7 @@ DV int chain_cmp_by_MEM_score(const DsbChain *a, const DsbChain *b)
 // glibc qsort == top-down merge sort: n1 = n/2, merge takes left when cmp(l,r) <= 0.
 // Iterative post-order walk of exactly that tree; chains are moved through hit_tmp.
 template <int WHICH>
-DN void glibc_sort_chains(WCtx &w, uint32_t n)
+DN void glibc_sort_chains(WCtxL &w, uint32_t n)
 {
 	if (n <= 1) return;
 	DsbChain *b = w.hit, *t = w.hit_tmp;
@@ -1375,7 +1415,7 @@ DN void glibc_sort_chains(WCtx &w, uint32_t n)
 }
 
 // resolve_tree (src/cly.c:326-349)
-DN void resolve_tree(WCtx &w)
+DN void resolve_tree(WCtxL &w)
 {
 	w.n_hit = 0;
 	const bool lds_dp = w.n_anc >= 50 && w.n_anc <= DSB_CHAINDP_LDS && w.wtab;
@@ -1575,7 +1615,7 @@ DV int MEM_search(P8 q, P8 t, bool forward, int max)
 	}
 	return len < max ? len : (max > 0 ? max : 0);
 }
-DV DsbSms *push_sms(WCtx &w)
+DV DsbSms *push_sms(WCtxL &w)
 {
 	const uint32_t cap = w.x->sms_cap;
 	if (w.n_sms >= cap) { w.status |= DSB_ST_SMS_OVF; return w.sms + cap - 1; }
@@ -1690,13 +1730,13 @@ DV uint32_t sdp_visit(uint32_t &lsteps, const uint32_t step_limit, int &st, cons
 }
 
 template <bool FWD, class P8>
-DN uint32_t sdp_match_t(WCtx &w, const SdpArgsT<P8> a, uint32_t n_sms)
+DN uint32_t sdp_match_t(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms)
 {
 	uint32_t t_kmer_num = a.t_len - 9 + 1;
 	if (t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return n_sms; // the reference's loop does not run either (t_len >= 13 at every call site)
 	uint32_t n_pos = (t_kmer_num - 4 + 3) / 4;                      // i = 4, 8, ... < t_kmer_num
 	// the context lives in memory (it is shared by reference with non-inlined callers): work on copies
-	const int lane = w.lane; uint32_t *const red = w.red; DsbSms *const sms = w.sms; const uint32_t sms_cap = w.x->sms_cap;
+	const int lane = DSB_LANE; uint32_t *const red = w.red; DsbSms *const sms = w.sms; const uint32_t sms_cap = w.x->sms_cap;
 	uint32_t lsteps = w.lsteps, mirror_bad = 0; int st = 0; const uint32_t step_limit = w.step_limit;
 	for (uint32_t g = 0; g < n_pos; g += DSB_WAVE) {
 		uint32_t pI = g + lane; bool valid = pI < n_pos; int i = 4 + 4 * (int)pI;
@@ -1717,8 +1757,11 @@ DN uint32_t sdp_match_t(WCtx &w, const SdpArgsT<P8> a, uint32_t n_sms)
 		n_sms += total;
 		wave_sync();
 	}
-	w.lsteps = lsteps;
-	if (st) w.status |= st;
+	// (the budget and the status bits of the lanes become the wavefront's: the largest count, the union of the bits)
+	const uint32_t ls = (uint32_t)grp_max_i(red, lane, (int)(lsteps >> 1));
+	const bool any_to = dsb_ballot64((st & DSB_ST_TIMEOUT) != 0) != 0, any_ovf = dsb_ballot64((st & DSB_ST_SMS_OVF) != 0) != 0;
+	w.lsteps = ls << 1;
+	if (any_to | any_ovf) w.status |= (any_to ? DSB_ST_TIMEOUT : 0) | (any_ovf ? DSB_ST_SMS_OVF : 0);
 	return n_sms | mirror_bad;      // bit 31: some nodes are missing from the LDS mirror
 }
 
@@ -1731,18 +1774,18 @@ DV uint32_t sdp_nq(uint32_t L, uint32_t q_bg, uint32_t q_ed)
 
 // appends the nodes to w.sms[n_sms...] and returns the new count (w.n_sms is not touched)
 template <class P8>
-DV uint32_t sdp_match_p(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, P8 q_base, int32_t q_lo, P8 t_str, uint32_t t_len, uint32_t t_st, bool isForward, uint4 *lnodes,
+DV uint32_t sdp_match_p(WCtxL &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, P8 q_base, int32_t q_lo, P8 t_str, uint32_t t_len, uint32_t t_st, bool isForward, uint4 *lnodes,
                         const uint64_t *qpk = nullptr)
 {
 	SdpArgsT<P8> a; a.lnodes = lnodes; a.q_bg = q_bg; a.q_ed = q_ed; a.q_base = q_base; a.q_lo = q_lo; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st;
-	a.tab = (const lds_u32 *)w.wtab; a.bm = reinterpret_cast<uint32_t *>(w.sortkey) + w.lane;
+	a.tab = (const lds_u32 *)w.wtab; a.bm = reinterpret_cast<uint32_t *>(w.sortkey) + DSB_LANE;
 	a.n_q = sdp_nq(w.L, q_bg, q_ed);
 	if (a.n_q > DSB_WTAB_MAXQ) { w.status |= DSB_ST_SMS_OVF; return n_sms; }     // cannot happen: windows are <= 2001 wide
 	uint32_t t_kmer_num = t_len - 9 + 1;
 	if (a.n_q == 0 || t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return n_sms;
 	TX0(w, t_b);
-	if (qpk) wtab_build_pk((lds_u32 *)w.wtab, w.lane, qpk, (w.L + 31) / 32 + 1, q_bg, a.n_q);
-	else wtab_build<P8>((lds_u32 *)w.wtab, w.lane, q_base + ((int32_t)q_bg - q_lo), 0u, a.n_q);
+	if (qpk) wtab_build_pk((lds_u32 *)w.wtab, DSB_LANE, qpk, (w.L + 31) / 32 + 1, q_bg, a.n_q);
+	else wtab_build<P8>((lds_u32 *)w.wtab, DSB_LANE, q_base + ((int32_t)q_bg - q_lo), 0u, a.n_q);
 	TX1(w, 0, t_b);
 	TX0(w, t_p);
 	const uint32_t rv = isForward ? sdp_match_t<true, P8>(w, a, n_sms) : sdp_match_t<false, P8>(w, a, n_sms);
@@ -1750,18 +1793,18 @@ DV uint32_t sdp_match_p(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, P
 	return rv;
 }
 // windows in global memory (q_str = the read strand) ...
-DN uint32_t sdp_match_n(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len,
+DN uint32_t sdp_match_n(WCtxL &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len,
                         uint32_t t_st, bool isForward, uint4 *lnodes, const uint64_t *qpk)
 {
 	return sdp_match_p<gp8>(w, n_sms, q_bg, q_ed, q_str, 0, t_str, t_len, t_st, isForward, lnodes, qpk);
 }
 // ... or staged in LDS by sdp_middle_M2: lq holds the read from position q_lo on, lt the reference window
-DN uint32_t sdp_match_lds(WCtx &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *lq, int32_t q_lo, const uint8_t *lt, uint32_t t_len,
+DN uint32_t sdp_match_lds(WCtxL &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *lq, int32_t q_lo, const uint8_t *lt, uint32_t t_len,
                           uint32_t t_st, uint4 *lnodes)
 {
 	return sdp_match_p<lp8>(w, n_sms, q_bg, q_ed, (lp8)lq, q_lo, (lp8)lt, t_len, t_st, true, lnodes);
 }
-DV void sdp_match(WCtx &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len, int key_len,
+DV void sdp_match(WCtxL &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len, int key_len,
                   int tbl, uint32_t t_st, bool isForward)
 {
 	(void)key_len;
@@ -1777,7 +1820,7 @@ typedef uint32_t dsb_u32x4 __attribute__((ext_vector_type(4)));
 DV uint4 ring_ld(const uint4 *ring, uint32_t i) { dsb_u32x4 v = ((const __attribute__((address_space(3))) dsb_u32x4 *)ring)[i]; uint4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
 DV void ring_st(uint4 *ring, uint32_t i, uint4 r) { dsb_u32x4 v; v.x = r.x; v.y = r.y; v.z = r.z; v.w = r.w; ((__attribute__((address_space(3))) dsb_u32x4 *)ring)[i] = v; }
 #endif
-DV void ring_put(WCtx &w, uint32_t idx, uint32_t t_pos, uint32_t q_pos, uint32_t len, uint32_t score)
+DV void ring_put(WCtxL &w, uint32_t idx, uint32_t t_pos, uint32_t q_pos, uint32_t len, uint32_t score)
 {
 	uint4 r; r.x = t_pos; r.y = q_pos; r.z = len; r.w = score;
 	ring_st(w.ring, idx & (DSB_RING - 1), r);
@@ -1785,12 +1828,12 @@ DV void ring_put(WCtx &w, uint32_t idx, uint32_t t_pos, uint32_t q_pos, uint32_t
 // the nodes sdp_match appended are consumed one by one: fetch them 64 at a time (one per lane) and hand
 // node idx to every lane with shuffles
 struct NodeBlock { uint32_t base, valid; DsbSms mine; };
-DV DsbSms node_get(WCtx &w, NodeBlock &b, uint32_t idx)
+DV DsbSms node_get(WCtxL &w, NodeBlock &b, uint32_t idx)
 {
 #if DSB_GROUP == 64 && !defined(DSB_HOST_EMU)
 	if (idx < b.base || idx >= b.base + b.valid) {
 		b.base = idx; b.valid = MINV((uint32_t)64, w.n_sms - idx);
-		if ((uint32_t)w.lane < b.valid) b.mine = w.sms[idx + w.lane];
+		if ((uint32_t)DSB_LANE < b.valid) b.mine = w.sms[idx + DSB_LANE];
 	}
 	DsbSms r; int src = (int)(idx - b.base);
 	r.t_pos = dsb_shfl(b.mine.t_pos, src); r.q_pos = dsb_shfl(b.mine.q_pos, src); r.len = dsb_shfl(b.mine.len, src); r.score = 0;
@@ -1805,7 +1848,7 @@ DV DsbSms node_get(WCtx &w, NodeBlock &b, uint32_t idx)
 // sdp_middle_M2 / sdp_right_M2 / sdp_left_M2 (src/cly.c:2495-2517, 2612-2638, 2759-2783), lanes over
 // predecessors (newest first), wave max at the end.  MODE 0 = middle (no distance cut), 1 = right, 2 = left.
 template <int MODE>
-DV int sdp_best_pred(WCtx &w, const DsbSms &cs, int32_t cur)
+DV int sdp_best_pred(WCtxL &w, const DsbSms &cs, int32_t cur)
 {
 	int best = (int)cs.len;
 	uint32_t lim_q, lim_t;
@@ -1818,7 +1861,7 @@ DV int sdp_best_pred(WCtx &w, const DsbSms &cs, int32_t cur)
 		DsbSms pv[DSB_DP_UNROLL];
 #pragma unroll
 		for (int u = 0; u < DSB_DP_UNROLL; u++) {
-			int32_t pi = hi - u * DSB_WAVE - w.lane;
+			int32_t pi = hi - u * DSB_WAVE - DSB_LANE;
 			if (pi < 0) { pv[u].t_pos = pv[u].q_pos = pv[u].len = pv[u].score = 0; }
 			else if (MODE != 0 && pi > cur - DSB_RING) { uint4 r = ring_ld(w.ring, pi & (DSB_RING - 1)); pv[u].t_pos = r.x; pv[u].q_pos = r.y; pv[u].len = r.z; pv[u].score = r.w; }
 			else pv[u] = w.sms[pi];
@@ -1827,7 +1870,7 @@ DV int sdp_best_pred(WCtx &w, const DsbSms &cs, int32_t cur)
 #pragma unroll
 		for (int u = 0; u < DSB_DP_UNROLL; u++) {
 			if (stop) break;
-			int32_t pi = hi - u * DSB_WAVE - w.lane; bool valid = pi >= 0;
+			int32_t pi = hi - u * DSB_WAVE - DSB_LANE; bool valid = pi >= 0;
 			DsbSms ps = pv[u];
 			bool skip, brk = false; int ns = 0;
 			if (MODE == 2) {
@@ -1855,13 +1898,13 @@ DV int sdp_best_pred(WCtx &w, const DsbSms &cs, int32_t cur)
 				}
 			}
 			// the reference stops at the first predecessor (newest first) that meets the distance cut
-			int first_brk = (MODE == 0) ? DSB_WAVE : grp_first(w.red, w.lane, valid && brk);
-			if (valid && !skip && !brk && w.lane < first_brk) best = MAXV(best, ns);
+			int first_brk = (MODE == 0) ? DSB_WAVE : grp_first(w.red, DSB_LANE, valid && brk);
+			if (valid && !skip && !brk && DSB_LANE < first_brk) best = MAXV(best, ns);
 			if (first_brk < DSB_WAVE) stop = true;
 		}
 		if (stop) break;
 	}
-	return grp_max_i(w.red, w.lane, best);
+	return grp_max_i(w.red, DSB_LANE, best);
 }
 
 
@@ -1912,7 +1955,7 @@ DV void sdp_judge(const DsbSms &cs, const DsbSms &ps, uint32_t lim_q, uint32_t l
 }
 
 template <int MODE>
-DN void sdp_batch_old(WCtx &w, DpBatchL &b)
+DN void sdp_batch_old(WCtxL &w, DpBatchL &b)
 {
 	// per node of the batch (group-uniform, kept in scalar registers): limits and the terms of sdp_judge that do
 	// not depend on the predecessor
@@ -1936,7 +1979,7 @@ DN void sdp_batch_old(WCtx &w, DpBatchL &b)
 #define DSB_FETCH_PREDS(dst, hi_, ng_)                                                                          \
 	_Pragma("unroll") for (int u = 0; u < DSB_DP_UNROLL; u++) {                                                 \
 		if (u >= (ng_)) break;                                                                                   \
-		int32_t pi = (hi_) - u * DSB_WAVE - w.lane;                                                              \
+		int32_t pi = (hi_) - u * DSB_WAVE - DSB_LANE;                                                              \
 		if (pi < 0) { dst[u].t_pos = 0; dst[u].q_pos = (MODE == 2) ? 0u : 0xfffffff0u; dst[u].len = 0; dst[u].score = 0; } \
 		else if (pi > n0 - DSB_RING) { uint4 r = ring_ld(w.ring, pi & (DSB_RING - 1)); dst[u].t_pos = r.x; dst[u].q_pos = r.y; dst[u].len = r.z; dst[u].score = r.w; } \
 		else dst[u] = w.sms[pi];                                                                                 \
@@ -1955,7 +1998,7 @@ DN void sdp_batch_old(WCtx &w, DpBatchL &b)
 		for (int u = 0; u < DSB_DP_UNROLL; u++) {
 			wrapped[u] = false; A[u] = B[u] = C[u] = D[u] = S[u] = 0;
 			if (u >= ng) continue;
-			int32_t pi = hi - u * DSB_WAVE - w.lane;
+			int32_t pi = hi - u * DSB_WAVE - DSB_LANE;
 			DsbSms ps = nx[u];
 			if (MODE == 2) { A[u] = ps.q_pos; B[u] = ps.t_pos; C[u] = ps.t_pos; }
 			else { A[u] = ps.q_pos + ps.len + 8; B[u] = ps.t_pos + ps.len + 8; C[u] = ps.t_pos + 600; }
@@ -2024,8 +2067,8 @@ DN void sdp_batch_old(WCtx &w, DpBatchL &b)
 				bool ok = !skip & !brk & (ai <= 200);
 				uint64_t bm = dsb_ballot64(brk);
 				if (bm) {	// the reference stops at the newest predecessor that meets the distance cut
-					int first_brk = grp_first(w.red, w.lane, brk);
-					ok = ok & (w.lane < first_brk);
+					int first_brk = grp_first(w.red, DSB_LANE, brk);
+					ok = ok & (DSB_LANE < first_brk);
 					stopm |= 1u << j;
 				}
 				if (ok && ns > best[j]) best[j] = ns;
@@ -2038,7 +2081,7 @@ DN void sdp_batch_old(WCtx &w, DpBatchL &b)
 	w.dp_preds += preds;
 	DSB_HEAVY_CHECK(w);
 #pragma unroll
-	for (int j = 0; j < DSB_DPB; j++) b.old_best[j] = ((uint32_t)j < b.K) ? grp_max_i(w.red, w.lane, best[j]) : 0;
+	for (int j = 0; j < DSB_DPB; j++) b.old_best[j] = ((uint32_t)j < b.K) ? grp_max_i(w.red, DSB_LANE, best[j]) : 0;
 }
 
 #ifndef DSB_HOST_EMU
@@ -2168,7 +2211,7 @@ DN void sdp_batch_old_mw(DsbMw *mw, uint4 *ring, uint32_t *red, const int lane, 
 #endif
 // best predecessor score of node `cur` (right/left extension), through the batch
 template <int MODE>
-DV int sdp_best_pred_b(WCtx &w, DpBatchL &b, const DsbSms &cs, int32_t cur, const NodeBlock &nb)
+DV int sdp_best_pred_b(WCtxL &w, DpBatchL &b, const DsbSms &cs, int32_t cur, const NodeBlock &nb)
 {
 	if ((uint32_t)cur < b.n0 || (uint32_t)cur >= b.n0 + b.K) {
 		b.n0 = (uint32_t)cur; b.K = MINV((uint32_t)DSB_DPB, w.n_sms - (uint32_t)cur);
@@ -2189,11 +2232,11 @@ DV int sdp_best_pred_b(WCtx &w, DpBatchL &b, const DsbSms &cs, int32_t cur, cons
 		if (w.mw && b.n0 >= DSB_MW_MIN_PREDS) {
 			// several wavefronts on this read: wake the helpers for the pass over the old predecessors
 			DsbMw *mw = w.mw;
-			if (w.lane < DSB_DPB) { const int sj = (uint32_t)w.lane < b.K ? w.lane : 0; mw->nd_t[w.lane] = b.nd_t[sj]; mw->nd_q[w.lane] = b.nd_q[sj]; mw->nd_l[w.lane] = b.nd_l[sj]; }
-			if (w.lane == 0) { mw->cmd = (uint32_t)MODE; mw->n0 = b.n0; mw->K = b.K; mw->sms = w.sms; }
+			if (DSB_LANE < DSB_DPB) { const int sj = (uint32_t)DSB_LANE < b.K ? DSB_LANE : 0; mw->nd_t[DSB_LANE] = b.nd_t[sj]; mw->nd_q[DSB_LANE] = b.nd_q[sj]; mw->nd_l[DSB_LANE] = b.nd_l[sj]; }
+			if (DSB_LANE == 0) { mw->cmd = (uint32_t)MODE; mw->n0 = b.n0; mw->K = b.K; mw->sms = w.sms; }
 			__syncthreads();
 			uint32_t preds = 0;
-			sdp_batch_old_mw<MODE>(mw, w.ring, w.red, w.lane, 0, w.n_waves, &preds);
+			sdp_batch_old_mw<MODE>(mw, w.ring, w.red, DSB_LANE, 0, w.n_waves, &preds);
 			w.dp_preds += preds;
 			for (uint32_t j = 0; j < DSB_DPB; j++) { int m = -2147483647 - 1; for (int u = 0; u < w.n_waves; u++) m = MAXV(m, mw->best[u][j]); b.old_best[j] = j < b.K ? m : 0; }
 		} else
@@ -2206,15 +2249,15 @@ DV int sdp_best_pred_b(WCtx &w, DpBatchL &b, const DsbSms &cs, int32_t cur, cons
 	// distance cut ends the scan -- lanes beyond it do not count
 	const int32_t m = cur - (int32_t)b.n0;
 	for (int32_t base = 0; base < m && !cut; base += DSB_WAVE) {
-		const int32_t l = base + w.lane; const bool valid = l < m;
+		const int32_t l = base + DSB_LANE; const bool valid = l < m;
 		bool skip = true, brk = false; int ns = 0;
 		if (valid) {
 			uint4 r = ring_ld(w.ring, (uint32_t)(cur - 1 - l) & (DSB_RING - 1)); DsbSms ps; ps.t_pos = r.x; ps.q_pos = r.y; ps.len = r.z; ps.score = r.w;
 			sdp_judge<MODE>(cs, ps, lim_q, lim_t, skip, brk, ns);
 		}
-		const int fb = grp_first(w.red, w.lane, valid && !skip && brk);
-		const int mine = (valid && !skip && !brk && w.lane < fb) ? ns : (-2147483647 - 1);
-		const int mx = grp_max_i(w.red, w.lane, mine);
+		const int fb = grp_first(w.red, DSB_LANE, valid && !skip && brk);
+		const int mine = (valid && !skip && !brk && DSB_LANE < fb) ? ns : (-2147483647 - 1);
+		const int mx = grp_max_i(w.red, DSB_LANE, mine);
 		if (mx > best) best = mx;
 		if (fb < DSB_WAVE) cut = true;
 	}
@@ -2223,9 +2266,9 @@ DV int sdp_best_pred_b(WCtx &w, DpBatchL &b, const DsbSms &cs, int32_t cur, cons
 	return best;
 }
 
-DV void fill_window(const WCtx &w, uint8_t *win, int n)
+DV void fill_window(const WCtxL &w, uint8_t *win, int n)
 {
-	for (int i = w.lane; i < n; i += DSB_WAVE) win[i] = DSB_TPAD_VAL;
+	for (int i = DSB_LANE; i < n; i += DSB_WAVE) win[i] = DSB_TPAD_VAL;
 }
 
 // sdp_middle_M2 (src/cly.c:2444-2530)
@@ -2260,10 +2303,10 @@ DV uint64_t gl_tload(const uint8_t *txt, uint64_t p) { return __builtin_bswap64(
 // 32 bases of the packed query from position p on (staged words start at word w0)
 #define GL_Q32(p_) gl_funnel(lq[(((p_) >> 5) - w0) * DSB_WAVE], lq[(((p_) >> 5) - w0 + 1) * DSB_WAVE], ((p_) & 31u) * 2)
 
-DN int gap_lane(WCtx &w, const DsbGap g, const uint64_t *qpk, uint64_t t_offset)
+DN int gap_lane(WCtxL &w, const DsbGap g, const uint64_t *qpk, uint64_t t_offset)
 {
 	DsbXP x = w.x;
-	const uint32_t L = w.L; const int lane = w.lane;
+	const uint32_t L = w.L; const int lane = DSB_LANE;
 	lds_u64 *lq = (lds_u64 *)w.wtab + lane, *ln = (lds_u64 *)w.wtab + DSB_GL_QW * DSB_WAVE + lane;
 	const int pre_mch = (int)g.pl, pre_refoffset = (int)(g.pt - 3);
 	const int total_ref_len = (int)(g.ct - (uint32_t)(pre_refoffset + pre_mch) + 3);
@@ -2365,14 +2408,14 @@ DN int gap_lane(WCtx &w, const DsbGap g, const uint64_t *qpk, uint64_t t_offset)
 }
 #undef GL_Q32
 
-DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int key_len)
+DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int key_len)
 {
 	DsbXP x = w.x;
 	if (w.status & DSB_ST_HEAVY) return 0;          // the read is being given up (see heavy_limit)
 	int score = 10000;
 	// the context lives in memory: work on copies (see sdp_match_t)
 	const DsbAnchor *A = w.anc; DsbSms *const S = w.sms; uint32_t *const wtab = w.wtab; uint8_t *const win = w.win_mid;
-	const int lane = w.lane; const uint32_t L = w.L;
+	const int lane = DSB_LANE; const uint32_t L = w.L;
 	DsbGap *const G = reinterpret_cast<DsbGap *>(w.anc_tmp);            // the unsorted anchor copy is idle from the chaining on
 	const uint64_t t_offset = x->refinfo[A[c_a].ref_ID].seq_offset;
 	// 1. the gaps of the chain (a linked list through Anchor.pre), from its last anchor backwards
@@ -2540,7 +2583,7 @@ DN int sdp_middle_M2(WCtx &w, int32_t c_a, const uint8_t *q_str, int tbl, int ke
 }
 
 // sdp_right_M2 (src/cly.c:2532-2677)
-DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain *c_st, int chain_ID, uint32_t l_read, DsbScHash *sc_hash, int score_ori)
+DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChain *c_st, int chain_ID, uint32_t l_read, DsbScHash *sc_hash, int score_ori)
 {
 	DsbXP x = w.x;
 	score_ori += 10000;
@@ -2574,7 +2617,7 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 			} else max_search_ref = t_length - c_t_offset;
 			max_search_ref = MINV(600u, max_search_ref);
 			TX0(w, t_r);
-			get_ref_wave(x->refbin, x->ref_bases, w.lane, ref, c_t_offset + t_offset_global, max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50);
+			get_ref_wave(x->refbin, x->ref_bases, DSB_LANE, ref, c_t_offset + t_offset_global, max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50);
 			wave_sync();
 			TX1(w, 3, t_r); if (w.dbg) w.tx[7] += 1;
 			int search_q_ed = (int)best_q + 1000;
@@ -2625,7 +2668,7 @@ DN int sdp_right_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 }
 
 // sdp_left_M2 (src/cly.c:2679-2819)
-DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain *c_st, int chain_ID, uint32_t l_read, DsbScHash *sc_hash, int score_ori)
+DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChain *c_st, int chain_ID, uint32_t l_read, DsbScHash *sc_hash, int score_ori)
 {
 	DsbXP x = w.x;
 	score_ori += 10000;
@@ -2659,9 +2702,9 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 			} else max_search_ref = c_t_offset;
 			max_search_ref = MINV(600u, max_search_ref);
 			if (t_offset_global == 0 && c_t_offset < 50 + max_search_ref)
-				{ get_ref_wave(x->refbin, x->ref_bases, w.lane, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref), max_search_ref); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref); }
+				{ get_ref_wave(x->refbin, x->ref_bases, DSB_LANE, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref), max_search_ref); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref); }
 			else
-				{ get_ref_wave(x->refbin, x->ref_bases, w.lane, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref - 50), max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50); }
+				{ get_ref_wave(x->refbin, x->ref_bases, DSB_LANE, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref - 50), max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50); }
 			wave_sync();
 			int search_q_st = (int)best_q - 1000;
 			search_q_st = MAXV(search_q_st, 0);
@@ -2703,7 +2746,7 @@ DN int sdp_left_M2(WCtx &w, const uint8_t *q_str, int tbl, int key_len, DsbChain
 }
 
 // get_score_M2 (src/cly.c:2821-2849)
-DN void get_score_M2(WCtx &w, SDir *sd, uint32_t l_read, DsbScHash *sc_hash)
+DN void get_score_M2(WCtxL &w, SDirL *sd, uint32_t l_read, DsbScHash *sc_hash)
 {
 	TICK(w, 8);
 	MARK(w, 50);
@@ -2713,7 +2756,7 @@ DN void get_score_M2(WCtx &w, SDir *sd, uint32_t l_read, DsbScHash *sc_hash)
 	DsbChain *H = w.hit;
 	for (uint32_t i = 0; i < w.n_hit; i++) {
 		if (H[i].sum_score == 0) continue;
-		SDir *csd = ((sd->direction == H[i].direction) ? 0 : 1) + sd;
+		SDirL *csd = ((sd->direction == H[i].direction) ? 0 : 1) + sd;
 		int tbl = (H[i].direction == D_FORWARD) ? 0 : 1;
 		MARK(w, 52);
 		int score = sdp_middle_M2(w, H[i].cur, csd->bin_read, tbl, key_len);
@@ -2730,11 +2773,11 @@ DN void get_score_M2(WCtx &w, SDir *sd, uint32_t l_read, DsbScHash *sc_hash)
 }
 
 // delete_small_score_rst (src/cly.c:2883-2993)
-DN void delete_small_score_rst(WCtx &w, SDir *sd, uint32_t l_read)
+DN void delete_small_score_rst(WCtxL &w, SDirL *sd, uint32_t l_read)
 {
 	DsbXP x = w.x;
 	if (w.n_hit == 0) return;
-	for (int i = w.lane; i < 256; i += DSB_WAVE) { w.sc[i].next = 0; w.sc[i].seed_ID = 0; }
+	for (int i = DSB_LANE; i < 256; i += DSB_WAVE) { w.sc[i].next = 0; w.sc[i].seed_ID = 0; }
 	wave_sync();
 	DSB_SERIAL(w) {
 		if (w.n_hit > 200) {
@@ -2790,7 +2833,7 @@ DN void delete_small_score_rst(WCtx &w, SDir *sd, uint32_t l_read)
 }
 
 // detect_primary (src/cly.c:2995-3058); the primary list lives in score_v (ints) / spset (bytes)
-DN void detect_primary(WCtx &w, uint32_t read_len)
+DN void detect_primary(WCtxL &w, uint32_t read_len)
 {
 	DsbChain *hit = w.hit; uint32_t n_hit = w.n_hit;
 	if (n_hit == 0) return;
@@ -2834,59 +2877,59 @@ DN void detect_primary(WCtx &w, uint32_t read_len)
 // its lane scratch; the wavefront then finishes the reads one after the other from those anchors (classify_read with
 // have_anchors).  Needs the seed lists of k_seed_scan.  *n_anc_out: anchors of the lane's read, *ovf_out: they did not fit
 // the lane scratch (the read then takes the usual path).
-DN void fast_classify_lane(WCtx &w, bool valid, uint8_t *bin, uint32_t read_len, DsbSeed *seeds, const DsbSeedInfo *info, uint32_t *n_anc_out, uint32_t *ovf_out)
+DN void fast_classify_lane(WCtxL &w, bool valid, uint8_t *bin, uint32_t read_len, DsbSeed *seeds, const DsbSeedInfo *info, uint32_t *n_anc_out, uint32_t *ovf_out)
 {
-	DsbAnchor *const main_anc = w.anc; uint64_t *const main_sp = w.spset; const int st0 = w.status;
-	w.k.uni = 0;
-	w.anc = w.lane_anc + (size_t)w.lane * DSB_LANE_ANC_CAP; w.n_anc = 0; w.anc_cap = DSB_LANE_ANC_CAP;
-	w.spset = w.lane_spset + (size_t)w.lane * DSB_SPHASH; w.status = 0; w.lsteps = 0;
+	DsbXP x = w.x; const int lane = DSB_LANE;
+	LCtx l = lctx_main(w);
+	l.k.uni = 0;
+	l.anc = w.lane_anc + (size_t)lane * DSB_LANE_ANC_CAP; l.n_anc = 0; l.anc_cap = DSB_LANE_ANC_CAP;
+	l.spset = w.lane_spset + (size_t)lane * DSB_SPHASH; l.status = 0; l.lsteps = 0;
 	// a lane gives a read up (ovf: the whole wavefront does it afterwards) once its anchors outgrow the lane's scratch or
 	// after DSB_LANE_STEPS search steps -- a read in a repeat would keep the other 63 lanes waiting
-	const uint32_t limit0 = w.step_limit; w.step_limit = MINV(limit0, (uint32_t)DSB_LANE_STEPS);
+	l.step_limit = MINV(l.step_limit, (uint32_t)DSB_LANE_STEPS);
 	if (valid && read_len >= 40) {
 		const DsbSeedInfo si = *info;
-		SDir sd[2];
-		sd[0].seed_v = seeds; sd[0].l_seed_v = si.n_seed[0]; sd[0].bin_read = bin; sd[0].bits = nullptr; sd[0].direction = D_FORWARD; sd[0].total_score = si.total[0];
-		sd[1].seed_v = seeds + (read_len >> 2); sd[1].l_seed_v = si.n_seed[1]; sd[1].bin_read = bin + read_len; sd[1].bits = nullptr; sd[1].direction = D_REVERSE; sd[1].total_score = si.total[1];
-		if (sd[0].total_score < sd[1].total_score) { SDir t = sd[0]; sd[0] = sd[1]; sd[1] = t; }
-		const bool both_direction = ((sd[0].total_score - sd[1].total_score) <= (sd[0].total_score >> 3));
+		SDirV sd[2]; uint32_t n_seed[2] = {si.n_seed[0], si.n_seed[1]}, total[2] = {si.total[0], si.total[1]};
+		sd[0].seed_v = seeds; sd[0].bin_read = bin; sd[0].direction = D_FORWARD;
+		sd[1].seed_v = seeds + (read_len >> 2); sd[1].bin_read = bin + read_len; sd[1].direction = D_REVERSE;
+		if (total[0] < total[1]) { SDirV t = sd[0]; sd[0] = sd[1]; sd[1] = t; uint32_t u = n_seed[0]; n_seed[0] = n_seed[1]; n_seed[1] = u; u = total[0]; total[0] = total[1]; total[1] = u; }
+		const bool both_direction = ((total[0] - total[1]) <= (total[0] >> 3));
 		for (int s = 0; s < (both_direction ? 2 : 1); s++) {
 			uint32_t skip_seed = 0xffffffffu;
-			for (uint32_t i = 0; i < sd[s].l_seed_v; i++) {
+			for (uint32_t i = 0; i < n_seed[s]; i++) {
 				if (!sd[s].seed_v[i].top || i == skip_seed) continue;
-				if (w.status & (DSB_ST_ANC_OVF | DSB_ST_TIMEOUT)) break;
-				if (fast_island(w, &sd[s], read_len, i)) skip_seed = i + 1;
+				if (l.status & (DSB_ST_ANC_OVF | DSB_ST_TIMEOUT)) break;
+				if (fast_island(x, l, sd[s], read_len, i)) skip_seed = i + 1;
 			}
 		}
 	}
-	w.step_limit = limit0;
-	*n_anc_out = w.n_anc; *ovf_out = (w.status & (DSB_ST_ANC_OVF | DSB_ST_TIMEOUT)) ? 1u : 0u;
-	w.anc = main_anc; w.n_anc = 0; w.anc_cap = w.anc_cap_main; w.spset = main_sp; w.status = st0; w.k.uni = 1;
-	w.sp_gen = (uint32_t)grp_max_i(w.red, w.lane, (int)w.sp_gen);
+	*n_anc_out = l.n_anc; *ovf_out = (l.status & (DSB_ST_ANC_OVF | DSB_ST_TIMEOUT)) ? 1u : 0u;
+	const uint32_t gen = (uint32_t)grp_max_i(w.red, lane, (int)l.sp_gen);
+	w.n_anc = 0; w.sp_gen = gen;
 	wave_sync();
 }
 
-DN uint32_t classify_read(WCtx &w, const uint64_t *bitsF, const uint64_t *bitsR, const bool have_anchors = false)
+DN uint32_t classify_read(WCtxL &w, const uint64_t *bitsF, const uint64_t *bitsR, const bool have_anchors = false)
 {
 	uint32_t read_len = w.L;
 	if (!have_anchors) w.n_anc = 0;
 	w.n_hit = 0; w.n_sms = 0; w.steps = 0; w.lsteps = 0; w.dp_preds = 0; w.boosted = 0; w.k.uni = 1;
 	uint32_t fast = 1;
 	if (read_len < 40) return fast;
-	SDir *sd = w.sd;
+	SDirL *sd = w.sd;
 	uint32_t n = read_len - w.x->ek_len + 1;
 	w.stage = 1; MARK(w, 1); if (w.dbg) w.tlast = DSB_CLOCK();
 	if (w.pre_seeds) {
 		// the seed lists of both strands came out of the seed-lookup kernel (k_seed_scan)
 		const DsbSeedInfo si = *w.pre_info;
-		sd[0].seed_v = w.pre_seeds; sd[0].l_seed_v = si.n_seed[0]; sd[0].bin_read = w.bin; sd[0].bits = bitsF; sd[0].direction = D_FORWARD; sd[0].total_score = si.total[0];
-		sd[1].seed_v = w.pre_seeds + (read_len >> 2); sd[1].l_seed_v = si.n_seed[1]; sd[1].bin_read = w.bin + read_len; sd[1].bits = bitsR; sd[1].direction = D_REVERSE; sd[1].total_score = si.total[1];
+		sdir_set(sd, w.pre_seeds, si.n_seed[0], w.bin, bitsF, D_FORWARD, si.total[0]);
+		sdir_set(sd + 1, w.pre_seeds + (read_len >> 2), si.n_seed[1], w.bin + read_len, bitsR, D_REVERSE, si.total[1]);
 	} else {
 		seed_vector(w, w.bin, bitsF, n, w.seeds, D_FORWARD, sd);
 		seed_vector(w, w.bin + read_len, bitsR, n, w.seeds + (read_len >> 2), D_REVERSE, sd + 1);
 	}
 	TICK(w, 0);
-	if (sd[0].total_score < sd[1].total_score) { SDir t = sd[0]; sd[0] = sd[1]; sd[1] = t; }
+	if (sd[0].total_score < sd[1].total_score) sdir_swap(sd, sd + 1);
 	bool both_direction = ((sd[0].total_score - sd[1].total_score) <= (sd[0].total_score >> 3));
 	int super_repeat = 0;
 	w.stage = 2; MARK(w, 2);

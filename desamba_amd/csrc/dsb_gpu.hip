@@ -430,9 +430,10 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 	if (lane < 4) lds_cnt[lane] = 0;                                                                                    \
 	if (lane == 0) sx = x;                                                                                              \
 	__syncthreads();                                                                                                    \
-	NS::WCtx w;                                                                                                         \
+	__shared__ NS::WCtx s_w;                  /* the context of the read: wave-uniform, in LDS (dsb_classify_dev.h) */   \
+	NS::WCtxL &w = *(NS::WCtxL *)&s_w;                                                                                  \
 	w.ring = lds_ring; w.dpb = (NS::DpBatchL *)&lds_dpb; w.red = lds_red; w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1;                                                                               \
-	w.x = (NS::DsbXP)&sx; w.lane = lane; w.dbg = dbg ? dbg + 4 * slot_id : nullptr;                                             \
+	w.x = (NS::DsbXP)&sx; w.dbg = dbg ? dbg + 4 * slot_id : nullptr;                                             \
 	for (int i = 0; i < 14; i++) w.tacc[i] = 0;                                                                         \
 	for (int i = 0; i < 10; i++) w.tx[i] = 0;                                                                           \
 	w.seeds = (DsbSeed *)(slot + ar.off_seeds);                                                                         \
@@ -564,10 +565,11 @@ __global__ void __launch_bounds__(64 * MWW, DSB_WAVES_PER_EU) k_classify_heavy(D
 	if (threadIdx.x < 4) lds_cnt[threadIdx.x] = 0;
 	if (threadIdx.x == 0) { sx = x; mw.cmd = 0; }
 	__syncthreads();
-	dsb_g64::WCtx w;
+	__shared__ dsb_g64::WCtx s_w;
+	dsb_g64::WCtxL &w = *(dsb_g64::WCtxL *)&s_w;
 	if (wv == 0) {
 		w.ring = lds_ring; w.dpb = (dsb_g64::DpBatchL *)&lds_dpb; w.red = lds_red; w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1;
-		w.x = (dsb_g64::DsbXP)&sx; w.lane = lane; w.dbg = nullptr;
+		w.x = (dsb_g64::DsbXP)&sx; w.dbg = nullptr;
 		for (int i = 0; i < 14; i++) w.tacc[i] = 0;
 		for (int i = 0; i < 10; i++) w.tx[i] = 0;
 		w.seeds = (DsbSeed *)(slot + ar.off_seeds);
@@ -1580,13 +1582,15 @@ __global__ void __launch_bounds__(64) k_seed_dump(DsbDevIndex x, DsbReadDesc d, 
 	__shared__ uint32_t lds_cnt[4];
 	if (threadIdx.x == 0) sx = x;
 	__syncthreads();
-	dsb_g64::WCtx w; w.x = (dsb_g64::DsbXP)&sx; w.lane = threadIdx.x; w.L = d.len; w.status = 0; w.dbg = nullptr; w.anc_cap = 0; w.wtab = nullptr;
+	__shared__ dsb_g64::WCtx s_w;
+	dsb_g64::WCtxL &w = *(dsb_g64::WCtxL *)&s_w;
+	w.x = (dsb_g64::DsbXP)&sx; w.L = d.len; w.status = 0; w.dbg = nullptr; w.anc_cap = 0; w.wtab = nullptr;
 	w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1; w.pre_seeds = nullptr; w.pre_info = nullptr; w.pk[0] = w.pk[1] = nullptr; w.mw = nullptr; w.n_waves = 1;
-	dsb_g64::SDir sd;
+	dsb_g64::SDirL *sd = w.sd;
 	uint32_t n = d.len - x.ek_len + 1;
-	if (strand) dsb_g64::seed_vector(w, bin + d.bin_off + DSB_QPAD_L, bits + d.bit_off, n, out, D_FORWARD, &sd);
-	else dsb_g64::seed_vector(w, bin + d.bin_off + DSB_QPAD_L + d.len, bits + d.bit_off + d.n_words, n, out, D_REVERSE, &sd);
-	if (threadIdx.x == 0) { n_out[0] = sd.l_seed_v; n_out[1] = sd.total_score; }
+	if (strand) dsb_g64::seed_vector(w, bin + d.bin_off + DSB_QPAD_L, bits + d.bit_off, n, out, D_FORWARD, sd);
+	else dsb_g64::seed_vector(w, bin + d.bin_off + DSB_QPAD_L + d.len, bits + d.bit_off + d.n_words, n, out, D_REVERSE, sd);
+	if (threadIdx.x == 0) { n_out[0] = sd->l_seed_v; n_out[1] = sd->total_score; }
 }
 extern "C" int dsb_batch_seeds(dsb_ctx *c, size_t read, int strand, dsb_seed *out, size_t cap, uint32_t *n, uint32_t *total_score)
 {

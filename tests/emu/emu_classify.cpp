@@ -59,7 +59,7 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	e->arena.assign(o + 256, 0xCD);
 	memset(e->arena.data() + off[9], 0, DSB_SPHASH * 8); memset(e->arena.data() + off[15], 0, DSB_SPHASH * 8); e->w.sp_gen = 0;
 	uint8_t *s = e->arena.data(); WCtx &w = e->w;
-	w.x = &e->dx; w.lane = 0; w.dbg = nullptr;
+	w.x = &e->dx; w.dbg = nullptr;
 	w.seeds = (DsbSeed *)(s + off[0]); w.anc = (DsbAnchor *)(s + off[1]); w.anc_tmp = (DsbAnchor *)(s + off[2]);
 	w.hit = (DsbChain *)(s + off[3]); w.hit_tmp = (DsbChain *)(s + off[4]); w.sms = (DsbSms *)(s + off[5]);
 	alignas(16) static uint32_t emu_wtab[DSB_WTAB_SLOTS]; w.wtab = emu_wtab;
