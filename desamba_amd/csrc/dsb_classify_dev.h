@@ -238,7 +238,6 @@ struct WCtx {
 	uint32_t dp_preds;         // predecessors scanned by the sparse DP of this read (heavy-read detection)
 	uint32_t heavy_limit;      // single-wavefront launches: give the read up for k_classify_heavy beyond this many (0: never)
 	DpBatchL *dpb;             // LDS: the batch of extension nodes being scored (sdp_best_pred_b)
-	uint32_t nm_base, nm_end;  // nodes [nm_base, nm_end) of the current extension are mirrored in LDS (node_mirror: the window table's memory, idle between two sdp_match calls)
 	uint4 *ring;               // LDS: the most recent DSB_RING sparse-DP nodes of sdp_right/left ({t_pos,q_pos,len,score})
 	int status; int max_read_l;
 	int stage; int boosted; uint32_t sp_gen;   // generation of the visited-row sets (monotonic within a launch)
@@ -1828,36 +1827,11 @@ DV void ring_put(WCtxL &w, uint32_t idx, uint32_t t_pos, uint32_t q_pos, uint32_
 	uint4 r; r.x = t_pos; r.y = q_pos; r.z = len; r.w = score;
 	ring_st(w.ring, idx & (DSB_RING - 1), r);
 }
-// ---- the recent nodes of a right / left extension in LDS ---------------------------------------------------------
-// Between two sdp_match calls the window table (12 KB of LDS) holds nothing that is still needed, and that is when the sparse
-// DP runs: per node it reads the node, the nodes of its batch and the predecessors within 600 reference bases -- the last
-// few dozen nodes of the list.  node_mirror() copies the tail of the list (DSB_NM_OLD scored nodes + the new ones, at most
-// DSB_NM_CAP) into the table's memory once per window; the DP, node_get and the batch set-up then read LDS instead of
-// global memory, and scores are written to both.  Older predecessors (repeats) still come from the list in global memory.
-#define DSB_NM_CAP (DSB_WTAB_SLOTS / 4)
-#define DSB_NM_OLD 256u
-DV void node_mirror(WCtxL &w, uint32_t first_new)
-{
-	const uint32_t base = first_new > DSB_NM_OLD ? first_new - DSB_NM_OLD : 0u, n = w.n_sms, end = MINV(n, base + (uint32_t)DSB_NM_CAP);
-	uint4 *const nm = reinterpret_cast<uint4 *>(w.wtab); const DsbSms *const sms = w.sms;
-	for (uint32_t i = base + (uint32_t)DSB_LANE; i < end; i += DSB_WAVE) { const DsbSms v = sms[i]; uint4 r; r.x = v.t_pos; r.y = v.q_pos; r.z = v.len; r.w = v.score; ring_st(nm, i - base, r); }
-	w.nm_base = base; w.nm_end = end;
-	wave_sync();
-}
-DV void node_mirror_score(WCtxL &w, uint32_t idx, uint32_t t_pos, uint32_t q_pos, uint32_t len, uint32_t score)
-{
-	const uint32_t base = w.nm_base;
-	if (idx >= base && idx < w.nm_end) { uint4 r; r.x = t_pos; r.y = q_pos; r.z = len; r.w = score; ring_st(reinterpret_cast<uint4 *>(w.wtab), idx - base, r); }
-}
 // the nodes sdp_match appended are consumed one by one: fetch them 64 at a time (one per lane) and hand
 // node idx to every lane with shuffles
 struct NodeBlock { uint32_t base, valid; DsbSms mine; };
 DV DsbSms node_get(WCtxL &w, NodeBlock &b, uint32_t idx)
 {
-	{
-		const uint32_t mb = w.nm_base;
-		if (idx >= mb && idx < w.nm_end) { const uint4 r = ring_ld(reinterpret_cast<const uint4 *>(w.wtab), idx - mb); DsbSms v; v.t_pos = r.x; v.q_pos = r.y; v.len = r.z; v.score = 0; return v; }
-	}
 #if DSB_GROUP == 64 && !defined(DSB_HOST_EMU)
 	if (idx < b.base || idx >= b.base + b.valid) {
 		b.base = idx; b.valid = MINV((uint32_t)64, w.n_sms - idx);
@@ -2002,7 +1976,6 @@ DN void sdp_batch_old(WCtxL &w, DpBatchL &b)
 	}
 	stopm = DSB_RFL(stopm); wnm = DSB_RFL(wnm);
 	const int32_t n0 = (int32_t)b.n0;
-	const int32_t nm_b = (int32_t)w.nm_base, nm_e = (int32_t)w.nm_end; const uint4 *const nm_p = reinterpret_cast<const uint4 *>(w.wtab);   // (node_mirror)
 	// predecessors are fetched one iteration ahead (4 x 64 nodes in flight while the previous 4 x 64 are judged)
 	DsbSms nx[DSB_DP_UNROLL];
 #define DSB_FETCH_PREDS(dst, hi_, ng_)                                                                          \
@@ -2010,7 +1983,6 @@ DN void sdp_batch_old(WCtxL &w, DpBatchL &b)
 		if (u >= (ng_)) break;                                                                                   \
 		int32_t pi = (hi_) - u * DSB_WAVE - DSB_LANE;                                                              \
 		if (pi < 0) { dst[u].t_pos = 0; dst[u].q_pos = (MODE == 2) ? 0u : 0xfffffff0u; dst[u].len = 0; dst[u].score = 0; } \
-		else if (pi >= nm_b && pi < nm_e) { uint4 r = ring_ld(nm_p, (uint32_t)(pi - nm_b)); dst[u].t_pos = r.x; dst[u].q_pos = r.y; dst[u].len = r.z; dst[u].score = r.w; } \
 		else if (pi > n0 - DSB_RING) { uint4 r = ring_ld(w.ring, pi & (DSB_RING - 1)); dst[u].t_pos = r.x; dst[u].q_pos = r.y; dst[u].len = r.z; dst[u].score = r.w; } \
 		else dst[u] = w.sms[pi];                                                                                 \
 	}
@@ -2245,10 +2217,8 @@ DV int sdp_best_pred_b(WCtxL &w, DpBatchL &b, const DsbSms &cs, int32_t cur, con
 {
 	if ((uint32_t)cur < b.n0 || (uint32_t)cur >= b.n0 + b.K) {
 		b.n0 = (uint32_t)cur; b.K = MINV((uint32_t)DSB_DPB, w.n_sms - (uint32_t)cur);
-		const uint32_t mb_ = w.nm_base, me_ = w.nm_end;
 		for (uint32_t j = 0; j < b.K; j++) {
 			const uint32_t idx = (uint32_t)cur + j;
-			if (idx >= mb_ && idx < me_) { const uint4 r = ring_ld(reinterpret_cast<const uint4 *>(w.wtab), idx - mb_); b.nd_t[j] = r.x; b.nd_q[j] = r.y; b.nd_l[j] = r.z; continue; }
 #if DSB_GROUP == 64 && !defined(DSB_HOST_EMU)
 			// the block of 64 nodes the caller holds in its lanes (node_get) has most of them: no load
 			if (idx >= nb.base && idx < nb.base + nb.valid) {
@@ -2628,7 +2598,6 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 	DsbSms *p = push_sms(w);
 	p->score = score_ori; p->q_pos = c_h->q_ed; p->t_pos = c_h->t_ed; p->len = 1 - 9;
 	ring_put(w, 0, p->t_pos, p->q_pos, p->len, p->score);
-	wave_sync(); node_mirror(w, 1);
 	uint32_t best_t = c_h->t_ed, best_q = c_h->q_ed, best_len = (uint32_t)(1 - 9);     // fields of node max_sms_id
 	NodeBlock nb; nb.base = 0; nb.valid = 0;
 	DpBatchL &db = *w.dpb; db.n0 = 0; db.K = 0;
@@ -2662,7 +2631,6 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 			c_t_offset += max_search_ref - 9 - 3;
 			if (w.n_sms == current_sms) break;
 			nb.valid = 0;
-			node_mirror(w, current_sms);
 			if (node_get(w, nb, current_sms).t_pos > best_t + 1000) break;
 		}
 		DsbSms *c_sms = w.sms + current_sms;
@@ -2676,7 +2644,6 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 		TX0(w, t_s);
 		c_sms->score = max_score;
 		ring_put(w, current_sms - 1, cs.t_pos, cs.q_pos, cs.len, (uint32_t)max_score);
-		node_mirror_score(w, current_sms - 1, cs.t_pos, cs.q_pos, cs.len, (uint32_t)max_score);
 		TX1(w, 4, t_s);
 		SUB0(w);
 		bool comb = (int)cs.len >= 8 && combine_chain(c_st, chain_ID, sc_hash, cs.t_pos - cs.q_pos, false, cs.q_pos, &combined) == true;
@@ -2689,7 +2656,6 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 			p = push_sms(w);
 			p->score = total_max_score; p->q_pos = c_h->q_ed; p->t_pos = c_h->t_ed; p->len = -9;
 			ring_put(w, 0, p->t_pos, p->q_pos, p->len, p->score);
-			wave_sync(); node_mirror(w, 1);
 			best_t = c_h->t_ed; best_q = c_h->q_ed; best_len = (uint32_t)(-9); nb.valid = 0; db.K = 0;
 			current_sms = 1;
 			c_t_offset = c_h->t_ed;
@@ -2717,7 +2683,6 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 	DsbSms *p = push_sms(w);
 	p->score = score_ori; p->q_pos = c_h->q_st; p->t_pos = c_h->t_st;
 	ring_put(w, 0, p->t_pos, p->q_pos, 0, p->score);                       // a[0].len is never read by the left DP
-	p->len = 0; wave_sync(); node_mirror(w, 1);
 	uint32_t best_t = c_h->t_st, best_q = c_h->q_st;                       // fields of node max_sms_id
 	NodeBlock nb; nb.base = 0; nb.valid = 0;
 	DpBatchL &db = *w.dpb; db.n0 = 0; db.K = 0;
@@ -2752,7 +2717,6 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 			c_t_offset = c_t_offset - max_search_ref + 9 + 3;
 			if (w.n_sms == current_sms) break;
 			nb.valid = 0;
-			node_mirror(w, current_sms);
 			if (node_get(w, nb, current_sms).t_pos + 1000 < best_t) break;
 		}
 		DsbSms *c_sms = w.sms + current_sms;
@@ -2762,7 +2726,6 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 		SUB1(w, 11);
 		c_sms->score = max_score;
 		ring_put(w, current_sms - 1, cs.t_pos, cs.q_pos, cs.len, (uint32_t)max_score);
-		node_mirror_score(w, current_sms - 1, cs.t_pos, cs.q_pos, cs.len, (uint32_t)max_score);
 		if ((int)cs.len >= 8 && combine_chain(c_st, chain_ID, sc_hash, cs.t_pos - cs.q_pos, true, cs.q_pos + cs.len, &combined) == true) {
 			int c_len = cs.len;
 			total_max_score = MAXV(score_ori, max_score) - c_len + sdp_middle_M2(w, combined->cur, q_str, tbl, key_len);
@@ -2771,7 +2734,6 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 			p = push_sms(w);
 			p->score = total_max_score; p->q_pos = c_h->q_st; p->t_pos = c_h->t_st;
 			ring_put(w, 0, p->t_pos, p->q_pos, 0, p->score);
-			p->len = 0; wave_sync(); node_mirror(w, 1);
 			best_t = c_h->t_st; best_q = c_h->q_st; nb.valid = 0; db.K = 0;
 			current_sms = 1;
 			c_t_offset = c_h->t_st;
