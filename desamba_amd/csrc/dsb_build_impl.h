@@ -177,7 +177,7 @@ int dsb_build_run(B &be, const DsbBuildIn &in, DsbBuildOut &out)
 		kv = be.template alloc<uint64_t>(n + 1);
 		be.to_dev(kv, in.kmers.data(), n * 8);
 	}
-	if (n == 0 || n >= 0xfffffff0ULL) return -4;
+	if (n == 0) return -4;                     // (no limit on the number of 31-mers: ranks, rows and offsets are 64-bit throughout; memory is the limit)
 	out.n_kmer = n;
 	uint64_t *pre = be.template alloc<uint64_t>(DSB_PRE_N);
 	be.for_n(n + 1, DSB_LAMBDA(uint64_t i) {
@@ -203,7 +203,11 @@ int dsb_build_run(B &be, const DsbBuildIn &in, DsbBuildOut &out)
 			b_or32(&info[loc], bits);
 		});
 	});
-	{ uint32_t m[4]; be.to_host(m, miss, 16); if (m[0]) return -4; }
+	// a k-mer of a supplied list that no window of the text touched (a list made from a superset of the text, or with canonical
+	// counting) would become a unitig with no length, end or position: such a list is refused like one that misses a k-mer of the
+	// text (the reference's builder would carry the stray k-mers along as isolated unitigs that no read of this text can reach)
+	be.for_n(n, DSB_LAMBDA(uint64_t i) { if (info[i] == 0) b_add32(miss + 1, 1); });
+	{ uint32_t m[4]; be.to_host(m, miss, 16); if (m[0] || m[1]) return -4; }
 	be.for_n(n, DSB_LAMBDA(uint64_t i) {
 		const uint32_t f = info[i], in_e = (f >> 4) & 0xfu, out_e = f & 0xfu;
 		const uint64_t v = kv[i];
@@ -237,6 +241,7 @@ int dsb_build_run(B &be, const DsbBuildIn &in, DsbBuildOut &out)
 	uint64_t *uend = be.template alloc<uint64_t>(n_uni);
 	uint32_t *kpos = be.template alloc<uint32_t>(2 * n);
 	uint64_t *cs = be.template alloc<uint64_t>(2 * n_chunk);               // per chunk: position + 1 of its last start window (0: none), and that unitig
+	be.zero(ulen, (n_uni + 1) * 4); be.zero(uend, n_uni * 8); be.zero(kpos, 2 * n * 4);   // (every entry is written below when the graph is consistent; the row-count check must not read stale memory when it is not)
 	be.for_n(n_chunk, DSB_LAMBDA(uint64_t ch) {
 		const uint64_t g0 = ch * DSB_BCHUNK, g1 = g0 + DSB_BCHUNK < N ? g0 + DSB_BCHUNK : N;
 		uint64_t at = 0, u = 0;

@@ -107,8 +107,10 @@ typedef struct {
  * front of it (src/idx_sort.c:298-401): the 31-mers are then enumerated from the reference text itself.
  * fasta: plain or gzip FASTA read with the reference's reader rules; out_dir is created; the ten deSAMBA.* files
  * written are byte-identical to the reference's (.ref_i: the reference leaves the padding behind each name
- * uninitialised; zeros here).  Limits: < 2^32 distinct 31-mers, < 2^32 / 30 unitigs.  DSB_EINVAL: reference shorter than
- * 31 bases, a k-mer of the text missing from kmer_srt, or a unitig cycle the reference's builder does not handle either. */
+ * uninitialised; zeros here).  Limits: < 2^32 / 30 unitigs (the file format holds unitig numbers in 32 bits); k-mer ranks and BWT rows
+ * are 64-bit (an index of > 2^32 BWT rows is built and classified on: tests/tools/huge_index.sh); the working set (~60 bytes per
+ * reference base) must fit the device.  DSB_EINVAL: reference shorter than 31 bases, a k-mer of the text missing from kmer_srt or a
+ * k-mer of kmer_srt missing from the text, or a unitig cycle the reference's builder does not handle either. */
 typedef struct {
 	uint64_t n_bases, n_refs, n_kmer, n_unitig, n_rows;
 	double parse_s, sort_s, graph_s, walk_s, rows_s, tables_s, write_s, total_s;
