@@ -314,6 +314,34 @@ finished:
  * piece is parsed by its own thread without touching the text, and the pieces are accepted only if each one ends exactly
  * where the next was guessed to start -- i.e. if the sequential kseq parse would have produced the same records.
  * Anything else (multi-line records, FASTA, '\r', a wrong guess) is parsed again by the sequential loop. */
+/* DSB_FASTA_COMPAT=1: the reference's FASTA quirk, reproduced.  kseq's look-ahead character (`last_char`: the '>' a FASTA
+ * record's parser has consumed of the NEXT record) lives in the kseq_t, and classify_main keeps 3 x 5000 kseq_t (one array per
+ * pipeline worker, allocated once: src/cly_mt.c:545-550) over ONE shared stream: record k+1 is read by another kseq_t than
+ * record k, whose last_char is 0 on its first use -- it skips to the next header, i.e. over record k+1 -- and whatever its last
+ * use left there afterwards.  With the switch on, every record is read with the look-ahead of the slot the reference would
+ * use: batches of <= 5000 reads and < 10 Mbp (read_reads, src/cly_mt.c:42-56) dealt to workers 0, 1, 2 in turn, from worker 0
+ * again for every input file (kt_pipeline is started per file, src/cly_mt.c:551-558).  Parsing is sequential then. */
+#define REF_N_NEEDED 5000
+#define REF_MAX_READ_SIZE 10000000
+typedef struct { int on; unsigned char slot[3][REF_N_NEEDED]; int tid, i; size_t total; } compat_t;
+static compat_t g_compat;
+static void compat_new_file(void) { g_compat.tid = 0; g_compat.i = 0; g_compat.total = 0; }
+static void compat_new_batch(void) { g_compat.tid = (g_compat.tid + 1) % 3; g_compat.i = 0; g_compat.total = 0; }
+/* look-ahead for the next record (carried: what the plain parser would use) */
+static int compat_last(int carried)
+{
+	if (!g_compat.on) return carried;
+	if (g_compat.i >= REF_N_NEEDED || g_compat.total >= REF_MAX_READ_SIZE) compat_new_batch();
+	return g_compat.slot[g_compat.tid][g_compat.i];
+}
+/* a record was read (rc 1) or dropped (rc -2) with that look-ahead */
+static void compat_done(int rc, const dsb_rec_t *r)
+{
+	if (!g_compat.on) return;
+	if (rc == 1) { g_compat.slot[g_compat.tid][g_compat.i] = (unsigned char)r->next_last; g_compat.total += r->seq_len; g_compat.i++; }
+	else if (rc == -2) { g_compat.slot[g_compat.tid][g_compat.i] = 0; compat_new_batch(); }     /* kseq_read returned -2: read_reads ends the batch there */
+}
+
 typedef struct {
 	char *t; size_t start, limit, end; int eof, last_in, sequential;
 	size_t n, cap; const char **name, **seq, **qual; uint32_t *name_len, *seq_len;
@@ -358,12 +386,15 @@ static void *parse_main(void *arg)
 	seg_t *g = arg; size_t pos = g->start; rec_t r; int last = g->last_in;
 	g->ok = 1; g->n = 0; g->name_bytes = 0; g->n_bad = 0; g->max_len = 0;
 	for (;;) {
-		if (pos >= g->limit && last == 0) break;           /* (with a header character already consumed the record is read here) */
+		if (g->sequential && g_compat.on) { if (pos >= g->limit) break; }      /* (the look-ahead comes from the slot, nothing is carried) */
+		else if (pos >= g->limit && last == 0) break;       /* (with a header character already consumed the record is read here) */
 		const char *base = g->t;
+		if (g->sequential) last = compat_last(last);
 		int rc = scan_record(g->t, pos, g->end, g->eof, last, 0, &r);
 		if (g->sequential) {
-			if (rc == -2) { g->n_bad++; pos = r.next; last = r.next_last; continue; }   /* read_reads (src/cly_mt.c:42-56) drops such a record and goes on behind it */
+			if (rc == -2) { compat_done(rc, &r); g->n_bad++; pos = r.next; last = r.next_last; continue; }   /* read_reads (src/cly_mt.c:42-56) drops such a record and goes on behind it */
 			if (rc != 1) { if (rc == -1) { pos = g->end; last = 0; } else pos = r.next; break; }   /* -1: nothing but junk is left; 0: more text needed (r.next skips junk, if any) */
+			compat_done(rc, &r);
 			if (r.seq_len > 0xffffffffUL) die("[classify] a read longer than 4 Gbp");
 			if (!r.plain) {
 				/* sequence or quality in several lines: the text is not written to (it is the mapped file); the record is
@@ -382,7 +413,7 @@ static void *parse_main(void *arg)
 		seg_push(g, base, &r);
 		pos = r.next; last = r.next_last;
 	}
-	g->end_pos = pos; g->last_out = last;
+	g->end_pos = pos; g->last_out = (g->sequential && g_compat.on) ? 0 : last;
 	return NULL;
 }
 static void *emit_main(void *arg)
@@ -405,7 +436,7 @@ static size_t parse_wave(app_t *a, batch_t *b, char *t, size_t pos, size_t soft_
 	const double t0 = now();
 	seg_t *seg = g_seg; int np = 0, parallel = 0;
 	if (soft_end > end) soft_end = end;
-	if (*last == 0 && a->n_parse > 1 && soft_end - pos >= 2 * a->seg_min) {
+	if (*last == 0 && a->n_parse > 1 && soft_end - pos >= 2 * a->seg_min && !g_compat.on) {
 		size_t want = (soft_end - pos) / a->seg_min; if (want > (size_t)a->n_parse) want = (size_t)a->n_parse;
 		size_t start[MAX_THREADS + 1]; start[0] = pos; np = 1;
 		for (size_t k = 1; k < want; k++) {
@@ -532,8 +563,10 @@ static void read_gz(rd_t *r, inflater_t *f)
 				char *j = xmalloc(carry_len + x + 1);
 				memcpy(j, carry, carry_len); memcpy(j + carry_len, g->p, x);
 				const int whole = x == g->len;
-				rc = scan_record(j, 0, carry_len + x, whole && g->eof, last, 0, &rec);
-				if (rc == 1 && !rec.plain) rc = scan_record(j, 0, carry_len + x, whole && g->eof, last, 1, &rec);   /* complete: join its pieces in place */
+				const int use_last = compat_last(last);
+				rc = scan_record(j, 0, carry_len + x, whole && g->eof, use_last, 0, &rec);
+				if (rc == 1 && !rec.plain) rc = scan_record(j, 0, carry_len + x, whole && g->eof, use_last, 1, &rec);   /* complete: join its pieces in place */
+				if (rc == 1 || rc == -2) compat_done(rc, &rec);
 				if (rc == 0 && !whole) { free(j); x = 2 * x < g->len ? 2 * x : g->len; continue; }
 				if (rc == 0) {                                /* longer than this whole block: carry on */
 					free(carry); carry = j; carry_len += x; pos = g->len; break;
@@ -653,6 +686,7 @@ static void *reader_main(void *arg)
 		for (int j = i; j < nf && j < i + ahead; j++)
 			if ((inf[j].z || inf[j].stream) && !inf[j].started) { inf[j].started = 1; pthread_create(&inf[j].th, NULL, inflater_main, &inf[j]); }
 		fprintf(stderr, "Processing file: [%s].\n", a->argv[a->first_file + i]);
+		compat_new_file();
 		if (inf[i].started) { read_gz(&r, &inf[i]); pthread_join(inf[i].th, NULL); if (inf[i].z) munmap((void *)inf[i].z, inf[i].zlen); }
 		else read_plain(&r, fds[i], sizes[i]);
 		if (!inf[i].stream) close(fds[i]);                    /* (gzclose closed a stream's descriptor) */
@@ -798,6 +832,7 @@ static void app_defaults(app_t *a)
 	if (a->wave_bytes < 64) a->wave_bytes = 64;
 	a->seg_min = env_size("DSB_CLI_SEG_KB", (size_t)2 << 20, 10);
 	a->trace = getenv("DSB_CLI_TRACE") != NULL;
+	g_compat.on = getenv("DSB_FASTA_COMPAT") != NULL && atoi(getenv("DSB_FASTA_COMPAT")) != 0;
 	pthread_mutex_init(&a->tr_mu, NULL); pthread_mutex_init(&a->gz_mu, NULL);
 }
 

@@ -1027,11 +1027,12 @@ static size_t arena_layout(DsbSlotArena &a, uint32_t max_len, int group, uint32_
 // fit into `budget` bytes: never fewer than min_slots.  An arena that was sized for a much longer read than the
 // current batch holds (an outlier: one ultra-long read) is given back and rebuilt at the current size.
 static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int want_slots, int min_slots, uint32_t sms_cap, uint32_t anc_cap, uint32_t hit_cap,
-                      int extra_slots, size_t budget, bool exact_cap = false)
+                      int extra_slots, size_t budget, bool exact_cap = false, bool check_only = false)
 {
 	const bool fits = a.base && a.max_len >= max_len && (exact_cap ? a.sms_cap == sms_cap : a.sms_cap >= sms_cap);
 	const bool oversized = a.base && a.max_len > 4 * (uint64_t)max_len + 65536 && a.stride * ((size_t)*cur_slots + extra_slots) > ((size_t)4 << 30);
 	if (fits && !oversized && (*cur_slots >= want_slots || a.max_len > max_len)) return 0;   // (fewer slots than wanted are kept if they were a budget decision for longer reads)
+	if (check_only) return 1;                      // would have to be built: the caller comes again with the memory budget
 	if (a.base && !oversized && a.max_len > max_len) max_len = a.max_len;
 	if (a.base) { hipFree(a.base); a.base = nullptr; budget += a.stride * ((size_t)*cur_slots + extra_slots); }
 	DsbSlotArena n = a;
@@ -1078,13 +1079,24 @@ static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_b
 	uint64_t cap2 = (uint64_t)cap1 * DSB_RETRY_GROW; if (cap2 > DSB_RETRY_MAX_NODES) cap2 = cap1 > DSB_RETRY_MAX_NODES ? cap1 : DSB_RETRY_MAX_NODES;
 	uint32_t anc1 = DSB_ANC_CAP;
 	if (const char *e = getenv("DSB_ANC_CAP_RT")) { anc1 = (uint32_t)atol(e); if (anc1 < 64) anc1 = 64; if (anc1 > DSB_ANC_CAP) anc1 = DSB_ANC_CAP; }   // diagnostics
-	// memory budget: what the device has free now, minus a reserve for the other buffers of this and a sibling context
-	size_t free_b = 0, total_b = 0;
-	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { free_b = (size_t)64 << 30; }
-	const size_t reserve = (size_t)2 << 30;
-	const size_t budget_big = free_b > reserve ? (free_b - reserve) / 4 : 0, budget_main = free_b > reserve ? (free_b - reserve) / 2 : 0;
-	if ((rc = size_arena(c->arena_big, &c->n_slots_big, max_len, DSB_RETRY_SLOTS, 4, (uint32_t)cap2, DSB_RETRY_ANC, DSB_RETRY_HIT, 0, budget_big))) return rc;
-	if ((rc = size_arena(c->arena, &c->n_slots, max_len, want, 64 < want ? 64 : want, cap1, anc1, DSB_HIT_CAP, DSB_HEAVY_SLOTS, budget_main, cap_forced || getenv("DSB_ANC_CAP_RT")))) return rc;
+	// memory budget: what the device has free now, minus a reserve for the other buffers of this and a sibling context.  Asked for
+	// only when an arena has to be (re)built: the query goes to the driver and was seen to wait seconds behind a running kernel.
+	const bool exact = cap_forced || getenv("DSB_ANC_CAP_RT");
+	for (int pass = 0; pass < 2; pass++) {
+		size_t budget_big = 0, budget_main = 0;
+		if (pass) {
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { free_b = (size_t)64 << 30; }
+			const size_t reserve = (size_t)2 << 30;
+			budget_big = free_b > reserve ? (free_b - reserve) / 4 : 0; budget_main = free_b > reserve ? (free_b - reserve) / 2 : 0;
+		}
+		const int r1 = size_arena(c->arena_big, &c->n_slots_big, max_len, DSB_RETRY_SLOTS, 4, (uint32_t)cap2, DSB_RETRY_ANC, DSB_RETRY_HIT, 0, budget_big, false, pass == 0);
+		const int r2 = size_arena(c->arena, &c->n_slots, max_len, want, 64 < want ? 64 : want, cap1, anc1, DSB_HIT_CAP, DSB_HEAVY_SLOTS, budget_main, exact, pass == 0);
+		if (r1 == 1 || r2 == 1) continue;            // (first pass: an arena must be built -- again with the budget)
+		if (r1) return r1;
+		if (r2) return r2;
+		break;
+	}
 	return DSB_OK;
 }
 
@@ -1214,9 +1226,13 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 	s.n_reads = n; s.n_words_total = bit_off; s.total_bases = seq_off; s.total_windows = windows; s.max_len = max_len; s.seed_entries = seed_off;
 	s.min_len = n ? min_len : 0; s.ragged = n && (uint64_t)max_len > (uint64_t)min_len + (min_len >> 3) + 64;
 	int rc;
+	const bool utrace = getenv("DSB_UPLOAD_TRACE") != nullptr;
+	auto uclk = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+	const double u0 = utrace ? uclk() : 0;
 	if ((rc = grow(&s.d_rd, &s.cap_rd, n + 1))) return rc;
 	if ((rc = grow(&s.d_ascii, &s.cap_ascii, (ext_text ? ext_len : (size_t)seq_off) + 64))) return rc;
 	if ((rc = ensure_buffers(c, n, max_len, bin_off, pk_off, bit_off, seed_off))) return rc;
+	if (utrace) fprintf(stderr, "[upload] %zu reads, longest %u, %.2f Gbases: descriptors %.3f s on the host, device buffers checked / grown in %.3f s%s\n", n, max_len, seq_off / 1e9, 0.0, uclk() - u0, s.ragged ? " (ragged: reads sorted by length for the seed scan)" : "");
 	if (n) {
 		HIPCHK(hipMemcpyAsync(s.d_rd, s.h_rd.data(), n * sizeof(DsbReadDesc), hipMemcpyHostToDevice, c->stream));
 		if (s.ragged) {

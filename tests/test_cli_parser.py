@@ -247,3 +247,46 @@ def test_pipe_input(harness, tmp_path):
         assert h.returncode == 0
         got = [tuple(l.split(b"\t")[:3]) for l in out.split(b"\n")[:-1]]
         assert got == exp
+
+
+def test_fasta_compat_matches_the_reference_reader(harness, demo, tmp_path, monkeypatch):
+    """DSB_FASTA_COMPAT=1 reproduces the reference's FASTA record loss (kseq's look-ahead character lives in each of its
+    3 x 5000 kseq_t while the stream is shared, src/cly_mt.c:42-56,545-558, src/lib/utils.c:939-977): the records the
+    reference binary itself reports (SAM_FULL: name and sequence of every read) on FASTA, FASTQ and mixed files, more than
+    5000 records (slots used a second time), more than 10 Mbp per batch, several files (the slots outlive a file) -- are
+    the records the reader delivers with the switch on.  Without it every record is delivered (the documented deviation)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "deSAMBA")
+    if not os.path.exists(ref):
+        pytest.skip("reference binary not built")
+    rnd = random.Random(11)
+    def dna(k):
+        return bytes(rnd.choice(b"ACGT") for _ in range(k))
+    fa_many = b"".join(b">a%d\n%s\n" % (i, dna(rnd.randint(20, 39))) for i in range(16500))            # slots of all three workers used twice
+    big = dna(600000)
+    fa_long = b"".join(b">L%d\n%s\n" % (i, big[i * 1000:i * 1000 + 450000]) for i in range(60))        # batches end at 10 Mbp
+    fq = b"".join(b"@q%d\n%s\n+\n%s\n" % (i, s, b"5" * len(s)) for i, s in enumerate(dna(rnd.randint(20, 39)) for _ in range(7000)))
+    mixed = b"".join(b">m%d\n%s\n" % (i, dna(30)) for i in range(300)) + b"".join(b"@n%d\n%s\n+\n%s\n" % (i, dna(30), b"I" * 30) for i in range(300)) + b"".join(b">o%d\n%s\n" % (i, dna(30)) for i in range(300))
+    files = []
+    for name, blob in (("many.fa", fa_many), ("long.fa", fa_long), ("reads.fq", fq), ("mixed.fa", mixed), ("again.fa", fa_many[:200000].rsplit(b">", 1)[0])):
+        p = tmp_path / name; p.write_bytes(blob); files.append(str(p))
+    out = tmp_path / "ref.sam"
+    subprocess.run([ref, "classify", "-t", "4", "-f", "SAM_FULL", demo["index"]] + files + ["-o", str(out)], check=True, stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+    exp = []
+    for ln in open(out, "rb"):
+        f = ln.rstrip(b"\t\n").split(b"\t")
+        if not (int(f[1]) & 0x900):          # one line per read: unmapped or primary
+            exp.append((f[0], f[9]))
+    n_all = sum(b.count(b">") + (b.count(b"\n@")) + b.startswith(b"@") for b in (open(f, "rb").read() for f in files))
+    assert 0 < len(exp) < n_all              # the reference did lose records
+    monkeypatch.setenv("DSB_FASTA_COMPAT", "1")
+    for cap in (1 << 16, 1 << 24):
+        o = subprocess.run([harness, str(cap)] + files, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+        got = [tuple(l.split(b"\t")[:2]) for l in o.split(b"\n")[:-1]]
+        # reads the reference reverse-complements print their sequence reversed: compare the forward sequence or its reverse complement
+        comp = bytes.maketrans(b"ACGT", b"TGCA")
+        assert len(got) == len(exp), (cap, len(got), len(exp))
+        for (gn, gs), (en, es) in zip(got, exp):
+            assert gn == en and (gs == es or gs.translate(comp)[::-1] == es), (cap, gn, en)
+    monkeypatch.delenv("DSB_FASTA_COMPAT")
+    o = subprocess.run([harness, str(1 << 24)] + files, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+    assert o.count(b"\n") == n_all
