@@ -768,7 +768,7 @@ struct dsb_ctx {
 	size_t cap_wd = 0, cap_bin = 0, cap_pk = 0, cap_bits = 0;
 	DsbReadOut *d_rout = nullptr; DsbHitOut *d_hout = nullptr; size_t cap_rout = 0, cap_hout = 0;
 	unsigned int *d_counters = nullptr;            // u32: [0] work, [1] hits, [2..3] u64 table-1 probes, [4] early work, [6] listed reads, [7] work of the second run, [8] third run list, [9] its work; u64 x 4 at +16 (main launch), +24 (early launch), +32 (second runs): occ, MEM searches, SA lookups, reference bases
-	DsbSlotArena arena; int n_slots = 0;
+	DsbSlotArena arena; int n_slots = 0, n_extra = 0;   // n_extra: slots behind the n_slots of the main launch, for the early launch of the heaviest reads (batches of >= 4096 reads)
 	DsbSlotArena arena_big; int n_slots_big = 0;  // second run of reads that outgrew an arena or their loop budget
 	uint32_t *d_score = nullptr, *d_order = nullptr, *d_heavy = nullptr; size_t cap_score = 0, cap_order = 0, cap_heavy = 0;
 	DsbSeed *d_seeds = nullptr; DsbSeedInfo *d_sinfo = nullptr; size_t cap_seeds = 0, cap_sinfo = 0;   // seed lists of the batch (k_seed_scan)
@@ -1027,26 +1027,28 @@ static size_t arena_layout(DsbSlotArena &a, uint32_t max_len, int group, uint32_
 // fit into `budget` bytes: never fewer than min_slots.  An arena that was sized for a much longer read than the
 // current batch holds (an outlier: one ultra-long read) is given back and rebuilt at the current size.
 static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int want_slots, int min_slots, uint32_t sms_cap, uint32_t anc_cap, uint32_t hit_cap,
-                      int extra_slots, size_t budget, bool exact_cap = false, bool check_only = false)
+                      int extra_slots, size_t budget, bool exact_cap = false, bool check_only = false, int *cur_extra = nullptr)
 {
-	const bool fits = a.base && a.max_len >= max_len && (exact_cap ? a.sms_cap == sms_cap : a.sms_cap >= sms_cap);
-	const bool oversized = a.base && a.max_len > 4 * (uint64_t)max_len + 65536 && a.stride * ((size_t)*cur_slots + extra_slots) > ((size_t)4 << 30);
+	const int have_extra = cur_extra ? *cur_extra : extra_slots;
+	const bool fits = a.base && a.max_len >= max_len && (exact_cap ? a.sms_cap == sms_cap : a.sms_cap >= sms_cap) && have_extra >= extra_slots;
+	const bool oversized = a.base && a.max_len > 4 * (uint64_t)max_len + 65536 && a.stride * ((size_t)*cur_slots + have_extra) > ((size_t)4 << 30);
 	if (fits && !oversized && (*cur_slots >= want_slots || a.max_len > max_len)) return 0;   // (fewer slots than wanted are kept if they were a budget decision for longer reads)
 	if (check_only) return 1;                      // would have to be built: the caller comes again with the memory budget
 	if (a.base && !oversized && a.max_len > max_len) max_len = a.max_len;
-	if (a.base) { hipFree(a.base); a.base = nullptr; budget += a.stride * ((size_t)*cur_slots + extra_slots); }
+	if (a.base) { hipFree(a.base); a.base = nullptr; budget += a.stride * ((size_t)*cur_slots + have_extra); }
 	DsbSlotArena n = a;
 	const size_t stride = arena_layout(n, max_len, 64, sms_cap, anc_cap, hit_cap);
 	int slots = want_slots;
 	while (slots > min_slots && stride * ((size_t)slots + extra_slots) > budget) slots = slots * 3 / 4 > min_slots ? slots * 3 / 4 : min_slots;
+	while (cur_extra && extra_slots > 0 && stride * ((size_t)slots + extra_slots) > budget) extra_slots /= 2;      // (multi-Mbp reads: the early launch gives way last)
 	for (;;) {
 		if (hipMalloc((void **)&n.base, stride * ((size_t)slots + extra_slots)) == hipSuccess) break;
 		(void)hipGetLastError();
 		n.base = nullptr;
-		if (slots <= min_slots) { a.base = nullptr; *cur_slots = 0; return DSB_ENOMEM; }
-		slots = slots / 2 > min_slots ? slots / 2 : min_slots;
+		if (slots <= min_slots && !(cur_extra && extra_slots > 0)) { a.base = nullptr; *cur_slots = 0; if (cur_extra) *cur_extra = 0; return DSB_ENOMEM; }
+		if (slots > min_slots) slots = slots / 2 > min_slots ? slots / 2 : min_slots; else extra_slots /= 2;
 	}
-	a = n; *cur_slots = slots;
+	a = n; *cur_slots = slots; if (cur_extra) *cur_extra = extra_slots;
 	return 0;
 }
 
@@ -1082,6 +1084,9 @@ static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_b
 	// memory budget: what the device has free now, minus a reserve for the other buffers of this and a sibling context.  Asked for
 	// only when an arena has to be (re)built: the query goes to the driver and was seen to wait seconds behind a running kernel.
 	const bool exact = cap_forced || getenv("DSB_ANC_CAP_RT");
+	// the early launch of the heaviest reads (dsb_batch_run) exists for batches of >= 4096 reads: only those pay for its slots
+	int want_extra = (n >= 4096 || getenv("DSB_HEAVY_FIRST")) ? DSB_HEAVY_SLOTS : 0;
+	if (want_extra < c->n_extra) want_extra = c->n_extra;
 	for (int pass = 0; pass < 2; pass++) {
 		size_t budget_big = 0, budget_main = 0;
 		if (pass) {
@@ -1091,7 +1096,7 @@ static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_b
 			budget_big = free_b > reserve ? (free_b - reserve) / 4 : 0; budget_main = free_b > reserve ? (free_b - reserve) / 2 : 0;
 		}
 		const int r1 = size_arena(c->arena_big, &c->n_slots_big, max_len, DSB_RETRY_SLOTS, 4, (uint32_t)cap2, DSB_RETRY_ANC, DSB_RETRY_HIT, 0, budget_big, false, pass == 0);
-		const int r2 = size_arena(c->arena, &c->n_slots, max_len, want, 64 < want ? 64 : want, cap1, anc1, DSB_HIT_CAP, DSB_HEAVY_SLOTS, budget_main, exact, pass == 0);
+		const int r2 = size_arena(c->arena, &c->n_slots, max_len, want, 64 < want ? 64 : want, cap1, anc1, DSB_HIT_CAP, want_extra, budget_main, exact, pass == 0, &c->n_extra);
 		if (r1 == 1 || r2 == 1) continue;            // (first pass: an arena must be built -- again with the budget)
 		if (r1) return r1;
 		if (r2) return r2;
@@ -1357,7 +1362,7 @@ static int batch_run_locked(dsb_ctx *c)
 	if (!dbg && s.n_words_total && !c->seed_only) {
 		const char *hv = getenv("DSB_HEAVY_FIRST");
 		n_heavy = hv ? (unsigned)atoi(hv) : (n >= 4096 ? (unsigned)(n / 64) : 0u);
-		if (n_heavy > DSB_HEAVY_SLOTS) n_heavy = DSB_HEAVY_SLOTS;
+		if (n_heavy > (unsigned)c->n_extra) n_heavy = (unsigned)c->n_extra;
 		if (n_heavy > n / 2) n_heavy = (unsigned)(n / 2);
 	}
 	c->n_early = n_heavy;
@@ -1450,7 +1455,7 @@ static int batch_run_locked(dsb_ctx *c)
 	// the slots the finished launches left free.  counters: [12] listed reads, [13] work counter.  An empty list drains at once.
 	if (dx1.heavy_limit) {
 		DsbDevIndex dxh = dx1; dxh.heavy_limit = 0;
-		unsigned gh = (unsigned)(c->n_slots + DSB_HEAVY_SLOTS); if (gh > 256u) gh = 256u;
+		unsigned gh = (unsigned)(c->n_slots + c->n_extra); if (gh > 256u) gh = 256u;
 		hipLaunchKernelGGL(k_collect_retry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const DsbReadOut *)c->d_rout, (uint32_t)n, c->d_heavy, c->d_counters + 12, DSB_ST_HEAVY, 0);
 		hipLaunchKernelGGL(k_classify_heavy<8>, dim3(gh), dim3(64 * 8), 0, c->stream, dxh, (const DsbReadDesc *)s.d_rd, 0u, (const unsigned int *)(c->d_counters + 12), (const uint32_t *)c->d_heavy, c->d_bin,
 		                   (const uint64_t *)c->d_bits, c->arena, c->d_counters + 13, c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, 0u,

@@ -67,8 +67,8 @@ struct ora_ctx {
 ora_ctx_t *ora_ctx_new(void)
 {
 	ora_ctx_t *c = calloc(1, sizeof *c);
-	c->sa_hash[0] = malloc(sizeof(sah_t) * 0x100000);     /* src/cly_mt.c:540-541 */
-	c->sa_hash[1] = malloc(sizeof(sah_t) * 0x100000);
+	c->sa_hash[0] = malloc(sizeof(sah_t) * 0x1000000);    /* src/cly_mt.c:540-541 has 0x100000 nodes and overruns them for reads > 786432 bases: U7, 2^24 nodes */
+	c->sa_hash[1] = malloc(sizeof(sah_t) * 0x1000000);
 	c->mem_slow = malloc(sizeof(mem_t) * (8 * 800 + 1 + 16));
 	return c;
 }

@@ -26,6 +26,10 @@
  *       small indexes, arbitrary bytes on large ones (found with a read running over the start of its reference).
  *   U4  max_read_l (src/cly.c:2958) is the prefix maximum of read length in
  *       input order (= the reference's `-t 1` behaviour).
+ *   U7  the per-thread 9-mer table of build_hash_table_M2 has room for every read: the reference allocates 2^20 nodes
+ *       (src/cly_mt.c:540-541), a read of L bases takes 2^18 heads + L nodes (src/cly.c:2173-2224), so the stock binary
+ *       writes behind the table for reads longer than 786432 bases.  2^24 nodes here and in the UB-pinned build
+ *       (tests/golden/synth/ultralong.fq.gz: one read of 0.87 Mbp).
  */
 #ifndef DSB_ORACLE_H
 #define DSB_ORACLE_H

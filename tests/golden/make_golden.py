@@ -57,10 +57,49 @@ def kseq():
         run([os.path.join(REF, "deSAMBA"), "classify", "-t", "1", "-f", "SAM_FULL", idx, path, "-o", path + ".full.ref.sam"])
 
 
+def ultralong():
+    """tests/golden/synth/ultralong.fq.gz: ONE read of 0.88 Mbp -- longer than the 786432 bases beyond which the stock
+    reference writes behind its per-thread 9-mer table (2^20 nodes, src/cly_mt.c:540-541; build_hash_table_M2,
+    src/cly.c:2173-2224 needs 2^18 + L) -- made of the four longest demo genomes back to back, each with 12 % errors
+    (numpy PCG64, seed 2026), and the SAM of the UB-pinned build, whose table holds 2^24 nodes (oracle/Makefile U7)."""
+    import gzip
+    import struct
+    import numpy as np
+    idx = os.path.join(DEMO, "index")
+    with open(os.path.join(idx, "deSAMBA.ref_i"), "rb") as f:
+        n = struct.unpack("<Q", f.read(8))[0]
+        refs = [struct.unpack("<QQ", f.read(144)[128:]) for _ in range(n)]
+    with open(os.path.join(idx, "deSAMBA.ref_b"), "rb") as f:
+        nb = struct.unpack("<Q", f.read(8))[0]; txt = np.frombuffer(f.read(nb), dtype=np.uint8)
+    rng = np.random.default_rng(2026)
+    parts = []
+    for (ln, off), take in zip(sorted(refs, reverse=True)[:4], (None, None, None, 100000)):
+        pos = np.arange(off, off + (take or ln), dtype=np.int64)
+        b = (txt[pos >> 2] >> (6 - 2 * (pos & 3))) & 3
+        u = rng.random(len(b))
+        sub = u < 0.05; b = np.where(sub, (b + rng.integers(1, 4, len(b))) & 3, b)
+        keep = ~((u >= 0.05) & (u < 0.09))                               # deletions
+        ins = (u >= 0.09) & (u < 0.12)                                   # an inserted base behind the base
+        out = np.empty(2 * len(b), dtype=np.uint8); out[0::2] = b; out[1::2] = rng.integers(0, 4, len(b))
+        mask = np.empty(2 * len(b), dtype=bool); mask[0::2] = keep; mask[1::2] = ins
+        parts.append(out[mask])
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[np.concatenate(parts)].tobytes()
+    fq = os.path.join(OUT, "ultralong.fq")
+    with open(fq, "wb") as f:
+        f.write(b"@ultralong_%d\n" % len(seq) + seq + b"\n+\n" + b"5" * len(seq) + b"\n")
+    run([os.path.join(REF, "deSAMBA_ubfree"), "classify", "-t", "1", idx, fq, "-o", os.path.join(OUT, "ultralong.ubfree.sam")])
+    with open(fq, "rb") as f, gzip.GzipFile(fq + ".gz", "wb", 9, mtime=0) as g:
+        g.write(f.read())
+    os.remove(fq)
+
+
 def main():
     subprocess.check_call([os.path.join(ROOT, "tools", "make_demo_index.sh"), DEMO])
+    if len(sys.argv) > 1 and sys.argv[1] == "ultralong":
+        return ultralong()
     strain()
     kseq()
+    ultralong()
     idx = os.path.join(DEMO, "index")
     sim = os.path.join(ROOT, "tools", "readsim")
     sets = [("ont20k", 12, 20000, 0.15, 11, "ont"), ("ngs150", 400, 150, 0.01, 12, "ngs"), ("pb", 24, 0, 0.13, 13, "pacbio"),

@@ -50,6 +50,33 @@ def test_synthetic_golden_sam(gpu, name):
     assert sam == open(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"), "rb").read()
 
 
+def test_ultralong_read(gpu, tmp_path):
+    """one read of 0.87 Mbp (longer than the 786432 bases from which the stock reference overruns its 9-mer table,
+    src/cly_mt.c:540-541): through the library and through the CLI from the .gz file, byte-identical to the UB-pinned
+    reference whose table is large enough (oracle/Makefile U7)"""
+    import gzip
+    import subprocess
+    D, idx, ctx = gpu
+    gz = os.path.join(GOLDEN, "synth", "ultralong.fq.gz")
+    exp = open(os.path.join(GOLDEN, "synth", "ultralong.ubfree.sam"), "rb").read()
+    hits, sam = classify_all(D, ctx, D.parse_fastq(gzip.open(gz).read()))
+    assert sam == exp
+    out = tmp_path / "ul.sam"
+    subprocess.run([os.path.join(ROOT, "desamba_amd", "bin", "deSAMBA"), "classify", os.path.join(ROOT, "data", "demo", "index"), gz, "-o", str(out)], check=True, stderr=subprocess.DEVNULL)
+    assert out.read_bytes() == exp
+
+
+def test_cli_fasta_compat_switch(gpu, tmp_path, monkeypatch):
+    """DSB_FASTA_COMPAT=1: the CLI loses the FASTA records the reference loses (every other one on the first use of a
+    kseq_t slot): SAM_FULL == the reference binary's own output for tests/golden/kseq/records.fa"""
+    import subprocess
+    path = os.path.join(GOLDEN, "kseq", "records.fa")
+    monkeypatch.setenv("DSB_FASTA_COMPAT", "1")
+    out = tmp_path / "fa.sam"
+    subprocess.run([os.path.join(ROOT, "desamba_amd", "bin", "deSAMBA"), "classify", "-f", "SAM_FULL", os.path.join(ROOT, "data", "demo", "index"), path, "-o", str(out)], check=True, stderr=subprocess.DEVNULL)
+    assert out.read_bytes() == open(path + ".full.ref.sam", "rb").read()
+
+
 @pytest.mark.parametrize("name", ["heavy", "ont5k_e25", "wrapq"])
 def test_heavy_first_launch(gpu, name, monkeypatch):
     """the early launch of the heaviest reads (second stream, own slots) must not change any result"""

@@ -27,6 +27,18 @@ def test_synthetic_golden(demo, oracle, name, tmp_path):
     assert sam_lines(str(out)) == sam_lines(os.path.join(GOLDEN, "synth", name + ".ubfree.sam"))
 
 
+def test_ultralong_read(demo, oracle, tmp_path):
+    """a read of 0.87 Mbp: beyond the 786432 bases from which the stock reference writes behind its 9-mer table
+    (2^20 nodes for 2^18 + L, src/cly_mt.c:540-541, src/cly.c:2173-2224); the golden SAM is the UB-pinned build's, whose
+    table holds 2^24 nodes (oracle/Makefile U7).  Behaviour of this build: such reads are classified like any other"""
+    import gzip
+    fq = tmp_path / "ultralong.fq"
+    fq.write_bytes(gzip.open(os.path.join(GOLDEN, "synth", "ultralong.fq.gz")).read())
+    out = tmp_path / "ultralong.sam"
+    oracle.classify_file(str(fq), str(out), threads=1)
+    assert sam_lines(str(out)) == sam_lines(os.path.join(GOLDEN, "synth", "ultralong.ubfree.sam"))
+
+
 # (no stock output for `overhang`: the stock binary crashes on it, oracle.h U6)
 @pytest.mark.parametrize("name", [n for n in SETS if n not in ("ngs_e14", "overhang")])
 def test_distance_to_stock_reference(name):
