@@ -614,6 +614,7 @@ static void peek_input(app_t *a)
 	int fd = open(path, O_RDONLY); struct stat st;
 	if (fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) { if (fd >= 0) close(fd); return; }
 	static batch_t pb; int last = 0; uint32_t hist = 0; size_t used = 0, total = 0; int gz = is_gzip(fd);
+	const int compat_on = g_compat.on; g_compat.on = 0;           /* (a look only: the slots of the FASTA quirk are not touched) */
 	char *t = NULL, *buf = NULL; size_t len = 0;
 	if (!gz) {
 		t = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
@@ -653,6 +654,7 @@ static void peek_input(app_t *a)
 	if (t) munmap(t, len);
 	free(buf); close(fd);
 	memset(&a->tr, 0, sizeof a->tr);
+	g_compat.on = compat_on;
 }
 
 static int is_gzip(int fd) { unsigned char m[2] = {0, 0}; return pread(fd, m, 2, 0) == 2 && m[0] == 0x1f && m[1] == 0x8b; }

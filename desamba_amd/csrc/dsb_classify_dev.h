@@ -1646,15 +1646,34 @@ template <class P8> struct SdpArgsT { uint32_t q_bg, q_ed; P8 q_base, t_str; int
 
 // one window position q_pos holding the 9-mer of reference position i: the two exact-match extensions and,
 // if the match qualifies, the node (src/cly.c:2390-2436)
+// MEM_search whose first eight bases have been compared already (x0 = XOR of the two first words): both extensions of a
+// candidate start with loads that do not depend on each other, so sdp_emit issues them together -- one round trip instead of two
+template <class P8>
+DV int MEM_search_from(P8 q, P8 t, bool forward, int max, uint64_t x0)
+{
+	int len = 0;
+	if (max <= 0) return 0;
+	if (x0) len = forward ? (int)(__builtin_ctzll(x0) >> 3) : (int)(__builtin_clzll(x0) >> 3);
+	else {
+		len = 8;
+		if (forward) {
+			while (len < max) { uint64_t x = ld_u64(q + len) ^ ld_u64(t + len); if (x) { len += (int)(__builtin_ctzll(x) >> 3); break; } len += 8; }
+		} else {
+			while (len < max) { uint64_t x = ld_u64(q - len - 7) ^ ld_u64(t - len - 7); if (x) { len += (int)(__builtin_clzll(x) >> 3); break; } len += 8; }
+		}
+	}
+	return len < max ? len : max;
+}
 template <bool FWD, bool WRITE, class P8>
 DV void sdp_emit(const SdpArgsT<P8> &a, int i, P8 c_t, uint32_t q_pos, DsbSms *out, uint32_t out_cap, uint32_t &cnt)
 {
+	const uint64_t xb = ld_u64(AQ(a, q_pos - 1) - 7) ^ ld_u64(c_t - 1 - 7), xf = ld_u64(AQ(a, q_pos + 9)) ^ ld_u64(c_t + 9);
 	if (FWD) {
-		int back_len = MEM_search<P8>(AQ(a, q_pos - 1), c_t - 1, false, 4);
+		int back_len = MEM_search_from<P8>(AQ(a, q_pos - 1), c_t - 1, false, 4, xb);
 		if (back_len < 4 || i == 4) {
 			uint32_t max_search = a.q_ed - q_pos - 1;
 			max_search = MINV(max_search, a.t_len - i - 1) + 50;
-			int fwd = MEM_search<P8>(AQ(a, q_pos + 9), c_t + 9, true, max_search);
+			int fwd = MEM_search_from<P8>(AQ(a, q_pos + 9), c_t + 9, true, (int)max_search, xf);
 			int total = back_len + fwd + 1;
 			if (total >= 4) {
 				if (WRITE && cnt < out_cap) { DsbSms *p = out + cnt; p->len = total; p->q_pos = q_pos - back_len; p->t_pos = i - back_len + a.t_st; }
@@ -1662,11 +1681,11 @@ DV void sdp_emit(const SdpArgsT<P8> &a, int i, P8 c_t, uint32_t q_pos, DsbSms *o
 			}
 		}
 	} else {
-		int fwd = MEM_search<P8>(AQ(a, q_pos + 9), c_t + 9, true, 4);
+		int fwd = MEM_search_from<P8>(AQ(a, q_pos + 9), c_t + 9, true, 4, xf);
 		if (fwd < 4 || i == 4) {
 			uint32_t max_search = q_pos;
 			max_search = MINV((long)max_search, (long)(c_t - a.t_str)) + 50;
-			int back_len = MEM_search<P8>(AQ(a, q_pos - 1), c_t - 1, false, max_search);
+			int back_len = MEM_search_from<P8>(AQ(a, q_pos - 1), c_t - 1, false, (int)max_search, xb);
 			int total = back_len + fwd + 1;
 			if (total >= 4) {
 				if (WRITE && cnt < out_cap) { DsbSms *p = out + cnt; p->len = total; p->q_pos = q_pos - back_len; p->t_pos = (uint32_t)((long)(c_t - a.t_str) - back_len + a.t_st); }
@@ -1675,25 +1694,29 @@ DV void sdp_emit(const SdpArgsT<P8> &a, int i, P8 c_t, uint32_t q_pos, DsbSms *o
 		}
 	}
 }
+// the ten reference bytes a probed position's 9-mer is made of (loaded one group of positions ahead by sdp_match_t)
+struct SdpRef { uint64_t v; uint32_t t8, t9; };
+template <bool FWD, class P8>
+DV P8 sdp_ct(const SdpArgsT<P8> &a, int i) { return FWD ? a.t_str + i : a.t_str + (a.t_len - 9 - 4) - (i - 4); }
+template <bool FWD, class P8>
+DV SdpRef sdp_ref_load(const SdpArgsT<P8> &a, int i)
+{
+	P8 c_t = sdp_ct<FWD, P8>(a, i);
+	SdpRef r; r.v = ld_u64(c_t); r.t8 = c_t[8]; r.t9 = FWD ? 0u : (uint32_t)c_t[9];
+	return r;
+}
 template <bool FWD, bool WRITE, class P8>
-DV uint32_t sdp_visit(uint32_t &lsteps, const uint32_t step_limit, int &st, const SdpArgsT<P8> &a, int i, DsbSms *out, uint32_t out_cap)
+DV uint32_t sdp_visit(uint32_t &lsteps, const uint32_t step_limit, int &st, const SdpArgsT<P8> &a, int i, const SdpRef rf, DsbSms *out, uint32_t out_cap)
 {
 	uint32_t cnt = 0;
-	P8 c_t; uint64_t kmer = 0;
-	if (FWD) {
-		c_t = a.t_str + i;
-		uint64_t v = ld_u64(c_t);
+	P8 c_t = sdp_ct<FWD, P8>(a, i); uint64_t kmer = 0;
+	{
+		const uint64_t v = rf.v;
 #pragma unroll
 		for (int j = 0; j < 8; j++) kmer |= ((v >> (8 * j)) & 0xffULL) << (16 - 2 * j);
-		kmer |= (uint64_t)c_t[8];
-		kmer &= 0x3FFFFULL;
-	} else {
-		c_t = a.t_str + (a.t_len - 9 - 4) - (i - 4);
-		uint64_t v = ld_u64(c_t);
-#pragma unroll
-		for (int j = 0; j < 8; j++) kmer |= ((v >> (8 * j)) & 0xffULL) << (16 - 2 * j);
-		kmer |= (uint64_t)c_t[8];
-		if (i > 4) kmer |= (uint64_t)(c_t[9] >> 2);
+		kmer |= (uint64_t)rf.t8;
+		if (FWD) kmer &= 0x3FFFFULL;
+		else if (i > 4) kmer |= (uint64_t)(rf.t9 >> 2);
 	}
 	// collect the window positions holding this 9-mer, then visit them in ascending order (= the reference's
 	// chain order).  A 9-mer with pad bits set (>= 2^18) matches nothing.
@@ -1740,10 +1763,14 @@ DN uint32_t sdp_match_t(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms)
 	// the context lives in memory (it is shared by reference with non-inlined callers): work on copies
 	const int lane = DSB_LANE; uint32_t *const red = w.red; DsbSms *const sms = w.sms; const uint32_t sms_cap = w.x->sms_cap;
 	uint32_t lsteps = w.lsteps, mirror_bad = 0; int st = 0; const uint32_t step_limit = w.step_limit;
+	SdpRef nxt; nxt.v = 0; nxt.t8 = nxt.t9 = 0;
+	if ((uint32_t)lane < n_pos) nxt = sdp_ref_load<FWD, P8>(a, 4 + 4 * lane);
 	for (uint32_t g = 0; g < n_pos; g += DSB_WAVE) {
 		uint32_t pI = g + lane; bool valid = pI < n_pos; int i = 4 + 4 * (int)pI;
+		const SdpRef cur = nxt;
+		if (pI + DSB_WAVE < n_pos) nxt = sdp_ref_load<FWD, P8>(a, i + 4 * DSB_WAVE);      // the next group's reference bytes travel while this group is worked on
 		DsbSms keep[DSB_SDP_KEEP];
-		uint32_t cnt = valid ? sdp_visit<FWD, true, P8>(lsteps, step_limit, st, a, i, keep, DSB_SDP_KEEP) : 0;
+		uint32_t cnt = valid ? sdp_visit<FWD, true, P8>(lsteps, step_limit, st, a, i, cur, keep, DSB_SDP_KEEP) : 0;
 		uint32_t total, off = grp_excl_scan_u(red, lane, cnt, &total);
 		if (total == 0) continue;
 		if (n_sms + total > sms_cap) { st |= DSB_ST_SMS_OVF; break; }
@@ -1754,7 +1781,7 @@ DN uint32_t sdp_match_t(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms)
 				// the first 64 nodes of the list are mirrored in LDS for the in-register DP of sdp_middle_M2
 				if (a.lnodes && n_sms + off + k < 64u) { uint4 r; r.x = keep[k].t_pos; r.y = keep[k].q_pos; r.z = keep[k].len; r.w = 0; a.lnodes[n_sms + off + k] = r; }
 			}
-		} else sdp_visit<FWD, true, P8>(lsteps, step_limit, st, a, i, dst, 0xffffffffu);
+		} else sdp_visit<FWD, true, P8>(lsteps, step_limit, st, a, i, cur, dst, 0xffffffffu);
 		if (a.lnodes && dsb_ballot64(cnt > DSB_SDP_KEEP)) mirror_bad = 0x80000000u;
 		n_sms += total;
 		wave_sync();

@@ -1105,24 +1105,6 @@ static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_b
 	return DSB_OK;
 }
 
-// Host threads worth starting: the CPUs this process may run on, capped by the CPU quota of its control group
-// (a container that sees 256 CPUs may be allowed the time of 16 of them: more runnable threads than that only take turns).
-extern "C" int dsb_host_cpus(void)
-{
-	static int cached = 0;
-	if (cached) return cached;
-	cpu_set_t set; int n = 1;
-	if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
-	FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
-	if (f) {
-		char q[64] = {0}; long period = 0;
-		if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) { long v = (atol(q) + period - 1) / period; if (v >= 1 && v < n) n = (int)v; }
-		fclose(f);
-	}
-	if (n < 1) n = 1;
-	return cached = n;
-}
-
 // The sequences of a batch lie wherever the caller keeps its reads (the kseq_t of the reference's batch, src/cly_mt.c:42-56;
 // the mapped input file of the CLI).  The device wants them back to back: destination chunk by destination chunk, a few
 // host threads copy the pieces of the reads that fall into a chunk into pinned memory and send the chunk on a stream of

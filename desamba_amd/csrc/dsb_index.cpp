@@ -5,6 +5,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <thread>
+#include <sched.h>
+#include <vector>
 #include "dsb_host.h"
 
 struct dsb_index { DsbHostIndex h; };
@@ -19,6 +22,24 @@ static FILE *open_ext(const char *dir, const char *ext)
 	if (!f) fprintf(stderr, "[desamba_amd] cannot open %s\n", path);
 	return f;
 }
+// Host threads worth starting: the CPUs this process may run on, capped by the CPU quota of its control group
+// (a container that sees 256 CPUs may be allowed the time of 16 of them: more runnable threads than that only take turns).
+extern "C" int dsb_host_cpus(void)
+{
+	static int cached = 0;
+	if (cached) return cached;
+	cpu_set_t set; int n = 1;
+	if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+	FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+	if (f) {
+		char q[64] = {0}; long period = 0;
+		if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) { long v = (atol(q) + period - 1) / period; if (v >= 1 && v < n) n = (int)v; }
+		fclose(f);
+	}
+	if (n < 1) n = 1;
+	return cached = n;
+}
+
 static bool rd(void *p, size_t sz, size_t n, FILE *f) { return fread(p, sz, n, f) == n; }
 #define FAIL(code) do { if (f) fclose(f); dsb_index_close(x); return (code); } while (0)
 
@@ -79,23 +100,39 @@ extern "C" int dsb_index_open(const char *dir, dsb_index **out)
 		h.fm_sb = (uint64_t *)calloc(h.n_fm_sb * 5, 8);
 		if (!h.fm_sb) { free(raw); FAIL(DSB_ENOMEM); }
 	}
-	for (uint64_t b = 0; b < n_blk256; b++) {
-		const uint8_t *blk = raw + b * 168;
-		uint64_t cnt[5]; memcpy(cnt, blk, 40);
-		for (int hblk = 0; hblk < 2; hblk++) {
-			const uint64_t bi = b * 2 + hblk;
-			DsbFmBlock &o = h.fm[bi];
-			uint64_t *sb = rank64 ? h.fm_sb + (bi >> 15) * 5 : NULL;
-			if (sb && (bi & 32767u) == 0) { for (int c = 0; c < 4; c++) sb[c] = cnt[c]; sb[4] = cnt[0] + cnt[1] + cnt[2] + cnt[3]; }
-			for (int c = 0; c < 4; c++) o.cnt[c] = (uint32_t)(cnt[c] - (sb ? sb[c] : 0));
-			for (int i = 0; i < 128; i++) {
-				int s = hblk * 128 + i;
-				uint8_t sym = (blk[40 + (s >> 1)] >> ((s & 1) * 4)) & 0xf;
-				int w = i >> 6; uint64_t bit = 1ULL << (i & 63);
-				if (sym < 4) { if (sym & 1) o.p0[w] |= bit; if (sym & 2) o.p1[w] |= bit; cnt[sym]++; }
-				else { o.sp[w] |= bit; if (sym == 5) { o.p0[w] |= bit; h.dollar_row = b * 256 + s; } else cnt[4]++; }
+	// (every reference block carries its own cumulative counts: the blocks are re-laid-out independently, on all host threads --
+	// a BWT of 4.4 G rows takes 20 s on one)
+	auto relayout = [&](uint64_t b0, uint64_t b1) {
+		for (uint64_t b = b0; b < b1; b++) {
+			const uint8_t *blk = raw + b * 168;
+			uint64_t cnt[5]; memcpy(cnt, blk, 40);
+			for (int hblk = 0; hblk < 2; hblk++) {
+				const uint64_t bi = b * 2 + hblk;
+				DsbFmBlock &o = h.fm[bi];
+				// (the superblock entry belongs to the first block of the superblock, which is the first half of a reference block)
+				uint64_t sbv[5] = {0, 0, 0, 0, 0};
+				if (rank64) {
+					if ((bi & 32767u) == 0) { uint64_t *sb = h.fm_sb + (bi >> 15) * 5; for (int c = 0; c < 4; c++) sb[c] = cnt[c]; sb[4] = cnt[0] + cnt[1] + cnt[2] + cnt[3]; }
+					const uint8_t *b0p = raw + ((bi >> 15 << 15) >> 1) * 168; uint64_t c0[5]; memcpy(c0, b0p, 40);
+					for (int c = 0; c < 4; c++) sbv[c] = c0[c];
+				}
+				for (int c = 0; c < 4; c++) o.cnt[c] = (uint32_t)(cnt[c] - sbv[c]);
+				for (int i = 0; i < 128; i++) {
+					int s = hblk * 128 + i;
+					uint8_t sym = (blk[40 + (s >> 1)] >> ((s & 1) * 4)) & 0xf;
+					int w = i >> 6; uint64_t bit = 1ULL << (i & 63);
+					if (sym < 4) { if (sym & 1) o.p0[w] |= bit; if (sym & 2) o.p1[w] |= bit; cnt[sym]++; }
+					else { o.sp[w] |= bit; if (sym == 5) { o.p0[w] |= bit; h.dollar_row = b * 256 + s; } else cnt[4]++; }
+				}
 			}
 		}
+	};
+	{
+		int T = dsb_host_cpus(); if (T > 32) T = 32; if ((uint64_t)T > n_blk256 / 4096 + 1) T = (int)(n_blk256 / 4096 + 1);
+		std::vector<std::thread> th;
+		for (int t = 1; t < T; t++) th.emplace_back(relayout, n_blk256 * t / T, n_blk256 * (t + 1) / T);
+		relayout(0, n_blk256 / T);
+		for (std::thread &x_ : th) x_.join();
 	}
 	free(raw);
 	// ---- .acg is only a LUT for the reference's nibble counting; popcount replaces it (not loaded)
