@@ -5,6 +5,8 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench, desamba_amd as D
+import __graft_entry__ as G
+G.demo_dir()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 mib = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 L = 50000
