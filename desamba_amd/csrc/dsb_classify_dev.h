@@ -57,10 +57,21 @@
 #endif
 // stage timers (100 MHz ticks), accumulated per slot when DSB_DEBUG is set
 #define TICK(w, k) do { if ((w).dbg) { uint64_t _t = DSB_CLOCK(); (w).tacc[k] += _t - (w).tlast; (w).tlast = _t; } } while (0)
+// the fine timers sit inside the per-node loops of the extensions: compiled in only with -DDSB_TIMERS (DSB_HIPCC_FLAGS=-DDSB_TIMERS
+// python -c "import __graft_entry__ as g; g.build()"): even a test of w.dbg per hook costs an LDS round trip there
+#ifdef DSB_TIMERS
 #define SUB0(w) do { if ((w).dbg) (w).tsub = DSB_CLOCK(); } while (0)
 #define SUB1(w, k) do { if ((w).dbg) (w).tacc[k] += DSB_CLOCK() - (w).tsub; } while (0)
 #define TX0(w, v) uint64_t v = (w).dbg ? DSB_CLOCK() : 0
 #define TX1(w, k, v) do { if ((w).dbg) (w).tx[k] += DSB_CLOCK() - (v); } while (0)
+#define TXC(w, k) do { if ((w).dbg) (w).tx[k] += 1; } while (0)
+#else
+#define SUB0(w) do { } while (0)
+#define SUB1(w, k) do { } while (0)
+#define TX0(w, v) do { } while (0)
+#define TX1(w, k, v) do { } while (0)
+#define TXC(w, k) do { } while (0)
+#endif
 #define MARK(w, code) do { if ((w).dbg && DSB_LANE == 0) { (w).dbg[0] = (code); (w).dbg[1] = (w).steps; } } while (0)
 #define DSB_WTAB_SLOTS 3072u     /* 12 KB of LDS: <= 2048 window positions, load factor <= 0.67 */
 #define DSB_WTAB_MAXQ 2048u
@@ -2240,11 +2251,14 @@ DN void sdp_batch_old_mw(DsbMw *mw, uint4 *ring, uint32_t *red, const int lane, 
 #endif
 // best predecessor score of node `cur` (right/left extension), through the batch
 template <int MODE>
-DV int sdp_best_pred_b(WCtxL &w, DpBatchL &b, const DsbSms &cs, int32_t cur, const NodeBlock &nb)
+DV int sdp_best_pred_b(WCtxL &w, DpBatchL &b, const DsbSms &cs, int32_t cur, const NodeBlock &nb, const uint32_t n_sms, uint4 *const ring, uint32_t &steps, uint32_t &bn0, uint32_t &bK)
 {
-	if ((uint32_t)cur < b.n0 || (uint32_t)cur >= b.n0 + b.K) {
-		b.n0 = (uint32_t)cur; b.K = MINV((uint32_t)DSB_DPB, w.n_sms - (uint32_t)cur);
-		for (uint32_t j = 0; j < b.K; j++) {
+	// (the extension loops keep the list length, the ring, the loop budget and the bounds of the current batch in registers: this
+	// runs per node, and every w.field is an LDS round trip)
+	if ((uint32_t)cur < bn0 || (uint32_t)cur >= bn0 + bK) {
+		bn0 = (uint32_t)cur; bK = MINV((uint32_t)DSB_DPB, n_sms - (uint32_t)cur);
+		b.n0 = bn0; b.K = bK;
+		for (uint32_t j = 0; j < bK; j++) {
 			const uint32_t idx = (uint32_t)cur + j;
 #if DSB_GROUP == 64 && !defined(DSB_HOST_EMU)
 			// the block of 64 nodes the caller holds in its lanes (node_get) has most of them: no load
@@ -2258,7 +2272,7 @@ DV int sdp_best_pred_b(WCtxL &w, DpBatchL &b, const DsbSms &cs, int32_t cur, con
 			b.nd_t[j] = g_.t_pos; b.nd_q[j] = g_.q_pos; b.nd_l[j] = g_.len;
 		}
 #ifndef DSB_HOST_EMU
-		if (w.mw && b.n0 >= DSB_MW_MIN_PREDS) {
+		if (w.mw && bn0 >= DSB_MW_MIN_PREDS) {
 			// several wavefronts on this read: wake the helpers for the pass over the old predecessors
 			DsbMw *mw = w.mw;
 			if (DSB_LANE < DSB_DPB) { const int sj = (uint32_t)DSB_LANE < b.K ? DSB_LANE : 0; mw->nd_t[DSB_LANE] = b.nd_t[sj]; mw->nd_q[DSB_LANE] = b.nd_q[sj]; mw->nd_l[DSB_LANE] = b.nd_l[sj]; }
@@ -2270,18 +2284,21 @@ DV int sdp_best_pred_b(WCtxL &w, DpBatchL &b, const DsbSms &cs, int32_t cur, con
 			for (uint32_t j = 0; j < DSB_DPB; j++) { int m = -2147483647 - 1; for (int u = 0; u < w.n_waves; u++) m = MAXV(m, mw->best[u][j]); b.old_best[j] = j < b.K ? m : 0; }
 		} else
 #endif
-		{ TX0(w, t_o); sdp_batch_old<MODE>(w, b); TX1(w, 2, t_o); if (w.dbg) w.tx[6] += 1; }
+		{ TX0(w, t_o); sdp_batch_old<MODE>(w, b); TX1(w, 2, t_o); TXC(w, 6); }
+		// once per batch: a read whose DP went quadratic is handed over (DSB_HEAVY_CHECK spent the budget) or gets issue priority
+		if (w.status & DSB_ST_HEAVY) steps = w.step_limit;
+		DSB_BOOST_IF_HEAVY(w);
 	}
 	int best = (int)cs.len; bool cut = false;
 	uint32_t lim_q, lim_t; sdp_limits<MODE>(cs, lim_q, lim_t);
 	// in-batch predecessors (at most DSB_DPB - 1, all in the ring), newest first: one per lane; the newest that meets the
 	// distance cut ends the scan -- lanes beyond it do not count
-	const int32_t m = cur - (int32_t)b.n0;
+	const int32_t m = cur - (int32_t)bn0;
 	for (int32_t base = 0; base < m && !cut; base += DSB_WAVE) {
 		const int32_t l = base + DSB_LANE; const bool valid = l < m;
 		bool skip = true, brk = false; int ns = 0;
 		if (valid) {
-			uint4 r = ring_ld(w.ring, (uint32_t)(cur - 1 - l) & (DSB_RING - 1)); DsbSms ps; ps.t_pos = r.x; ps.q_pos = r.y; ps.len = r.z; ps.score = r.w;
+			uint4 r = ring_ld(ring, (uint32_t)(cur - 1 - l) & (DSB_RING - 1)); DsbSms ps; ps.t_pos = r.x; ps.q_pos = r.y; ps.len = r.z; ps.score = r.w;
 			sdp_judge<MODE>(cs, ps, lim_q, lim_t, skip, brk, ns);
 		}
 		const int fb = grp_first(w.red, DSB_LANE, valid && !skip && brk);
@@ -2290,7 +2307,7 @@ DV int sdp_best_pred_b(WCtxL &w, DpBatchL &b, const DsbSms &cs, int32_t cur, con
 		if (mx > best) best = mx;
 		if (fb < DSB_WAVE) cut = true;
 	}
-	int ob = b.old_best[cur - (int32_t)b.n0];
+	int ob = b.old_best[cur - (int32_t)bn0];
 	if (!cut && ob > best) best = ob;
 	return best;
 }
@@ -2628,14 +2645,16 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 	uint32_t best_t = c_h->t_ed, best_q = c_h->q_ed, best_len = (uint32_t)(1 - 9);     // fields of node max_sms_id
 	NodeBlock nb; nb.base = 0; nb.valid = 0;
 	DpBatchL &db = *w.dpb; db.n0 = 0; db.K = 0;
+	uint32_t bn0 = 0, bK = 0;                                 // the bounds of the batch in db
 	uint32_t current_sms = 1;
 	uint64_t t_offset_global = x->refinfo[c_h->ref_ID].seq_offset, t_length = x->refinfo[c_h->ref_ID].seq_l;
 	uint32_t c_t_offset = c_h->t_ed - 3;
 	int last_search = false;
+	// loop state in registers (the context is in LDS: a round trip per access, and this loop runs per match node)
+	uint32_t steps = w.steps, n_sms = 1; const uint32_t step_limit = w.step_limit; DsbSms *const sms = w.sms; uint4 *const ring = w.ring;
 	while (1) {
-		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
-		DSB_BOOST_IF_HEAVY(w);
-		if (w.n_sms == current_sms) {
+		if (++steps > step_limit) { w.status |= DSB_ST_TIMEOUT; break; }
+		if (n_sms == current_sms) {
 			uint32_t next_step = t_length - c_t_offset;
 			if (next_step < 12) break;
 			uint32_t max_search_ref;
@@ -2648,7 +2667,7 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 			TX0(w, t_r);
 			get_ref_wave(x->refbin, x->ref_bases, DSB_LANE, ref, c_t_offset + t_offset_global, max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50);
 			wave_sync();
-			TX1(w, 3, t_r); if (w.dbg) w.tx[7] += 1;
+			TX1(w, 3, t_r); TXC(w, 7);
 			int search_q_ed = (int)best_q + 1000;
 			search_q_ed = MINV((uint32_t)search_q_ed, l_read);
 			int search_q_st = MAXV((uint32_t)(search_q_ed - 2000), c_h->q_st - 8);
@@ -2656,34 +2675,37 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 			sdp_match(w, search_q_st, search_q_ed, q_str, ref, max_search_ref, key_len, tbl, c_t_offset, true);
 			SUB1(w, 10);
 			c_t_offset += max_search_ref - 9 - 3;
-			if (w.n_sms == current_sms) break;
+			n_sms = w.n_sms;
+			if (n_sms == current_sms) break;
 			nb.valid = 0;
 			if (node_get(w, nb, current_sms).t_pos > best_t + 1000) break;
 		}
-		DsbSms *c_sms = w.sms + current_sms;
+		DsbSms *c_sms = sms + current_sms;
 		TX0(w, t_g);
 		DsbSms cs = node_get(w, nb, current_sms); current_sms++;
 		TX1(w, 5, t_g);
 		SUB0(w);
-		int max_score = sdp_best_pred_b<1>(w, db, cs, (int32_t)current_sms - 1, nb);
+		int max_score = sdp_best_pred_b<1>(w, db, cs, (int32_t)current_sms - 1, nb, n_sms, ring, steps, bn0, bK);
 		SUB1(w, 11);
-		if (w.dbg) w.tx[8] += 1;
+		TXC(w, 8);
 		TX0(w, t_s);
 		c_sms->score = max_score;
-		ring_put(w, current_sms - 1, cs.t_pos, cs.q_pos, cs.len, (uint32_t)max_score);
+		{ uint4 r_; r_.x = cs.t_pos; r_.y = cs.q_pos; r_.z = cs.len; r_.w = (uint32_t)max_score; ring_st(ring, (current_sms - 1) & (DSB_RING - 1), r_); }
 		TX1(w, 4, t_s);
 		SUB0(w);
 		bool comb = (int)cs.len >= 8 && combine_chain(c_st, chain_ID, sc_hash, cs.t_pos - cs.q_pos, false, cs.q_pos, &combined) == true;
 		SUB1(w, 12);
 		if (comb) {
 			int c_len = cs.len;
+			w.steps = steps;
 			total_max_score = MAXV(score_ori, max_score) - c_len + sdp_middle_M2(w, combined->cur, q_str, tbl, key_len);
+			steps = w.steps;
 			score_ori = total_max_score; max_sms_id = 0;
 			w.n_sms = 0;
-			p = push_sms(w);
+			p = push_sms(w); n_sms = 1;
 			p->score = total_max_score; p->q_pos = c_h->q_ed; p->t_pos = c_h->t_ed; p->len = -9;
 			ring_put(w, 0, p->t_pos, p->q_pos, p->len, p->score);
-			best_t = c_h->t_ed; best_q = c_h->q_ed; best_len = (uint32_t)(-9); nb.valid = 0; db.K = 0;
+			best_t = c_h->t_ed; best_q = c_h->q_ed; best_len = (uint32_t)(-9); nb.valid = 0; db.K = 0; bK = 0;
 			current_sms = 1;
 			c_t_offset = c_h->t_ed;
 			continue;
@@ -2691,6 +2713,7 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 		if (total_max_score < max_score) { total_max_score = max_score; max_sms_id = current_sms - 1; best_t = cs.t_pos; best_q = cs.q_pos; best_len = cs.len; }
 		if (cs.t_pos > best_t + 1000) break;
 	}
+	w.steps = steps;
 	c_h->q_ed = best_q + best_len + 9;
 	c_h->t_ed = best_t + best_len + 9;
 	return total_max_score - 10000;
@@ -2713,14 +2736,15 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 	uint32_t best_t = c_h->t_st, best_q = c_h->q_st;                       // fields of node max_sms_id
 	NodeBlock nb; nb.base = 0; nb.valid = 0;
 	DpBatchL &db = *w.dpb; db.n0 = 0; db.K = 0;
+	uint32_t bn0 = 0, bK = 0;
 	uint32_t current_sms = 1;
 	uint64_t t_offset_global = x->refinfo[c_h->ref_ID].seq_offset;
 	uint32_t c_t_offset = c_h->t_st + 3;
 	int last_search = false;
+	uint32_t steps = w.steps, n_sms = 1; const uint32_t step_limit = w.step_limit; DsbSms *const sms = w.sms; uint4 *const ring = w.ring;   // (as in sdp_right_M2)
 	while (1) {
-		if (SPENT(w)) { w.status |= DSB_ST_TIMEOUT; break; }
-		DSB_BOOST_IF_HEAVY(w);
-		if (w.n_sms == current_sms) {
+		if (++steps > step_limit) { w.status |= DSB_ST_TIMEOUT; break; }
+		if (n_sms == current_sms) {
 			uint32_t next_step = c_t_offset;
 			if (next_step < 12) break;
 			uint32_t max_search_ref;
@@ -2742,26 +2766,29 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 			sdp_match(w, search_q_st, search_q_ed, q_str, ref + 50, max_search_ref, key_len, tbl, c_t_offset - max_search_ref, false);
 			SUB1(w, 10);
 			c_t_offset = c_t_offset - max_search_ref + 9 + 3;
-			if (w.n_sms == current_sms) break;
+			n_sms = w.n_sms;
+			if (n_sms == current_sms) break;
 			nb.valid = 0;
 			if (node_get(w, nb, current_sms).t_pos + 1000 < best_t) break;
 		}
-		DsbSms *c_sms = w.sms + current_sms;
+		DsbSms *c_sms = sms + current_sms;
 		DsbSms cs = node_get(w, nb, current_sms); current_sms++;
 		SUB0(w);
-		int max_score = sdp_best_pred_b<2>(w, db, cs, (int32_t)current_sms - 1, nb);
+		int max_score = sdp_best_pred_b<2>(w, db, cs, (int32_t)current_sms - 1, nb, n_sms, ring, steps, bn0, bK);
 		SUB1(w, 11);
 		c_sms->score = max_score;
-		ring_put(w, current_sms - 1, cs.t_pos, cs.q_pos, cs.len, (uint32_t)max_score);
+		{ uint4 r_; r_.x = cs.t_pos; r_.y = cs.q_pos; r_.z = cs.len; r_.w = (uint32_t)max_score; ring_st(ring, (current_sms - 1) & (DSB_RING - 1), r_); }
 		if ((int)cs.len >= 8 && combine_chain(c_st, chain_ID, sc_hash, cs.t_pos - cs.q_pos, true, cs.q_pos + cs.len, &combined) == true) {
 			int c_len = cs.len;
+			w.steps = steps;
 			total_max_score = MAXV(score_ori, max_score) - c_len + sdp_middle_M2(w, combined->cur, q_str, tbl, key_len);
+			steps = w.steps;
 			score_ori = total_max_score; max_sms_id = 0;
 			w.n_sms = 0;
-			p = push_sms(w);
+			p = push_sms(w); n_sms = 1;
 			p->score = total_max_score; p->q_pos = c_h->q_st; p->t_pos = c_h->t_st;
 			ring_put(w, 0, p->t_pos, p->q_pos, 0, p->score);
-			best_t = c_h->t_st; best_q = c_h->q_st; nb.valid = 0; db.K = 0;
+			best_t = c_h->t_st; best_q = c_h->q_st; nb.valid = 0; db.K = 0; bK = 0;
 			current_sms = 1;
 			c_t_offset = c_h->t_st;
 			continue;
@@ -2769,6 +2796,7 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 		if (total_max_score < max_score) { total_max_score = max_score; max_sms_id = current_sms - 1; best_t = cs.t_pos; best_q = cs.q_pos; }
 		if (cs.t_pos + 1000 < best_t) break;
 	}
+	w.steps = steps;
 	c_h->q_st = best_q;
 	c_h->t_st = best_t;
 	return total_max_score - 10000;
