@@ -425,7 +425,7 @@ def main():
     ap.add_argument("--index-mbp", type=int, default=320, help="size of the synthetic strain collection of the headline index")
     ap.add_argument("--headline", choices=["strain", "demo"], default="strain", help="profiling runs: `demo` puts the reference's demo index in the headline position (nothing is built)")
     ap.add_argument("--cpu-sample", type=int, default=8192)
-    ap.add_argument("--t1-sample", type=int, default=384, help="reads of the stock reference's -t 1 vs -t N self-comparison (0 = skip)")
+    ap.add_argument("--t1-sample", type=int, default=1024, help="reads of the stock reference's -t 1 vs -t N self-comparison (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-cli", action="store_true", help="skip the runs of the deSAMBA binary (cli_end_to_end)")
@@ -433,7 +433,7 @@ def main():
     ap.add_argument("--no-demo-index", action="store_true", help="skip the measurements on the reference's demo index")
     ap.add_argument("--demo-batches", type=int, default=8)
     ap.add_argument("--demo-steps", type=int, default=8)
-    ap.add_argument("--demo-cli-reads", type=int, default=262144)
+    ap.add_argument("--demo-cli-reads", type=int, default=524288)
     ap.add_argument("--no-short-reads", action="store_true", help="skip the 1 M x 150 bp measurement (BASELINE configs[2] shape)")
     ap.add_argument("--no-seed-hbm", action="store_true", help="skip the seed-lookup measurement on synthetic multi-GiB filter tables")
     ap.add_argument("--seed-hbm-mib", type=int, default=2048, help="size of each synthetic filter table (MiB, power of two 128 .. 16384)")

@@ -2,6 +2,7 @@
 # rocprofv3 kernel-trace statistics of the bench command (one batch, 4 steps): writes gpurun_out/<tag>_kernel_stats.csv
 #   tools/prof_stats.sh <tag> [reads]        PROF_HEADLINE=demo: the demo index instead of the strain index built in the bench; PROF_SEED_HBM_MIB=<MiB>: tools/seed_hbm_only.py
 set -e -o pipefail
+export DSB_NO_WARMUP=1      # (the four-read batch dsb_ctx_create runs with hints would count as a launch of every kernel)
 cd "$(dirname "$0")/.."
 ROOT=$PWD; tag=$1; reads=${2:-65536}
 export TMPDIR=/tmp
