@@ -1765,21 +1765,85 @@ DV uint32_t sdp_visit(uint32_t &lsteps, const uint32_t step_limit, int &st, cons
 	return cnt;
 }
 
+// ---- sdp_match in phases ------------------------------------------------------------------------------------------
+// A 600-base step of an extension probes ~150 reference positions: three groups of 64 lanes.  Worked on group after group
+// (sdp_match_groups below, rounds 1-2) every group is a chain of dependent round trips of its own -- reference bytes, table
+// walk, the loads of the two exact-match extensions, scan, store -- and only the few lanes whose 9-mer occurs in the window
+// (one in nine) take part in the expensive middle of it.  Here up to DSB_SDP_G groups go through the phases together: (A) the
+// 9-mers and the table walks of all of them (LDS), collecting at most DSB_SDP_INL window positions per probed position; (B) the
+// first words of both extensions of every candidate loaded at once, then the extensions; (C) per group the scan over the
+// lanes and the stores, in the reference's order (probed position ascending, window position ascending within it).  A chunk in
+// which some probed position has more candidates than a lane keeps inline (repeats) goes group by group as before.
+#define DSB_SDP_G 3
+#define DSB_SDP_INL 2
+// phase A for one probed position: its 9-mer, the walk of its table chain; returns the number of window positions found
+// (DSB_SDP_INL + 1: more than the lane keeps), cq[] ascending
 template <bool FWD, class P8>
-DN uint32_t sdp_match_t(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms)
+DV uint32_t sdp_collect(uint32_t &lsteps, const uint32_t step_limit, int &st, const SdpArgsT<P8> &a, int i, const SdpRef rf, uint32_t (&cq)[DSB_SDP_INL])
 {
-	uint32_t t_kmer_num = a.t_len - 9 + 1;
-	if (t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return n_sms; // the reference's loop does not run either (t_len >= 13 at every call site)
-	uint32_t n_pos = (t_kmer_num - 4 + 3) / 4;                      // i = 4, 8, ... < t_kmer_num
-	// the context lives in memory (it is shared by reference with non-inlined callers): work on copies
-	const int lane = DSB_LANE; uint32_t *const red = w.red; DsbSms *const sms = w.sms; const uint32_t sms_cap = w.x->sms_cap;
-	uint32_t lsteps = w.lsteps, mirror_bad = 0; int st = 0; const uint32_t step_limit = w.step_limit;
-	SdpRef nxt; nxt.v = 0; nxt.t8 = nxt.t9 = 0;
-	if ((uint32_t)lane < n_pos) nxt = sdp_ref_load<FWD, P8>(a, 4 + 4 * lane);
-	for (uint32_t g = 0; g < n_pos; g += DSB_WAVE) {
+	uint64_t kmer = 0;
+	{
+		const uint64_t v = rf.v;
+#pragma unroll
+		for (int j = 0; j < 8; j++) kmer |= ((v >> (8 * j)) & 0xffULL) << (16 - 2 * j);
+		kmer |= (uint64_t)rf.t8;
+		if (FWD) kmer &= 0x3FFFFULL;
+		else if (i > 4) kmer |= (uint64_t)(rf.t9 >> 2);
+	}
+	uint32_t nc = 0;
+	if (a.n_q == 0 || kmer >= (1ULL << 18)) return 0;
+	const uint32_t slots = wtab_size(a.n_q);
+	const uint32_t k32 = (uint32_t)kmer;
+	for (uint32_t sl = wtab_slot(k32, slots);;) {
+		if (++lsteps > step_limit) { st |= DSB_ST_TIMEOUT; break; }
+		const uint32_t e = a.tab[sl];
+		if (e == DSB_WTAB_EMPTY) break;
+		if ((e >> 12) == k32) {
+			if (nc == DSB_SDP_INL) return DSB_SDP_INL + 1;
+			uint32_t q = a.q_bg + (e & 0xfffu);
+			if (nc == 1 && q < cq[0]) { const uint32_t t_ = cq[0]; cq[0] = q; q = t_; }
+			cq[nc++] = q;
+		}
+		sl = sl + 1 == slots ? 0 : sl + 1;
+	}
+	return nc;
+}
+// phase B for one candidate whose first extension words are loaded (xb: the eight bases left of the 9-mer, xf: the eight right
+// of it): the node, or nothing (src/cly.c:2390-2436)
+template <bool FWD, class P8>
+DV bool sdp_emit1(const SdpArgsT<P8> &a, int i, P8 c_t, uint32_t q_pos, uint64_t xb, uint64_t xf, DsbSms &o)
+{
+	if (FWD) {
+		const int back_len = MEM_search_from<P8>(AQ(a, q_pos - 1), c_t - 1, false, 4, xb);
+		if (!(back_len < 4 || i == 4)) return false;
+		uint32_t max_search = a.q_ed - q_pos - 1;
+		max_search = MINV(max_search, a.t_len - i - 1) + 50;
+		const int fwd = MEM_search_from<P8>(AQ(a, q_pos + 9), c_t + 9, true, (int)max_search, xf);
+		const int total = back_len + fwd + 1;
+		if (total < 4) return false;
+		o.len = total; o.q_pos = q_pos - back_len; o.t_pos = i - back_len + a.t_st;
+		return true;
+	} else {
+		const int fwd = MEM_search_from<P8>(AQ(a, q_pos + 9), c_t + 9, true, 4, xf);
+		if (!(fwd < 4 || i == 4)) return false;
+		uint32_t max_search = q_pos;
+		max_search = MINV((long)max_search, (long)(c_t - a.t_str)) + 50;
+		const int back_len = MEM_search_from<P8>(AQ(a, q_pos - 1), c_t - 1, false, (int)max_search, xb);
+		const int total = back_len + fwd + 1;
+		if (total < 4) return false;
+		o.len = total; o.q_pos = q_pos - back_len; o.t_pos = (uint32_t)((long)(c_t - a.t_str) - back_len + a.t_st);
+		return true;
+	}
+}
+// the groups [g_lo, g_hi) one after the other (a chunk with a crowded probed position)
+template <bool FWD, class P8>
+DV void sdp_match_groups(const SdpArgsT<P8> &a, uint32_t g_lo, uint32_t g_hi, uint32_t n_pos, const int lane, uint32_t *red, DsbSms *sms, const uint32_t sms_cap,
+                         uint32_t &lsteps, const uint32_t step_limit, int &st, uint32_t &n_sms, uint32_t &mirror_bad)
+{
+	for (uint32_t g = g_lo; g < g_hi && g < n_pos; g += DSB_WAVE) {
 		uint32_t pI = g + lane; bool valid = pI < n_pos; int i = 4 + 4 * (int)pI;
-		const SdpRef cur = nxt;
-		if (pI + DSB_WAVE < n_pos) nxt = sdp_ref_load<FWD, P8>(a, i + 4 * DSB_WAVE);      // the next group's reference bytes travel while this group is worked on
+		SdpRef cur; cur.v = 0; cur.t8 = cur.t9 = 0;
+		if (valid) cur = sdp_ref_load<FWD, P8>(a, i);
 		DsbSms keep[DSB_SDP_KEEP];
 		uint32_t cnt = valid ? sdp_visit<FWD, true, P8>(lsteps, step_limit, st, a, i, cur, keep, DSB_SDP_KEEP) : 0;
 		uint32_t total, off = grp_excl_scan_u(red, lane, cnt, &total);
@@ -1797,12 +1861,237 @@ DN uint32_t sdp_match_t(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms)
 		n_sms += total;
 		wave_sync();
 	}
+}
+template <bool FWD, class P8>
+DN uint32_t sdp_match_t(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms)
+{
+	uint32_t t_kmer_num = a.t_len - 9 + 1;
+	if (t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return n_sms; // the reference's loop does not run either (t_len >= 13 at every call site)
+	uint32_t n_pos = (t_kmer_num - 4 + 3) / 4;                      // i = 4, 8, ... < t_kmer_num
+	// the context lives in memory (it is shared by reference with non-inlined callers): work on copies
+	const int lane = DSB_LANE; uint32_t *const red = w.red; DsbSms *const sms = w.sms; const uint32_t sms_cap = w.x->sms_cap;
+	uint32_t lsteps = w.lsteps, mirror_bad = 0; int st = 0; const uint32_t step_limit = w.step_limit;
+	for (uint32_t g0 = 0; g0 < n_pos && !(st & DSB_ST_SMS_OVF); g0 += DSB_SDP_G * DSB_WAVE) {
+		// (A) 9-mers and table walks of up to DSB_SDP_G groups
+		SdpRef rf[DSB_SDP_G]; uint32_t cq[DSB_SDP_G][DSB_SDP_INL], nc[DSB_SDP_G]; bool crowded = false;
+#pragma unroll
+		for (int u = 0; u < DSB_SDP_G; u++) {
+			const uint32_t pI = g0 + (uint32_t)u * DSB_WAVE + (uint32_t)lane;
+			rf[u].v = 0; rf[u].t8 = rf[u].t9 = 0;
+			if (pI < n_pos) rf[u] = sdp_ref_load<FWD, P8>(a, 4 + 4 * (int)pI);
+		}
+#pragma unroll
+		for (int u = 0; u < DSB_SDP_G; u++) {
+			const uint32_t pI = g0 + (uint32_t)u * DSB_WAVE + (uint32_t)lane;
+			cq[u][0] = cq[u][1] = 0;
+			nc[u] = pI < n_pos ? sdp_collect<FWD, P8>(lsteps, step_limit, st, a, 4 + 4 * (int)pI, rf[u], cq[u]) : 0u;
+			crowded |= nc[u] > DSB_SDP_INL;
+		}
+		if (dsb_ballot64(crowded)) {
+			sdp_match_groups<FWD, P8>(a, g0, g0 + DSB_SDP_G * DSB_WAVE, n_pos, lane, red, sms, sms_cap, lsteps, step_limit, st, n_sms, mirror_bad);
+			continue;
+		}
+		// (B) the first words of both extensions of every candidate, then the extensions
+		uint64_t xb[DSB_SDP_G][DSB_SDP_INL], xf[DSB_SDP_G][DSB_SDP_INL];
+#pragma unroll
+		for (int u = 0; u < DSB_SDP_G; u++) {
+			const int i = 4 + 4 * (int)(g0 + (uint32_t)u * DSB_WAVE + (uint32_t)lane);
+			P8 c_t = sdp_ct<FWD, P8>(a, i);
+#pragma unroll
+			for (int c = 0; c < DSB_SDP_INL; c++) {
+				xb[u][c] = xf[u][c] = 0;
+				if ((uint32_t)c < nc[u]) { const uint32_t q = cq[u][c]; xb[u][c] = ld_u64(AQ(a, q - 1) - 7) ^ ld_u64(c_t - 1 - 7); xf[u][c] = ld_u64(AQ(a, q + 9)) ^ ld_u64(c_t + 9); }
+			}
+		}
+		DsbSms nd[DSB_SDP_G][DSB_SDP_INL]; uint32_t cnt[DSB_SDP_G];
+#pragma unroll
+		for (int u = 0; u < DSB_SDP_G; u++) {
+			const int i = 4 + 4 * (int)(g0 + (uint32_t)u * DSB_WAVE + (uint32_t)lane);
+			P8 c_t = sdp_ct<FWD, P8>(a, i);
+			cnt[u] = 0;
+#pragma unroll
+			for (int c = 0; c < DSB_SDP_INL; c++) {
+				DsbSms o; o.t_pos = o.q_pos = o.len = o.score = 0;
+				if ((uint32_t)c < nc[u] && sdp_emit1<FWD, P8>(a, i, c_t, cq[u][c], xb[u][c], xf[u][c], o)) { if (cnt[u] == 0) nd[u][0] = o; else nd[u][1] = o; cnt[u]++; }
+			}
+		}
+		// (C) per group: places by a scan over the lanes, stores
+#pragma unroll
+		for (int u = 0; u < DSB_SDP_G; u++) {
+			if (g0 + (uint32_t)u * DSB_WAVE >= n_pos) break;
+			uint32_t total, off = grp_excl_scan_u(red, lane, cnt[u], &total);
+			if (total == 0) continue;
+			if (n_sms + total > sms_cap) { st |= DSB_ST_SMS_OVF; break; }
+			DsbSms *dst = sms + n_sms + off;
+#pragma unroll
+			for (int k = 0; k < DSB_SDP_INL; k++) {
+				if ((uint32_t)k >= cnt[u]) break;
+				const DsbSms v = k == 0 ? nd[u][0] : nd[u][1];
+				dst[k].len = v.len; dst[k].q_pos = v.q_pos; dst[k].t_pos = v.t_pos;
+				if (a.lnodes && n_sms + off + (uint32_t)k < 64u) { uint4 r; r.x = v.t_pos; r.y = v.q_pos; r.z = v.len; r.w = 0; a.lnodes[n_sms + off + (uint32_t)k] = r; }
+			}
+			n_sms += total;
+		}
+		wave_sync();
+	}
 	// (the budget and the status bits of the lanes become the wavefront's: the largest count, the union of the bits)
 	const uint32_t ls = (uint32_t)grp_max_i(red, lane, (int)(lsteps >> 1));
 	const bool any_to = dsb_ballot64((st & DSB_ST_TIMEOUT) != 0) != 0, any_ovf = dsb_ballot64((st & DSB_ST_SMS_OVF) != 0) != 0;
 	w.lsteps = ls << 1;
 	if (any_to | any_ovf) w.status |= (any_to ? DSB_ST_TIMEOUT : 0) | (any_ovf ? DSB_ST_SMS_OVF : 0);
 	return n_sms | mirror_bad;      // bit 31: some nodes are missing from the LDS mirror
+}
+
+// ---- sdp_match the other way round -----------------------------------------------------------------------------------------
+// A step of the right / left extension looks ~148 reference 9-mers (every 4th of 600 bases) up among the 9-mers of ~2000 read
+// positions.  Rounds 1-3 hashed the 2000 (32 LDS compare-and-swap chains per lane and step: a sixth of k_classify on the strain
+// index, profiles/r03_*) to walk 148 chains of which one in nine is not empty.  The join does not care which side is hashed:
+// here the <= 256 reference 9-mers go into a small table (2-3 inserts per lane) plus a 16-kbit filter of their hashes, every
+// lane streams its run of read positions through the filter with plain LDS reads that do not depend on each other, walks the
+// table for the one position in sixty that passes, and appends (probed position, read position) to a list.  The list -- ~35
+// pairs per step -- is ranked into the reference's order (probed position ascending, read position ascending within it) and
+// each lane evaluates one pair, so the exact-match extensions run on full wavefronts, not on one lane in nine.  Same pairs, same
+// order, same tests as sdp_match_t: same nodes.  More pairs than DSB_INV_PAIRS (repeats): the caller takes the old path.
+#define DSB_INV_SLOTS 512u      /* reference table: (9-mer << 8 | probed position index), <= 256 entries */
+#define DSB_INV_FWORDS 512u     /* filter: 16384 bits */
+#define DSB_INV_PAIRS 256u
+#define DSB_INV_MINQ 96u        /* narrower windows: hashing them is as cheap */
+#define DSB_INV_NONE 0xffffffffu
+template <bool FWD>
+DV uint64_t sdp_kmer(const SdpRef rf, int i)
+{
+	uint64_t kmer = 0;
+	const uint64_t v = rf.v;
+#pragma unroll
+	for (int j = 0; j < 8; j++) kmer |= ((v >> (8 * j)) & 0xffULL) << (16 - 2 * j);
+	kmer |= (uint64_t)rf.t8;
+	if (FWD) kmer &= 0x3FFFFULL;
+	else if (i > 4) kmer |= (uint64_t)(rf.t9 >> 2);
+	return kmer;
+}
+// the 9-mer at position rel (< 64) of the three packed words W0 W1 W2 (32 bases each, first base in the top bits)
+DV uint32_t pk3_kmer9(uint64_t W0, uint64_t W1, uint64_t W2, uint32_t rel)
+{
+	const uint32_t sh = (rel & 31u) * 2;
+	const uint64_t a = rel < 32 ? W0 : W1, b = rel < 32 ? W1 : W2;
+	const uint64_t hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
+	return (uint32_t)(hi >> 46);
+}
+template <bool FWD>
+DN uint32_t sdp_match_inv(WCtxL &w, const SdpArgsT<gp8> a, uint32_t n_sms, const uint64_t *P, uint32_t n_words)
+{
+	const int lane = DSB_LANE;
+	lds_u32 *const rt = (lds_u32 *)w.wtab, *const flt = rt + DSB_INV_SLOTS, *const cntp = flt + DSB_INV_FWORDS, *const pairs = cntp + 4, *const sorted = pairs + DSB_INV_PAIRS;
+	const uint32_t n_pos = (a.t_len - 9 + 1 - 4 + 3) / 4;             // i = 4, 8, ... < t_len - 9 + 1; <= 256 (caller)
+	TX0(w, t_b);
+	// (A) empty table and filter
+#ifdef DSB_HOST_EMU
+	for (uint32_t i = lane; i < DSB_INV_SLOTS; i += DSB_WAVE) rt[i] = DSB_INV_NONE;
+	for (uint32_t i = lane; i < DSB_INV_FWORDS; i += DSB_WAVE) flt[i] = 0;
+#else
+	{
+		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+		const u32x4 e4 = {DSB_INV_NONE, DSB_INV_NONE, DSB_INV_NONE, DSB_INV_NONE}, z4 = {0u, 0u, 0u, 0u};
+		for (uint32_t i = 4 * lane; i < DSB_INV_SLOTS; i += 4 * DSB_WAVE) *(__attribute__((address_space(3))) u32x4 *)(rt + i) = e4;
+		for (uint32_t i = 4 * lane; i < DSB_INV_FWORDS; i += 4 * DSB_WAVE) *(__attribute__((address_space(3))) u32x4 *)(flt + i) = z4;
+	}
+#endif
+	if (lane == 0) cntp[0] = 0;
+	wave_sync();
+	// (B) the reference 9-mers
+	for (uint32_t pI = (uint32_t)lane; pI < n_pos; pI += DSB_WAVE) {
+		const int i = 4 + 4 * (int)pI;
+		const uint64_t kmer = sdp_kmer<FWD>(sdp_ref_load<FWD, gp8>(a, i), i);
+		if (kmer >= (1ULL << 18)) continue;                             // pad bits: matches nothing
+		const uint32_t k = (uint32_t)kmer, prod = k * 2654435761u, h = prod >> 18, e = (k << 8) | pI;
+		uint32_t sl = prod >> 23;
+#ifdef DSB_HOST_EMU
+		flt[h >> 5] |= 1u << (h & 31);
+		while (rt[sl] != DSB_INV_NONE) sl = (sl + 1) & (DSB_INV_SLOTS - 1);
+		rt[sl] = e;
+#else
+		__hip_atomic_fetch_or(flt + (h >> 5), 1u << (h & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		for (;;) {
+			uint32_t old = DSB_INV_NONE;
+			__hip_atomic_compare_exchange_strong(rt + sl, &old, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (old == DSB_INV_NONE) break;
+			sl = (sl + 1) & (DSB_INV_SLOTS - 1);
+		}
+#endif
+	}
+	wave_sync();
+	// (C) the read positions: a run of consecutive ones per lane, 32 at a time out of three packed words
+	{
+		const uint32_t C = (a.n_q + DSB_WAVE - 1) / DSB_WAVE;
+		const uint32_t r0 = (uint32_t)lane * C, r1 = MINV(a.n_q, r0 + C);
+		for (uint32_t rb = r0; rb < r1; rb += 32) {
+			const uint32_t wi = (a.q_bg + rb) >> 5, rel0 = (a.q_bg + rb) & 31u, nr = MINV(32u, r1 - rb);
+			const uint64_t W0 = DSB_G64(P, wi), W1 = wi + 1 < n_words ? DSB_G64(P, wi + 1) : 0, W2 = wi + 2 < n_words ? DSB_G64(P, wi + 2) : 0;
+			uint32_t hit = 0;
+#pragma unroll 8
+			for (uint32_t j = 0; j < 32; j++) {                          // (positions past the run: a filter read more, masked below)
+				const uint32_t h = (pk3_kmer9(W0, W1, W2, rel0 + j) * 2654435761u) >> 18;
+				hit |= ((flt[h >> 5] >> (h & 31)) & 1u) << j;
+			}
+			if (nr < 32) hit &= (1u << nr) - 1u;
+			while (hit) {
+				const uint32_t j = (uint32_t)__builtin_ctz(hit); hit &= hit - 1;
+				const uint32_t k = pk3_kmer9(W0, W1, W2, rel0 + j);
+				for (uint32_t sl = (k * 2654435761u) >> 23;; sl = (sl + 1) & (DSB_INV_SLOTS - 1)) {
+					const uint32_t e = rt[sl];
+					if (e == DSB_INV_NONE) break;
+					if ((e >> 8) != k) continue;
+#ifdef DSB_HOST_EMU
+					const uint32_t idx = cntp[0]++;
+#else
+					const uint32_t idx = __hip_atomic_fetch_add(cntp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+					if (idx < DSB_INV_PAIRS) pairs[idx] = ((e & 0xffu) << 12) | (rb + j);
+				}
+			}
+		}
+	}
+	wave_sync();
+	const uint32_t n_pairs = cntp[0];
+	TX1(w, 0, t_b);
+	if (n_pairs == 0) return n_sms;
+	if (n_pairs > DSB_INV_PAIRS) return DSB_INV_NONE;
+	TX0(w, t_p);
+	// (D) the reference's order: rank of every pair among all (the keys are distinct)
+	for (uint32_t b0 = 0; b0 < n_pairs; b0 += DSB_WAVE) {
+		const bool valid = b0 + (uint32_t)lane < n_pairs;
+		const uint32_t key = valid ? pairs[b0 + (uint32_t)lane] : DSB_INV_NONE;
+		uint32_t rank = 0;
+		for (uint32_t j = 0; j < n_pairs; j++) rank += pairs[j] < key ? 1u : 0u;
+		if (valid) sorted[rank] = key;
+	}
+	wave_sync();
+	// (E) one pair per lane: the two exact-match extensions, the node if it qualifies
+	uint32_t *const red = w.red; DsbSms *const sms = w.sms; const uint32_t sms_cap = w.x->sms_cap; bool ovf = false;
+	for (uint32_t b0 = 0; b0 < n_pairs; b0 += DSB_WAVE) {
+		DsbSms o; o.t_pos = o.q_pos = o.len = o.score = 0; bool ok = false;
+		if (b0 + (uint32_t)lane < n_pairs) {
+			const uint32_t key = sorted[b0 + (uint32_t)lane], q_pos = a.q_bg + (key & 0xfffu);
+			const int i = 4 + 4 * (int)(key >> 12);
+			gp8 c_t = sdp_ct<FWD, gp8>(a, i);
+			const uint64_t xb = ld_u64(AQ(a, q_pos - 1) - 7) ^ ld_u64(c_t - 1 - 7), xf = ld_u64(AQ(a, q_pos + 9)) ^ ld_u64(c_t + 9);
+			ok = sdp_emit1<FWD, gp8>(a, i, c_t, q_pos, xb, xf, o);
+		}
+		uint32_t total, off = grp_excl_scan_u(red, lane, ok ? 1u : 0u, &total);
+		if (total == 0) continue;
+		if (n_sms + total > sms_cap) { ovf = true; break; }
+		if (ok) {
+			DsbSms *dst = sms + n_sms + off;
+			dst->len = o.len; dst->q_pos = o.q_pos; dst->t_pos = o.t_pos;
+			// the first 64 nodes of the list are mirrored in LDS for the in-register DP of sdp_middle_M2
+			if (a.lnodes && n_sms + off < 64u) { uint4 r; r.x = o.t_pos; r.y = o.q_pos; r.z = o.len; r.w = 0; a.lnodes[n_sms + off] = r; }
+		}
+		n_sms += total;
+	}
+	wave_sync();
+	if (ovf) w.status |= DSB_ST_SMS_OVF;
+	TX1(w, 1, t_p);
+	return n_sms;
 }
 
 // read positions sdp_match can return: q_bg <= pos <= q_ed, and pos has a 9-mer (pos <= L - 9)
@@ -1836,6 +2125,15 @@ DV uint32_t sdp_match_p(WCtxL &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, 
 DN uint32_t sdp_match_n(WCtxL &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len,
                         uint32_t t_st, bool isForward, uint4 *lnodes, const uint64_t *qpk)
 {
+	if (qpk) {
+		const uint32_t n_q = sdp_nq(w.L, q_bg, q_ed), t_kmer_num = t_len - 9 + 1;
+		if (n_q >= DSB_INV_MINQ && n_q <= DSB_WTAB_MAXQ && t_kmer_num > 4 && t_kmer_num <= 4 * 256u) {
+			SdpArgsT<gp8> a; a.lnodes = lnodes; a.q_bg = q_bg; a.q_ed = q_ed; a.q_base = q_str; a.q_lo = 0; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st;
+			a.tab = nullptr; a.bm = nullptr; a.n_q = n_q;
+			const uint32_t rv = isForward ? sdp_match_inv<true>(w, a, n_sms, qpk, (w.L + 31) / 32 + 1) : sdp_match_inv<false>(w, a, n_sms, qpk, (w.L + 31) / 32 + 1);
+			if (rv != DSB_INV_NONE) return rv;
+		}
+	}
 	return sdp_match_p<gp8>(w, n_sms, q_bg, q_ed, q_str, 0, t_str, t_len, t_st, isForward, lnodes, qpk);
 }
 // ... or staged in LDS by sdp_middle_M2: lq holds the read from position q_lo on, lt the reference window
@@ -2664,10 +2962,9 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 				max_search_ref = l_read - c_h->q_ed + 60;
 			} else max_search_ref = t_length - c_t_offset;
 			max_search_ref = MINV(600u, max_search_ref);
-			TX0(w, t_r);
 			get_ref_wave(x->refbin, x->ref_bases, DSB_LANE, ref, c_t_offset + t_offset_global, max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50);
 			wave_sync();
-			TX1(w, 3, t_r); TXC(w, 7);
+			TXC(w, 7);
 			int search_q_ed = (int)best_q + 1000;
 			search_q_ed = MINV((uint32_t)search_q_ed, l_read);
 			int search_q_st = MAXV((uint32_t)(search_q_ed - 2000), c_h->q_st - 8);
@@ -2681,17 +2978,13 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 			if (node_get(w, nb, current_sms).t_pos > best_t + 1000) break;
 		}
 		DsbSms *c_sms = sms + current_sms;
-		TX0(w, t_g);
 		DsbSms cs = node_get(w, nb, current_sms); current_sms++;
-		TX1(w, 5, t_g);
 		SUB0(w);
 		int max_score = sdp_best_pred_b<1>(w, db, cs, (int32_t)current_sms - 1, nb, n_sms, ring, steps, bn0, bK);
 		SUB1(w, 11);
 		TXC(w, 8);
-		TX0(w, t_s);
 		c_sms->score = max_score;
 		{ uint4 r_; r_.x = cs.t_pos; r_.y = cs.q_pos; r_.z = cs.len; r_.w = (uint32_t)max_score; ring_st(ring, (current_sms - 1) & (DSB_RING - 1), r_); }
-		TX1(w, 4, t_s);
 		SUB0(w);
 		bool comb = (int)cs.len >= 8 && combine_chain(c_st, chain_ID, sc_hash, cs.t_pos - cs.q_pos, false, cs.q_pos, &combined) == true;
 		SUB1(w, 12);
@@ -2762,9 +3055,10 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 			int search_q_st = (int)best_q - 1000;
 			search_q_st = MAXV(search_q_st, 0);
 			int search_q_ed = MINV((uint32_t)(search_q_st + 2000), c_h->q_st - 1);
-			SUB0(w);
+			TXC(w, 9);
+			TX0(w, t_lm);
 			sdp_match(w, search_q_st, search_q_ed, q_str, ref + 50, max_search_ref, key_len, tbl, c_t_offset - max_search_ref, false);
-			SUB1(w, 10);
+			TX1(w, 3, t_lm);
 			c_t_offset = c_t_offset - max_search_ref + 9 + 3;
 			n_sms = w.n_sms;
 			if (n_sms == current_sms) break;
@@ -2773,9 +3067,9 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 		}
 		DsbSms *c_sms = sms + current_sms;
 		DsbSms cs = node_get(w, nb, current_sms); current_sms++;
-		SUB0(w);
+		TX0(w, t_ld);
 		int max_score = sdp_best_pred_b<2>(w, db, cs, (int32_t)current_sms - 1, nb, n_sms, ring, steps, bn0, bK);
-		SUB1(w, 11);
+		TX1(w, 4, t_ld);
 		c_sms->score = max_score;
 		{ uint4 r_; r_.x = cs.t_pos; r_.y = cs.q_pos; r_.z = cs.len; r_.w = (uint32_t)max_score; ring_st(ring, (current_sms - 1) & (DSB_RING - 1), r_); }
 		if ((int)cs.len >= 8 && combine_chain(c_st, chain_ID, sc_hash, cs.t_pos - cs.q_pos, true, cs.q_pos + cs.len, &combined) == true) {
