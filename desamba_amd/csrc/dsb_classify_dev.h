@@ -1952,11 +1952,13 @@ DN uint32_t sdp_match_t(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms)
 // pairs per step -- is ranked into the reference's order (probed position ascending, read position ascending within it) and
 // each lane evaluates one pair, so the exact-match extensions run on full wavefronts, not on one lane in nine.  Same pairs, same
 // order, same tests as sdp_match_t: same nodes.  More pairs than DSB_INV_PAIRS (repeats): the caller takes the old path.
-#define DSB_INV_SLOTS 512u      /* reference table: (9-mer << 8 | probed position index), <= 256 entries */
+#define DSB_INV_SLOTS 512u      /* reference table: (9-mer << 9 | probed position index), <= DSB_INV_MAXPOS entries */
+#define DSB_INV_MAXPOS 300u
 #define DSB_INV_FWORDS 512u     /* filter: 16384 bits */
 #define DSB_INV_PAIRS 256u
 #define DSB_INV_MINQ 96u        /* narrower windows: hashing them is as cheap */
 #define DSB_INV_NONE 0xffffffffu
+#define DSB_INV_WORDS (DSB_INV_SLOTS + DSB_INV_FWORDS + 4u + 2u * DSB_INV_PAIRS)   /* words of w.wtab it uses */
 template <bool FWD>
 DV uint64_t sdp_kmer(const SdpRef rf, int i)
 {
@@ -1969,20 +1971,18 @@ DV uint64_t sdp_kmer(const SdpRef rf, int i)
 	else if (i > 4) kmer |= (uint64_t)(rf.t9 >> 2);
 	return kmer;
 }
-// the 9-mer at position rel (< 64) of the three packed words W0 W1 W2 (32 bases each, first base in the top bits)
-DV uint32_t pk3_kmer9(uint64_t W0, uint64_t W1, uint64_t W2, uint32_t rel)
+// the 9-mer at base j (< 32) of the 64 bases hi:lo (first base in the top bits of hi)
+DV uint32_t pk2_kmer9(uint64_t hi, uint64_t lo, uint32_t j)
 {
-	const uint32_t sh = (rel & 31u) * 2;
-	const uint64_t a = rel < 32 ? W0 : W1, b = rel < 32 ? W1 : W2;
-	const uint64_t hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
-	return (uint32_t)(hi >> 46);
+	const uint32_t sh = 2 * j;
+	return (uint32_t)((sh ? ((hi << sh) | (lo >> (64 - sh))) : hi) >> 46);
 }
-template <bool FWD>
-DN uint32_t sdp_match_inv(WCtxL &w, const SdpArgsT<gp8> a, uint32_t n_sms, const uint64_t *P, uint32_t n_words)
+template <bool FWD, class P8>
+DN uint32_t sdp_match_inv(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms, const uint64_t *P, uint32_t n_words)
 {
 	const int lane = DSB_LANE;
 	lds_u32 *const rt = (lds_u32 *)w.wtab, *const flt = rt + DSB_INV_SLOTS, *const cntp = flt + DSB_INV_FWORDS, *const pairs = cntp + 4, *const sorted = pairs + DSB_INV_PAIRS;
-	const uint32_t n_pos = (a.t_len - 9 + 1 - 4 + 3) / 4;             // i = 4, 8, ... < t_len - 9 + 1; <= 256 (caller)
+	const uint32_t n_pos = (a.t_len - 9 + 1 - 4 + 3) / 4;             // i = 4, 8, ... < t_len - 9 + 1; <= DSB_INV_MAXPOS (caller)
 	TX0(w, t_b);
 	// (A) empty table and filter
 #ifdef DSB_HOST_EMU
@@ -2001,9 +2001,9 @@ DN uint32_t sdp_match_inv(WCtxL &w, const SdpArgsT<gp8> a, uint32_t n_sms, const
 	// (B) the reference 9-mers
 	for (uint32_t pI = (uint32_t)lane; pI < n_pos; pI += DSB_WAVE) {
 		const int i = 4 + 4 * (int)pI;
-		const uint64_t kmer = sdp_kmer<FWD>(sdp_ref_load<FWD, gp8>(a, i), i);
+		const uint64_t kmer = sdp_kmer<FWD>(sdp_ref_load<FWD, P8>(a, i), i);
 		if (kmer >= (1ULL << 18)) continue;                             // pad bits: matches nothing
-		const uint32_t k = (uint32_t)kmer, prod = k * 2654435761u, h = prod >> 18, e = (k << 8) | pI;
+		const uint32_t k = (uint32_t)kmer, prod = k * 2654435761u, h = prod >> 18, e = (k << 9) | pI;
 		uint32_t sl = prod >> 23;
 #ifdef DSB_HOST_EMU
 		flt[h >> 5] |= 1u << (h & 31);
@@ -2025,28 +2025,30 @@ DN uint32_t sdp_match_inv(WCtxL &w, const SdpArgsT<gp8> a, uint32_t n_sms, const
 		const uint32_t C = (a.n_q + DSB_WAVE - 1) / DSB_WAVE;
 		const uint32_t r0 = (uint32_t)lane * C, r1 = MINV(a.n_q, r0 + C);
 		for (uint32_t rb = r0; rb < r1; rb += 32) {
-			const uint32_t wi = (a.q_bg + rb) >> 5, rel0 = (a.q_bg + rb) & 31u, nr = MINV(32u, r1 - rb);
+			const uint32_t wi = (a.q_bg + rb) >> 5, sh0 = ((a.q_bg + rb) & 31u) * 2, nr = MINV(32u, r1 - rb);
 			const uint64_t W0 = DSB_G64(P, wi), W1 = wi + 1 < n_words ? DSB_G64(P, wi + 1) : 0, W2 = wi + 2 < n_words ? DSB_G64(P, wi + 2) : 0;
+			// the 64 bases from the first position of the run on: position j's 9-mer is a shift by a constant away
+			const uint64_t hi = sh0 ? ((W0 << sh0) | (W1 >> (64 - sh0))) : W0, lo = sh0 ? ((W1 << sh0) | (W2 >> (64 - sh0))) : W1;
 			uint32_t hit = 0;
-#pragma unroll 8
+#pragma unroll
 			for (uint32_t j = 0; j < 32; j++) {                          // (positions past the run: a filter read more, masked below)
-				const uint32_t h = (pk3_kmer9(W0, W1, W2, rel0 + j) * 2654435761u) >> 18;
+				const uint32_t h = (pk2_kmer9(hi, lo, j) * 2654435761u) >> 18;
 				hit |= ((flt[h >> 5] >> (h & 31)) & 1u) << j;
 			}
 			if (nr < 32) hit &= (1u << nr) - 1u;
 			while (hit) {
 				const uint32_t j = (uint32_t)__builtin_ctz(hit); hit &= hit - 1;
-				const uint32_t k = pk3_kmer9(W0, W1, W2, rel0 + j);
+				const uint32_t k = pk2_kmer9(hi, lo, j);
 				for (uint32_t sl = (k * 2654435761u) >> 23;; sl = (sl + 1) & (DSB_INV_SLOTS - 1)) {
 					const uint32_t e = rt[sl];
 					if (e == DSB_INV_NONE) break;
-					if ((e >> 8) != k) continue;
+					if ((e >> 9) != k) continue;
 #ifdef DSB_HOST_EMU
 					const uint32_t idx = cntp[0]++;
 #else
 					const uint32_t idx = __hip_atomic_fetch_add(cntp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
-					if (idx < DSB_INV_PAIRS) pairs[idx] = ((e & 0xffu) << 12) | (rb + j);
+					if (idx < DSB_INV_PAIRS) pairs[idx] = ((e & 0x1ffu) << 12) | (rb + j);
 				}
 			}
 		}
@@ -2073,9 +2075,9 @@ DN uint32_t sdp_match_inv(WCtxL &w, const SdpArgsT<gp8> a, uint32_t n_sms, const
 		if (b0 + (uint32_t)lane < n_pairs) {
 			const uint32_t key = sorted[b0 + (uint32_t)lane], q_pos = a.q_bg + (key & 0xfffu);
 			const int i = 4 + 4 * (int)(key >> 12);
-			gp8 c_t = sdp_ct<FWD, gp8>(a, i);
+			P8 c_t = sdp_ct<FWD, P8>(a, i);
 			const uint64_t xb = ld_u64(AQ(a, q_pos - 1) - 7) ^ ld_u64(c_t - 1 - 7), xf = ld_u64(AQ(a, q_pos + 9)) ^ ld_u64(c_t + 9);
-			ok = sdp_emit1<FWD, gp8>(a, i, c_t, q_pos, xb, xf, o);
+			ok = sdp_emit1<FWD, P8>(a, i, c_t, q_pos, xb, xf, o);
 		}
 		uint32_t total, off = grp_excl_scan_u(red, lane, ok ? 1u : 0u, &total);
 		if (total == 0) continue;
@@ -2112,6 +2114,11 @@ DV uint32_t sdp_match_p(WCtxL &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, 
 	if (a.n_q > DSB_WTAB_MAXQ) { w.status |= DSB_ST_SMS_OVF; return n_sms; }     // cannot happen: windows are <= 2001 wide
 	uint32_t t_kmer_num = t_len - 9 + 1;
 	if (a.n_q == 0 || t_kmer_num > 0x7fffffffu || t_kmer_num <= 4) return n_sms;
+	// wide window, few probed positions (every step of the right / left extensions, the bigger gaps): the reference side is hashed
+	if (qpk && a.n_q >= DSB_INV_MINQ && t_kmer_num <= 4 * DSB_INV_MAXPOS) {
+		const uint32_t rv = isForward ? sdp_match_inv<true, P8>(w, a, n_sms, qpk, (w.L + 31) / 32 + 1) : sdp_match_inv<false, P8>(w, a, n_sms, qpk, (w.L + 31) / 32 + 1);
+		if (rv != DSB_INV_NONE) return rv;
+	}
 	TX0(w, t_b);
 	if (qpk) wtab_build_pk((lds_u32 *)w.wtab, DSB_LANE, qpk, (w.L + 31) / 32 + 1, q_bg, a.n_q);
 	else wtab_build<P8>((lds_u32 *)w.wtab, DSB_LANE, q_base + ((int32_t)q_bg - q_lo), 0u, a.n_q);
@@ -2125,22 +2132,13 @@ DV uint32_t sdp_match_p(WCtxL &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, 
 DN uint32_t sdp_match_n(WCtxL &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len,
                         uint32_t t_st, bool isForward, uint4 *lnodes, const uint64_t *qpk)
 {
-	if (qpk) {
-		const uint32_t n_q = sdp_nq(w.L, q_bg, q_ed), t_kmer_num = t_len - 9 + 1;
-		if (n_q >= DSB_INV_MINQ && n_q <= DSB_WTAB_MAXQ && t_kmer_num > 4 && t_kmer_num <= 4 * 256u) {
-			SdpArgsT<gp8> a; a.lnodes = lnodes; a.q_bg = q_bg; a.q_ed = q_ed; a.q_base = q_str; a.q_lo = 0; a.t_str = t_str; a.t_len = t_len; a.t_st = t_st;
-			a.tab = nullptr; a.bm = nullptr; a.n_q = n_q;
-			const uint32_t rv = isForward ? sdp_match_inv<true>(w, a, n_sms, qpk, (w.L + 31) / 32 + 1) : sdp_match_inv<false>(w, a, n_sms, qpk, (w.L + 31) / 32 + 1);
-			if (rv != DSB_INV_NONE) return rv;
-		}
-	}
 	return sdp_match_p<gp8>(w, n_sms, q_bg, q_ed, q_str, 0, t_str, t_len, t_st, isForward, lnodes, qpk);
 }
-// ... or staged in LDS by sdp_middle_M2: lq holds the read from position q_lo on, lt the reference window
+// ... or staged in LDS by sdp_middle_M2 behind the tables: lq holds the read from position q_lo on, lt the reference window
 DN uint32_t sdp_match_lds(WCtxL &w, uint32_t n_sms, uint32_t q_bg, uint32_t q_ed, const uint8_t *lq, int32_t q_lo, const uint8_t *lt, uint32_t t_len,
-                          uint32_t t_st, uint4 *lnodes)
+                          uint32_t t_st, uint4 *lnodes, const uint64_t *qpk)
 {
-	return sdp_match_p<lp8>(w, n_sms, q_bg, q_ed, (lp8)lq, q_lo, (lp8)lt, t_len, t_st, true, lnodes);
+	return sdp_match_p<lp8>(w, n_sms, q_bg, q_ed, (lp8)lq, q_lo, (lp8)lt, t_len, t_st, true, lnodes, qpk);
 }
 DV void sdp_match(WCtxL &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, const uint8_t *t_str, uint32_t t_len, int key_len,
                   int tbl, uint32_t t_st, bool isForward)
@@ -2857,9 +2855,10 @@ DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int k
 			const uint32_t n_q = sdp_nq(L, q_bg, q_ed), slots = wtab_size(n_q);
 			const int32_t q_lo = (int32_t)q_bg - 16, q_hi = (int32_t)q_ed + 80;
 			const uint32_t q_bytes = q_hi > q_lo ? (uint32_t)(q_hi - q_lo + 7) & ~7u : 0u, t_bytes = ((uint32_t)total_ref_len + 64 + 7) & ~7u;
-			if (n_q > 0 && q_bytes && q_lo >= -(int32_t)DSB_QPAD_L + 8 && 4 * slots + q_bytes + 8 + t_bytes + 8 + 1024 <= 4 * DSB_WTAB_SLOTS) {
-				uint8_t *lq = reinterpret_cast<uint8_t *>(wtab + slots), *lt = lq + q_bytes + 8;
-				lnodes = reinterpret_cast<uint4 *>(lt + t_bytes + (((4 * slots + q_bytes + t_bytes) & 8u) ? 0 : 8));   // 16-byte aligned: the table starts 16-aligned
+			const uint32_t tbase = w.pk[tbl] ? MAXV(slots, (DSB_INV_WORDS + 3u) & ~3u) : slots;   // words of the window's table, whichever way round it is built
+			if (n_q > 0 && q_bytes && q_lo >= -(int32_t)DSB_QPAD_L + 8 && 4 * tbase + q_bytes + 8 + t_bytes + 8 + 1024 <= 4 * DSB_WTAB_SLOTS) {
+				uint8_t *lq = reinterpret_cast<uint8_t *>(wtab + tbase), *lt = lq + q_bytes + 8;
+				lnodes = reinterpret_cast<uint4 *>(lt + t_bytes + (((4 * tbase + q_bytes + t_bytes) & 8u) ? 0 : 8));   // 16-byte aligned: the table starts 16-aligned
 				const bool use_pf = cur_has_q && cur_qlo == q_lo;
 				for (uint32_t k = 8 * lane; k < q_bytes; k += 8 * DSB_WAVE) *reinterpret_cast<uint64_t *>(lq + k) = (use_pf && k < 8 * DSB_WAVE) ? cur_q : ld_u64(q_str + q_lo + (int32_t)k);
 				ref = lt; qs = nullptr; lq_st = lq;
@@ -2869,7 +2868,7 @@ DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int k
 			cnt_add(Cnt{w.k.c, 1u}, 3, (uint32_t)total_ref_len);
 			for (int k = total_ref_len + lane; k < total_ref_len + 64; k += DSB_WAVE) ref[k] = DSB_TPAD_VAL;   // reads reach <= 58 past the window
 			wave_sync();
-			n_sms = lq_st ? sdp_match_lds(w, n_sms, q_bg, q_ed, lq_st, q_lo, ref, total_ref_len, pre_refoffset + pre_mch, lnodes)
+			n_sms = lq_st ? sdp_match_lds(w, n_sms, q_bg, q_ed, lq_st, q_lo, ref, total_ref_len, pre_refoffset + pre_mch, lnodes, w.pk[tbl])
 			              : sdp_match_n(w, n_sms, q_bg, q_ed, qs, ref, total_ref_len, pre_refoffset + pre_mch, true, lnodes, w.pk[tbl]);
 			mirror = lnodes != nullptr && !(n_sms >> 31); n_sms &= 0x7fffffffu;
 		}
