@@ -1464,6 +1464,26 @@ DV void sc_hash_idx(DsbScHash *sc, DsbChain *hit, uint32_t n_hit)
 			sc[con++].next = 0;
 		}
 }
+// which of the 256 buckets hold anything (bit key of m[key >> 6]): the extensions ask once per match node, and a read has a
+// handful of chains -- nine buckets in ten are empty, which a register tells without the round trip to the table
+struct ScMask { uint64_t m[4]; };
+DV ScMask sc_mask(const DsbScHash *sc)
+{
+	ScMask r;
+#ifdef DSB_HOST_EMU
+	for (int g = 0; g < 4; g++) { r.m[g] = 0; for (int i = 0; i < 64; i++) if (sc[64 * g + i].next != 0) r.m[g] |= 1ULL << i; }
+#else
+#pragma unroll
+	for (int g = 0; g < 4; g++) r.m[g] = dsb_ballot64(sc[64 * g + DSB_LANE].next != 0);
+#endif
+	return r;
+}
+DV bool sc_mask_has(const ScMask &k, int dis)
+{
+	const uint32_t key = (uint32_t)dis & 0xffu;
+	const uint64_t m = key < 128 ? (key < 64 ? k.m[0] : k.m[1]) : (key < 192 ? k.m[2] : k.m[3]);
+	return ((m >> (key & 63u)) & 1ULL) != 0;
+}
 DV bool combine_chain(DsbChain *c_st, int chain_ID, DsbScHash *sc, int dis, bool isleft, int c_q_pos, DsbChain **combined)
 {
 	uint16_t key = (dis) & 0xff;
@@ -2947,6 +2967,7 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 	uint64_t t_offset_global = x->refinfo[c_h->ref_ID].seq_offset, t_length = x->refinfo[c_h->ref_ID].seq_l;
 	uint32_t c_t_offset = c_h->t_ed - 3;
 	int last_search = false;
+	uint32_t ch_q_st = c_h->q_st, ch_q_ed = c_h->q_ed;       // (they change when a chain is combined in: read again there)
 	// loop state in registers (the context is in LDS: a round trip per access, and this loop runs per match node)
 	uint32_t steps = w.steps, n_sms = 1; const uint32_t step_limit = w.step_limit; DsbSms *const sms = w.sms; uint4 *const ring = w.ring;
 	while (1) {
@@ -2955,10 +2976,10 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 			uint32_t next_step = t_length - c_t_offset;
 			if (next_step < 12) break;
 			uint32_t max_search_ref;
-			if (l_read - c_h->q_ed < 600) {
+			if (l_read - ch_q_ed < 600) {
 				if (last_search == true) break;
 				last_search = true;
-				max_search_ref = l_read - c_h->q_ed + 60;
+				max_search_ref = l_read - ch_q_ed + 60;
 			} else max_search_ref = t_length - c_t_offset;
 			max_search_ref = MINV(600u, max_search_ref);
 			get_ref_wave(x->refbin, x->ref_bases, DSB_LANE, ref, c_t_offset + t_offset_global, max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50);
@@ -2966,7 +2987,7 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 			TXC(w, 7);
 			int search_q_ed = (int)best_q + 1000;
 			search_q_ed = MINV((uint32_t)search_q_ed, l_read);
-			int search_q_st = MAXV((uint32_t)(search_q_ed - 2000), c_h->q_st - 8);
+			int search_q_st = MAXV((uint32_t)(search_q_ed - 2000), ch_q_st - 8);
 			SUB0(w);
 			sdp_match(w, search_q_st, search_q_ed, q_str, ref, max_search_ref, key_len, tbl, c_t_offset, true);
 			SUB1(w, 10);
@@ -2992,6 +3013,7 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 			w.steps = steps;
 			total_max_score = MAXV(score_ori, max_score) - c_len + sdp_middle_M2(w, combined->cur, q_str, tbl, key_len);
 			steps = w.steps;
+			ch_q_st = c_h->q_st; ch_q_ed = c_h->q_ed;
 			score_ori = total_max_score; max_sms_id = 0;
 			w.n_sms = 0;
 			p = push_sms(w); n_sms = 1;
@@ -3033,6 +3055,7 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 	uint64_t t_offset_global = x->refinfo[c_h->ref_ID].seq_offset;
 	uint32_t c_t_offset = c_h->t_st + 3;
 	int last_search = false;
+	uint32_t ch_q_st = c_h->q_st;                             // (changes when a chain is combined in: read again there)
 	uint32_t steps = w.steps, n_sms = 1; const uint32_t step_limit = w.step_limit; DsbSms *const sms = w.sms; uint4 *const ring = w.ring;   // (as in sdp_right_M2)
 	while (1) {
 		if (++steps > step_limit) { w.status |= DSB_ST_TIMEOUT; break; }
@@ -3040,10 +3063,10 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 			uint32_t next_step = c_t_offset;
 			if (next_step < 12) break;
 			uint32_t max_search_ref;
-			if (c_h->q_st < 600) {
+			if (ch_q_st < 600) {
 				if (last_search == true) break;
 				last_search = true;
-				max_search_ref = c_h->q_st + 60;
+				max_search_ref = ch_q_st + 60;
 			} else max_search_ref = c_t_offset;
 			max_search_ref = MINV(600u, max_search_ref);
 			if (t_offset_global == 0 && c_t_offset < 50 + max_search_ref)
@@ -3053,7 +3076,7 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 			wave_sync();
 			int search_q_st = (int)best_q - 1000;
 			search_q_st = MAXV(search_q_st, 0);
-			int search_q_ed = MINV((uint32_t)(search_q_st + 2000), c_h->q_st - 1);
+			int search_q_ed = MINV((uint32_t)(search_q_st + 2000), ch_q_st - 1);
 			TXC(w, 9);
 			TX0(w, t_lm);
 			sdp_match(w, search_q_st, search_q_ed, q_str, ref + 50, max_search_ref, key_len, tbl, c_t_offset - max_search_ref, false);
@@ -3076,6 +3099,7 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 			w.steps = steps;
 			total_max_score = MAXV(score_ori, max_score) - c_len + sdp_middle_M2(w, combined->cur, q_str, tbl, key_len);
 			steps = w.steps;
+			ch_q_st = c_h->q_st;
 			score_ori = total_max_score; max_sms_id = 0;
 			w.n_sms = 0;
 			p = push_sms(w); n_sms = 1;
