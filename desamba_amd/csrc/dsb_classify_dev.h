@@ -1785,50 +1785,7 @@ DV uint32_t sdp_visit(uint32_t &lsteps, const uint32_t step_limit, int &st, cons
 	return cnt;
 }
 
-// ---- sdp_match in phases ------------------------------------------------------------------------------------------
-// A 600-base step of an extension probes ~150 reference positions: three groups of 64 lanes.  Worked on group after group
-// (sdp_match_groups below, rounds 1-2) every group is a chain of dependent round trips of its own -- reference bytes, table
-// walk, the loads of the two exact-match extensions, scan, store -- and only the few lanes whose 9-mer occurs in the window
-// (one in nine) take part in the expensive middle of it.  Here up to DSB_SDP_G groups go through the phases together: (A) the
-// 9-mers and the table walks of all of them (LDS), collecting at most DSB_SDP_INL window positions per probed position; (B) the
-// first words of both extensions of every candidate loaded at once, then the extensions; (C) per group the scan over the
-// lanes and the stores, in the reference's order (probed position ascending, window position ascending within it).  A chunk in
-// which some probed position has more candidates than a lane keeps inline (repeats) goes group by group as before.
-#define DSB_SDP_G 3
-#define DSB_SDP_INL 2
-// phase A for one probed position: its 9-mer, the walk of its table chain; returns the number of window positions found
-// (DSB_SDP_INL + 1: more than the lane keeps), cq[] ascending
-template <bool FWD, class P8>
-DV uint32_t sdp_collect(uint32_t &lsteps, const uint32_t step_limit, int &st, const SdpArgsT<P8> &a, int i, const SdpRef rf, uint32_t (&cq)[DSB_SDP_INL])
-{
-	uint64_t kmer = 0;
-	{
-		const uint64_t v = rf.v;
-#pragma unroll
-		for (int j = 0; j < 8; j++) kmer |= ((v >> (8 * j)) & 0xffULL) << (16 - 2 * j);
-		kmer |= (uint64_t)rf.t8;
-		if (FWD) kmer &= 0x3FFFFULL;
-		else if (i > 4) kmer |= (uint64_t)(rf.t9 >> 2);
-	}
-	uint32_t nc = 0;
-	if (a.n_q == 0 || kmer >= (1ULL << 18)) return 0;
-	const uint32_t slots = wtab_size(a.n_q);
-	const uint32_t k32 = (uint32_t)kmer;
-	for (uint32_t sl = wtab_slot(k32, slots);;) {
-		if (++lsteps > step_limit) { st |= DSB_ST_TIMEOUT; break; }
-		const uint32_t e = a.tab[sl];
-		if (e == DSB_WTAB_EMPTY) break;
-		if ((e >> 12) == k32) {
-			if (nc == DSB_SDP_INL) return DSB_SDP_INL + 1;
-			uint32_t q = a.q_bg + (e & 0xfffu);
-			if (nc == 1 && q < cq[0]) { const uint32_t t_ = cq[0]; cq[0] = q; q = t_; }
-			cq[nc++] = q;
-		}
-		sl = sl + 1 == slots ? 0 : sl + 1;
-	}
-	return nc;
-}
-// phase B for one candidate whose first extension words are loaded (xb: the eight bases left of the 9-mer, xf: the eight right
+// one candidate whose first extension words are loaded (xb: the eight bases left of the 9-mer, xf: the eight right
 // of it): the node, or nothing (src/cly.c:2390-2436)
 template <bool FWD, class P8>
 DV bool sdp_emit1(const SdpArgsT<P8> &a, int i, P8 c_t, uint32_t q_pos, uint64_t xb, uint64_t xf, DsbSms &o)
@@ -1855,7 +1812,8 @@ DV bool sdp_emit1(const SdpArgsT<P8> &a, int i, P8 c_t, uint32_t q_pos, uint64_t
 		return true;
 	}
 }
-// the groups [g_lo, g_hi) one after the other (a chunk with a crowded probed position)
+// the groups of 64 probed positions [g_lo, g_hi) one after the other: reference bytes, table walk, the two exact-match extensions,
+// scan over the lanes, stores (the path of narrow windows, and of the windows whose pairs overflow sdp_match_inv's list)
 template <bool FWD, class P8>
 DV void sdp_match_groups(const SdpArgsT<P8> &a, uint32_t g_lo, uint32_t g_hi, uint32_t n_pos, const int lane, uint32_t *red, DsbSms *sms, const uint32_t sms_cap,
                          uint32_t &lsteps, const uint32_t step_limit, int &st, uint32_t &n_sms, uint32_t &mirror_bad)
@@ -1891,69 +1849,7 @@ DN uint32_t sdp_match_t(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms)
 	// the context lives in memory (it is shared by reference with non-inlined callers): work on copies
 	const int lane = DSB_LANE; uint32_t *const red = w.red; DsbSms *const sms = w.sms; const uint32_t sms_cap = w.x->sms_cap;
 	uint32_t lsteps = w.lsteps, mirror_bad = 0; int st = 0; const uint32_t step_limit = w.step_limit;
-	for (uint32_t g0 = 0; g0 < n_pos && !(st & DSB_ST_SMS_OVF); g0 += DSB_SDP_G * DSB_WAVE) {
-		// (A) 9-mers and table walks of up to DSB_SDP_G groups
-		SdpRef rf[DSB_SDP_G]; uint32_t cq[DSB_SDP_G][DSB_SDP_INL], nc[DSB_SDP_G]; bool crowded = false;
-#pragma unroll
-		for (int u = 0; u < DSB_SDP_G; u++) {
-			const uint32_t pI = g0 + (uint32_t)u * DSB_WAVE + (uint32_t)lane;
-			rf[u].v = 0; rf[u].t8 = rf[u].t9 = 0;
-			if (pI < n_pos) rf[u] = sdp_ref_load<FWD, P8>(a, 4 + 4 * (int)pI);
-		}
-#pragma unroll
-		for (int u = 0; u < DSB_SDP_G; u++) {
-			const uint32_t pI = g0 + (uint32_t)u * DSB_WAVE + (uint32_t)lane;
-			cq[u][0] = cq[u][1] = 0;
-			nc[u] = pI < n_pos ? sdp_collect<FWD, P8>(lsteps, step_limit, st, a, 4 + 4 * (int)pI, rf[u], cq[u]) : 0u;
-			crowded |= nc[u] > DSB_SDP_INL;
-		}
-		if (dsb_ballot64(crowded)) {
-			sdp_match_groups<FWD, P8>(a, g0, g0 + DSB_SDP_G * DSB_WAVE, n_pos, lane, red, sms, sms_cap, lsteps, step_limit, st, n_sms, mirror_bad);
-			continue;
-		}
-		// (B) the first words of both extensions of every candidate, then the extensions
-		uint64_t xb[DSB_SDP_G][DSB_SDP_INL], xf[DSB_SDP_G][DSB_SDP_INL];
-#pragma unroll
-		for (int u = 0; u < DSB_SDP_G; u++) {
-			const int i = 4 + 4 * (int)(g0 + (uint32_t)u * DSB_WAVE + (uint32_t)lane);
-			P8 c_t = sdp_ct<FWD, P8>(a, i);
-#pragma unroll
-			for (int c = 0; c < DSB_SDP_INL; c++) {
-				xb[u][c] = xf[u][c] = 0;
-				if ((uint32_t)c < nc[u]) { const uint32_t q = cq[u][c]; xb[u][c] = ld_u64(AQ(a, q - 1) - 7) ^ ld_u64(c_t - 1 - 7); xf[u][c] = ld_u64(AQ(a, q + 9)) ^ ld_u64(c_t + 9); }
-			}
-		}
-		DsbSms nd[DSB_SDP_G][DSB_SDP_INL]; uint32_t cnt[DSB_SDP_G];
-#pragma unroll
-		for (int u = 0; u < DSB_SDP_G; u++) {
-			const int i = 4 + 4 * (int)(g0 + (uint32_t)u * DSB_WAVE + (uint32_t)lane);
-			P8 c_t = sdp_ct<FWD, P8>(a, i);
-			cnt[u] = 0;
-#pragma unroll
-			for (int c = 0; c < DSB_SDP_INL; c++) {
-				DsbSms o; o.t_pos = o.q_pos = o.len = o.score = 0;
-				if ((uint32_t)c < nc[u] && sdp_emit1<FWD, P8>(a, i, c_t, cq[u][c], xb[u][c], xf[u][c], o)) { if (cnt[u] == 0) nd[u][0] = o; else nd[u][1] = o; cnt[u]++; }
-			}
-		}
-		// (C) per group: places by a scan over the lanes, stores
-#pragma unroll
-		for (int u = 0; u < DSB_SDP_G; u++) {
-			if (g0 + (uint32_t)u * DSB_WAVE >= n_pos) break;
-			uint32_t total, off = grp_excl_scan_u(red, lane, cnt[u], &total);
-			if (total == 0) continue;
-			if (n_sms + total > sms_cap) { st |= DSB_ST_SMS_OVF; break; }
-			DsbSms *dst = sms + n_sms + off;
-#pragma unroll
-			for (int k = 0; k < DSB_SDP_INL; k++) {
-				if ((uint32_t)k >= cnt[u]) break;
-				const DsbSms v = k == 0 ? nd[u][0] : nd[u][1];
-				dst[k].len = v.len; dst[k].q_pos = v.q_pos; dst[k].t_pos = v.t_pos;
-				if (a.lnodes && n_sms + off + (uint32_t)k < 64u) { uint4 r; r.x = v.t_pos; r.y = v.q_pos; r.z = v.len; r.w = 0; a.lnodes[n_sms + off + (uint32_t)k] = r; }
-			}
-			n_sms += total;
-		}
-		wave_sync();
-	}
+	sdp_match_groups<FWD, P8>(a, 0, n_pos, n_pos, lane, red, sms, sms_cap, lsteps, step_limit, st, n_sms, mirror_bad);
 	// (the budget and the status bits of the lanes become the wavefront's: the largest count, the union of the bits)
 	const uint32_t ls = (uint32_t)grp_max_i(red, lane, (int)(lsteps >> 1));
 	const bool any_to = dsb_ballot64((st & DSB_ST_TIMEOUT) != 0) != 0, any_ovf = dsb_ballot64((st & DSB_ST_SMS_OVF) != 0) != 0;
@@ -1966,7 +1862,7 @@ DN uint32_t sdp_match_t(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms)
 // A step of the right / left extension looks ~148 reference 9-mers (every 4th of 600 bases) up among the 9-mers of ~2000 read
 // positions.  Rounds 1-3 hashed the 2000 (32 LDS compare-and-swap chains per lane and step: a sixth of k_classify on the strain
 // index, profiles/r03_*) to walk 148 chains of which one in nine is not empty.  The join does not care which side is hashed:
-// here the <= 256 reference 9-mers go into a small table (2-3 inserts per lane) plus a 16-kbit filter of their hashes, every
+// here the <= 300 reference 9-mers go into a small table (2-3 inserts per lane) plus a 16-kbit filter of their hashes, every
 // lane streams its run of read positions through the filter with plain LDS reads that do not depend on each other, walks the
 // table for the one position in sixty that passes, and appends (probed position, read position) to a list.  The list -- ~35
 // pairs per step -- is ranked into the reference's order (probed position ascending, read position ascending within it) and
