@@ -2280,7 +2280,7 @@ DN void sdp_batch_old(WCtxL &w, DpBatchL &b)
 					int ovl = MAXV(oq, ot); ovl = MAXV(ovl, 0);
 					const bool skip = ovl > 6;
 					const bool brk = !skip & ((MODE == 2) ? (lt[j] + 600 < C[u]) : (C[u] < lt[j]));
-					const int ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3)) - ovl;
+					const int ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3) - (uint32_t)ovl);   // (unsigned: a lane that fails the first test carries a huge ovl)
 					anyb |= brk;
 					if (!skip & !brk & (ai <= 200) & (ns > tb)) tb = ns;
 				}
@@ -2314,7 +2314,7 @@ DN void sdp_batch_old(WCtxL &w, DpBatchL &b)
 					int ovl = MAXV(oq, ot); ovl = MAXV(ovl, 0);
 					skip = ovl > 6;
 					brk = !skip & ((MODE == 2) ? (lt[j] + 600 < C[u]) : (C[u] < lt[j]));
-					ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3)) - ovl;
+					ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3) - (uint32_t)ovl);   // (unsigned: a lane that fails the first test carries a huge ovl)
 				}
 				bool ok = !skip & !brk & (ai <= 200);
 				uint64_t bm = dsb_ballot64(brk);
@@ -2404,7 +2404,7 @@ DN void sdp_batch_old_mw(DsbMw *mw, uint4 *ring, uint32_t *red, const int lane, 
 						int ovl = MAXV(oq, ot); ovl = MAXV(ovl, 0);
 						const bool skip = ovl > 6;
 						const bool brk = !skip & ((MODE == 2) ? (lt[j] + 600 < C[u]) : (C[u] < lt[j]));
-						const int ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3)) - ovl;
+						const int ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3) - (uint32_t)ovl);   // (unsigned: a lane that fails the first test carries a huge ovl)
 						anyb |= brk;
 						if (!skip & !brk & (ai <= 200) & (ns > tb)) tb = ns;
 					}
@@ -2433,7 +2433,7 @@ DN void sdp_batch_old_mw(DsbMw *mw, uint4 *ring, uint32_t *red, const int lane, 
 						int ovl = MAXV(oq, ot); ovl = MAXV(ovl, 0);
 						skip = ovl > 6;
 						brk = !skip & ((MODE == 2) ? (lt[j] + 600 < C[u]) : (C[u] < lt[j]));
-						ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3)) - ovl;
+						ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3) - (uint32_t)ovl);   // (unsigned: a lane that fails the first test carries a huge ovl)
 					}
 					bool ok = !skip & !brk & (ai <= 200);
 					if (dsb_ballot64(brk)) { const int first_brk = grp_first(red, lane, brk); ok = ok & (lane < first_brk); cutm |= 1u << j; }

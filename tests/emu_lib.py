@@ -2,7 +2,7 @@
 import ctypes as C
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EMU_SO = os.path.join(ROOT, "tests", "emu", "libdsbemu.so")
+EMU_SO = os.environ.get("DSB_EMU_LIB", os.path.join(ROOT, "tests", "emu", "libdsbemu.so"))   # override: the sanitizer build of tests/tools/emu_sanitize.sh
 
 
 class EmuHit(C.Structure):
