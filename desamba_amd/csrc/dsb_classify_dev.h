@@ -973,6 +973,38 @@ DN void fast_classify(WCtxL &w, SDirL *s_d_, uint32_t read_len)
 	wave_sync();
 	if (n_top == 0) return;
 	DsbAnchor *const main_anc = w.anc; uint32_t *const red = w.red; DsbAnchor *const lane_anc = w.lane_anc;
+	// The order the walks are handed out in: longest island first.  A 50-kbp read has ~500 top islands of 1 to 60 windows (a walk
+	// costs about its island's length), eight per lane: handed out by index, the wave ends up waiting for whichever lane drew a
+	// long one last (makespan 93-116 units where 73 are possible, tools note in DESIGN 2.2).  A counting sort by length, 64 buckets;
+	// the order within a bucket is whatever the atomics make it -- results are committed in island order below either way.
+	uint32_t *const ord = w.sortidx;                                      // (idle until the chains are sorted)
+	const bool lpt = n_top > 2u * DSB_WAVE && n_top <= 2u * w.anc_cap_main && w.wtab != nullptr;
+	if (lpt) {
+		lds_u32 *const hist = (lds_u32 *)w.wtab;                          // 64 counts, 64 start offsets (the window table is idle here)
+		for (int i = lane; i < 128; i += DSB_WAVE) hist[i] = 0;
+		wave_sync();
+		for (uint32_t t = (uint32_t)lane; t < n_top; t += DSB_WAVE) {
+			const uint32_t b = MINV((uint32_t)sv_b[top_idx[t]].len, 63u);
+#ifdef DSB_HOST_EMU
+			hist[b]++;
+#else
+			__hip_atomic_fetch_add(hist + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+		}
+		wave_sync();
+		if (lane == 0) { uint32_t acc = 0; for (int b = 63; b >= 0; b--) { hist[64 + b] = acc; acc += hist[b]; } }
+		wave_sync();
+		for (uint32_t t = (uint32_t)lane; t < n_top; t += DSB_WAVE) {
+			const uint32_t b = MINV((uint32_t)sv_b[top_idx[t]].len, 63u);
+#ifdef DSB_HOST_EMU
+			const uint32_t pos = hist[64 + b]++;
+#else
+			const uint32_t pos = __hip_atomic_fetch_add(hist + 64 + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+			ord[pos] = t;
+		}
+		wave_sync();
+	}
 	// Phase 1: every lane walks islands into its own scratch (anchors, visited-row set), taking the next unwalked
 	// island from a counter in LDS when it is done with one -- island walks differ widely in length, and fixed
 	// rounds of 64 would wait for the longest of each round.  Per island: which lane, where in its scratch, how
@@ -991,12 +1023,13 @@ DN void fast_classify(WCtxL &w, SDirL *s_d_, uint32_t read_len)
 #endif
 			if (t >= n_top) break;
 			const uint32_t start = l.n_anc; const int st_before = l.status;
+			const uint32_t ti = lpt ? ord[t] : t;                              // the island this lane walks now
 			// a full scratch: an overflowing walk would overwrite its last slot, which belongs to an earlier island
-			if (start >= DSB_LANE_ANC_CAP) { info[t] = (uint32_t)lane | (start << 6) | (1u << 27); continue; }
-			int flag = fast_island(x, l, s_d, read_len, top_idx[t]);
+			if (start >= DSB_LANE_ANC_CAP) { info[ti] = (uint32_t)lane | (start << 6) | (1u << 27); continue; }
+			int flag = fast_island(x, l, s_d, read_len, top_idx[ti]);
 			int ovf = ((l.status & DSB_ST_ANC_OVF) && !(st_before & DSB_ST_ANC_OVF)) ? 1 : 0;
 			if (ovf) { l.status &= ~DSB_ST_ANC_OVF; l.n_anc = start; }
-			info[t] = (uint32_t)lane | (start << 6) | ((l.n_anc - start) << 16) | ((uint32_t)flag << 26) | ((uint32_t)ovf << 27);
+			info[ti] = (uint32_t)lane | (start << 6) | ((l.n_anc - start) << 16) | ((uint32_t)flag << 26) | ((uint32_t)ovf << 27);
 		}
 		// each lane bumped its own copy of the set generation: continue from the largest so that no lane's stale
 		// entries can look current; a lane that ran out of its loop budget marks the read (the reference has no budget)
