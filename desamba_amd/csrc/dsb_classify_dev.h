@@ -195,7 +195,9 @@ typedef const __attribute__((address_space(3))) DsbDevIndex *DsbXP;
 // barrier and are woken for the old-predecessor pass of the batched sparse DP (sdp_batch_old_mw), the one piece of a
 // tandem-repeat read that costs tens of milliseconds.  One of these per workgroup, in LDS.
 #define DSB_MW_MAXW 8
+#ifndef DSB_MW_MIN_PREDS
 #define DSB_MW_MIN_PREDS 2048      /* shorter predecessor lists stay on wave 0 alone */
+#endif
 struct DsbMw {
 	uint32_t cmd;                  // 1 / 2: DP pass of a right / left extension batch; 3: the read is done
 	uint32_t n0, K;
