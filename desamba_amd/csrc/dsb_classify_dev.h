@@ -163,9 +163,9 @@ template <class T> DV T dsb_shfl(T v, int l) { static_assert(sizeof(T) == 4, "32
 
 // words in LDS, addressed as LDS (ds_read / ds_cmpst / ds_add), not through generic pointers
 #ifdef DSB_HOST_EMU
-typedef uint32_t lds_u32;
+typedef uint32_t lds_u32; typedef uint64_t lds_u64;
 #else
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint32_t lds_u32; typedef __attribute__((address_space(3))) uint64_t lds_u64;
 #endif
 
 // Work counters of a launch (the terms of the algorithmic bytes): [0] occ() evaluations, [1] MEM searches
@@ -1462,6 +1462,49 @@ DN void glibc_sort_chains(WCtxL &w, uint32_t n)
 	}
 }
 
+// The end of resolve_tree (src/cly.c:343-348): qsort by chain_cmp_by_score, then the first five chains and every further one with
+// a top anchor stay.  The comparator is a consistent weak order (top-anchor chains first, then by score), so glibc's merge sort is
+// any stable sort, the chains with a top anchor all come first, and what stays is the first max(5, their number) of the sorted
+// list: every chain's place is the number of chains that precede it (better key, or equal key and smaller index) -- counted by the
+// whole wavefront from keys in LDS instead of a merge sort of 48-byte records by one lane (a read has 100-300 chains here).
+DN void chain_top_select(WCtxL &w)
+{
+	const uint32_t n = w.n_hit; const int lane = DSB_LANE;
+	if (n <= 1) return;
+	DsbChain *const H = w.hit, *const T = w.hit_tmp;
+	if (!w.wtab || n > DSB_WTAB_SLOTS / 2) {                              // (no room for the keys: as the reference does it)
+		DSB_SERIAL(w) {
+			glibc_sort_chains<0>(w, n);
+			uint32_t rst_num = MINV(5u, n);
+			while (rst_num < n && H[rst_num].with_top_anchor == 1) rst_num++;
+			w.n_hit = rst_num;
+		}
+		serial_end(w);
+		return;
+	}
+	lds_u64 *const K = (lds_u64 *)w.wtab;                                 // smaller key = earlier in the sorted list
+	uint32_t tops = 0;
+	for (uint32_t i = (uint32_t)lane; i < n; i += DSB_WAVE) {
+		const DsbChain *c = H + i;
+		int sa = c->sum_score + ((c->q_ed - c->q_st) << 1); sa -= (c->indel << 2);      // chain_cmp_by_score, src/cly.c:38-52
+		K[i] = ((uint64_t)(c->with_top_anchor ? 0u : 1u) << 32) | (uint64_t)(uint32_t)(0x7fffffffLL - (long long)sa);
+		tops += c->with_top_anchor ? 1u : 0u;
+	}
+	uint32_t n_tops; grp_excl_scan_u(w.red, lane, tops, &n_tops);
+	wave_sync();
+	const uint32_t keep = n_tops >= 5u ? n_tops : MINV(5u, n);
+	for (uint32_t i = (uint32_t)lane; i < n; i += DSB_WAVE) {
+		const uint64_t me = K[i]; uint32_t rank = 0;
+		for (uint32_t j = 0; j < n; j++) { const uint64_t o = K[j]; rank += (o < me || (o == me && j < i)) ? 1u : 0u; }
+		if (rank < keep) T[rank] = H[i];
+	}
+	wave_sync();
+	for (uint32_t i = (uint32_t)lane; i < keep; i += DSB_WAVE) H[i] = T[i];
+	wave_sync();
+	w.n_hit = keep;
+	wave_sync();
+}
+
 // resolve_tree (src/cly.c:326-349)
 DN void resolve_tree(WCtxL &w)
 {
@@ -1479,12 +1522,9 @@ DN void resolve_tree(WCtxL &w)
 	DSB_SERIAL(w) {
 		if (w.n_anc < 50) for (uint32_t i = 0; i < w.n_anc; i++) chain_insert_M2(w, i);
 		else if (!wave_dp) chain_dp_M3<false>(w);
-		if (w.n_hit > 1) glibc_sort_chains<0>(w, w.n_hit);
-		int rst_num = MINV(5, w.n_hit);
-		while (rst_num < w.n_hit && w.hit[rst_num].with_top_anchor == 1) rst_num++;
-		w.n_hit = rst_num;
 	}
 	serial_end(w);
+	chain_top_select(w);
 }
 
 // ---- sc_hash_idx / combine_chain (src/cly.c:1691-1710,1763-1808) -------------------------------
@@ -2585,11 +2625,6 @@ DV void fill_window(const WCtxL &w, uint8_t *win, int n)
 #define DSB_GL_K 10000
 struct DsbGap { uint32_t pq, pt, pl, cq, ct, cl; int32_t gain; uint32_t pad; };   // previous / current anchor: index_in_read, ref_offset, mtch_len
 
-#ifdef DSB_HOST_EMU
-typedef uint64_t lds_u64;
-#else
-typedef __attribute__((address_space(3))) uint64_t lds_u64;
-#endif
 DV uint64_t gl_funnel(uint64_t a, uint64_t b, uint32_t s) { return s ? ((a << s) | (b >> (64 - s))) : a; }
 // 29 bases of the 2-bit reference text from base p on, first base in the top bits (the low 6 bits are not to be used)
 DV uint64_t gl_tload(const uint8_t *txt, uint64_t p) { return __builtin_bswap64(dsb_g64u(txt + (p >> 2))) << (((uint32_t)p & 3u) * 2); }
@@ -2728,6 +2763,7 @@ DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int k
 	// 2. one gap per lane (gap_lane): most gaps are scored here, 64 at a time.  The lanes of a wavefront finish together, so
 	// gaps of similar cost (probed reference positions x query words) share a round: counting sort by log2 of the cost,
 	// heaviest first (the order changes no result: every gap's gain is its own).
+	TX0(w, t_gl);
 	if (w.pk[tbl] && wtab) {
 		uint32_t *const perm = w.sortidx;
 		lds_u32 *hist = (lds_u32 *)w.ring;                                  // 32 words: counts, then start offsets (the DP ring is idle here)
@@ -2761,6 +2797,7 @@ DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int k
 		for (uint32_t k = (uint32_t)lane; k < n_gap; k += DSB_WAVE) { const uint32_t gi = perm[k]; G[gi].gain = gap_lane(w, G[gi], w.pk[tbl], t_offset); }
 		wave_sync();
 	}
+	TX1(w, 5, t_gl);
 	// 3. what is left, one gap at a time on the whole wavefront
 	uint64_t pf_q = 0; uint32_t pf_t = 0; int32_t pf_qlo = 0; uint64_t pf_toff = ~0ULL; bool pf_has_q = false, pf_has_t = false;
 	for (uint32_t gi = 0; gi < n_gap; gi++) {
