@@ -429,7 +429,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--no-cli", action="store_true", help="skip the runs of the deSAMBA binary (cli_end_to_end)")
-    ap.add_argument("--cli-reads", type=int, default=131072, help="reads per GPU of the CLI run on the headline index")
+    ap.add_argument("--cli-reads", type=int, default=262144, help="reads per GPU of the CLI run on the headline index")
     ap.add_argument("--no-demo-index", action="store_true", help="skip the measurements on the reference's demo index")
     ap.add_argument("--demo-batches", type=int, default=8)
     ap.add_argument("--demo-steps", type=int, default=8)
