@@ -2761,35 +2761,38 @@ DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int k
 	n_gap = dsb_shfl(n_gap, 0); tail_len = dsb_shfl(tail_len, 0);
 	wave_sync();
 	// 2. one gap per lane (gap_lane): most gaps are scored here, 64 at a time.  The lanes of a wavefront finish together, so
-	// gaps of similar cost (probed reference positions x query words) share a round: counting sort by log2 of the cost,
-	// heaviest first (the order changes no result: every gap's gain is its own).
+	// gaps of similar cost (probed reference positions x query words) share a round: counting sort by the cost's logarithm
+	// (to a quarter octave), heaviest first (the order changes no result: every gap's gain is its own).
 	TX0(w, t_gl);
 	if (w.pk[tbl] && wtab) {
 		uint32_t *const perm = w.sortidx;
-		lds_u32 *hist = (lds_u32 *)w.ring;                                  // 32 words: counts, then start offsets (the DP ring is idle here)
-		for (int i = lane; i < 32; i += DSB_WAVE) hist[i] = 0;
+		lds_u32 *hist = (lds_u32 *)wtab;                                    // 64 counts, then 64 start offsets (gap_lane takes the table's LDS over afterwards)
+		for (int i = lane; i < 128; i += DSB_WAVE) hist[i] = 0;
 		wave_sync();
 		for (uint32_t gi = (uint32_t)lane; gi < n_gap; gi += DSB_WAVE) {
 			const DsbGap g = G[gi];
 			const int tl = (int)(g.ct - ((g.pt - 3) + g.pl) + 3);
 			uint32_t cost = 0;
 			if (tl > 12) { const uint32_t nq = g.cq - (g.pq + g.pl - 8); cost = ((uint32_t)tl >> 2) * ((nq >> 5) + 1); }
-			const uint32_t bk = cost ? 32u - (uint32_t)__builtin_clz(cost) : 0u;   // 0 .. 15 for the gaps the lane form takes
-			G[gi].pad = bk > 15 ? 15u : bk;
+			// bucket = log2 of the cost and its next two bits: the lanes of a round differ by a quarter at most, not by a factor of two
+			uint32_t bk = 0;
+			if (cost) { const uint32_t lg = 31u - (uint32_t)__builtin_clz(cost); bk = 4u * lg + (lg >= 2 ? (cost >> (lg - 2)) & 3u : 0u) + 1u; }
+			bk = bk > 63u ? 63u : bk;
+			G[gi].pad = bk;
 #ifdef DSB_HOST_EMU
-			hist[G[gi].pad]++;
+			hist[bk]++;
 #else
-			__hip_atomic_fetch_add(hist + (bk > 15 ? 15u : bk), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			__hip_atomic_fetch_add(hist + bk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 		}
 		wave_sync();
-		if (lane == 0) { uint32_t acc = 0; for (int b = 15; b >= 0; b--) { hist[16 + b] = acc; acc += hist[b]; } }
+		if (lane == 0) { uint32_t acc = 0; for (int b = 63; b >= 0; b--) { hist[64 + b] = acc; acc += hist[b]; } }
 		wave_sync();
 		for (uint32_t gi = (uint32_t)lane; gi < n_gap; gi += DSB_WAVE) {
 #ifdef DSB_HOST_EMU
-			const uint32_t pos = hist[16 + G[gi].pad]++;
+			const uint32_t pos = hist[64 + G[gi].pad]++;
 #else
-			const uint32_t pos = __hip_atomic_fetch_add(hist + 16 + G[gi].pad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			const uint32_t pos = __hip_atomic_fetch_add(hist + 64 + G[gi].pad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 			perm[pos] = gi;
 		}
