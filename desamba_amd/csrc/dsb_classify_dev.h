@@ -1950,6 +1950,7 @@ DN uint32_t sdp_match_t(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms)
 #define DSB_INV_MINQ 96u        /* narrower windows: hashing them is as cheap */
 #define DSB_INV_NONE 0xffffffffu
 #define DSB_INV_WORDS (DSB_INV_SLOTS + DSB_INV_FWORDS + 4u + 2u * DSB_INV_PAIRS)   /* words of w.wtab it uses */
+static_assert(DSB_INV_WORDS <= DSB_WTAB_SLOTS && DSB_INV_MAXPOS <= 512u && DSB_WTAB_MAXQ <= 4096u, "sdp_match_inv: its tables live in the window table's LDS; 9 bits of probed position and 12 of read position per pair");
 template <bool FWD>
 DV uint64_t sdp_kmer(const SdpRef rf, int i)
 {
