@@ -121,7 +121,7 @@ typedef struct {
 	size_t batch_bytes, batch_reads, batch_max_bytes, batch_max_reads;   /* a batch closes once it has batch_reads reads AND batch_bytes of text, or either maximum */
 	size_t seg_min;                                   /* smallest piece worth a parse thread of its own */
 	int n_parse, n_format, n_inflate;
-	int ramp, every_wave;                             /* batches of growing size at the start (2 = a quarter, a half, full); tests: every wave closes a batch */
+	int ramp, every_wave;                             /* batches of growing size at the start (1 = a half, then full -- the default; 2 = a quarter, a half, full); tests: every wave closes a batch */
 	unsigned long total;
 	unsigned long n_badqual;                          /* records dropped because their quality string had the wrong length */
 	unsigned long n_status;                           /* reads whose device status stayed non-zero after the second run */
@@ -829,7 +829,7 @@ static void app_defaults(app_t *a)
 	a->batch_reads = env_size("DSB_CLI_BATCH_READS", 65536, 0); a->batch_bytes = (size_t)1 << 30;
 	a->batch_max_bytes = env_size("DSB_CLI_BATCH_MB", (size_t)8 << 30, 20); a->batch_max_reads = env_size("DSB_CLI_BATCH_MAX_READS", (size_t)4 << 20, 0);
 	if (a->batch_bytes > a->batch_max_bytes) a->batch_bytes = a->batch_max_bytes;
-	a->ramp = getenv("DSB_CLI_RAMP") ? atoi(getenv("DSB_CLI_RAMP")) : 2; if (a->ramp < 0 || a->ramp > 8) a->ramp = 0;
+	a->ramp = getenv("DSB_CLI_RAMP") ? atoi(getenv("DSB_CLI_RAMP")) : 1; if (a->ramp < 0 || a->ramp > 8) a->ramp = 0;
 	if (getenv("DSB_CLI_BATCH_KB")) { a->wave_bytes = env_size("DSB_CLI_BATCH_KB", 0, 10); a->batch_reads = 1; a->batch_bytes = 1; a->ramp = 0; a->every_wave = 1; }
 	if (a->wave_bytes < 64) a->wave_bytes = 64;
 	a->seg_min = env_size("DSB_CLI_SEG_KB", (size_t)2 << 20, 10);
