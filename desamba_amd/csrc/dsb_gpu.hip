@@ -781,7 +781,7 @@ struct dsb_ctx {
 	int hist_max = 0;
 	hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; dsb_timing timing; unsigned long long p1 = 0;
 	hipStream_t stream3 = nullptr; hipEvent_t ev_heavy3 = nullptr;    // k_classify_heavy: several wavefronts on each of the very heaviest reads
-	hipStream_t stream2 = nullptr; hipEvent_t ev_order = nullptr, ev_heavy = nullptr, ev_hprobe = nullptr, ev_cls = nullptr;   // the heaviest reads run beside the seed probe
+	hipStream_t stream2 = nullptr; hipEvent_t ev_order = nullptr, ev_heavy = nullptr, ev_hprobe = nullptr, ev_cls = nullptr, ev_cls_wait = nullptr;   // the heaviest reads run beside the seed probe
 	uint32_t *dbg_host = nullptr, *dbg_dev = nullptr;
 	std::vector<UpStage> up; size_t up_chunk = 0;     // pinned staging of dsb_batch_upload (upload_gather)
 	dsb_opts opts;
@@ -822,6 +822,7 @@ extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 	for (int i = 0; i < 4; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	if (c->ev_order) hipEventDestroy(c->ev_order);
 	if (c->ev_cls) hipEventDestroy(c->ev_cls);
+	if (c->ev_cls_wait) hipEventDestroy(c->ev_cls_wait);
 	if (c->ev_heavy) hipEventDestroy(c->ev_heavy);
 	if (c->ev_hprobe) hipEventDestroy(c->ev_hprobe);
 	if (c->stream2) hipStreamDestroy(c->stream2);
@@ -851,7 +852,7 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));   // contexts on one device overlap each other's copies and kernels
 	for (int i = 0; i < 3; i++) CK(hipEventCreate(&c->ev[i]));
 	CK(hipEventCreateWithFlags(&c->ev[3], hipEventBlockingSync));     // the end of a batch is waited for asleep (a spinning host thread per context costs a CPU of the quota)
-	CK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)); CK(hipEventCreate(&c->ev_order)); CK(hipEventCreate(&c->ev_cls));
+	CK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)); CK(hipEventCreate(&c->ev_order)); CK(hipEventCreate(&c->ev_cls)); CK(hipEventCreateWithFlags(&c->ev_cls_wait, hipEventBlockingSync));
 	CK(hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming)); CK(hipEventCreateWithFlags(&c->ev_hprobe, hipEventDisableTiming));
 	CK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)); CK(hipEventCreateWithFlags(&c->ev_heavy3, hipEventDisableTiming));
 	if (rc == DSB_OK) rc = stage_acquire(idx, device_id, &c->staged);           // the index goes to HBM once per (index, device)
@@ -1300,17 +1301,17 @@ static void launch_classify(K kern, dsb_ctx *c, hipStream_t st, unsigned grid, c
 	                   pre_seeds ? c->d_seeds : nullptr, (const DsbSeedInfo *)c->d_sinfo, (const uint64_t *)c->d_pk, (uint32_t)((pre_seeds && s.max_len <= DSB_GROUP_MAX_LEN && !getenv("DSB_NO_GROUP")) ? (getenv("DSB_GROUP_HEAD") ? (unsigned)atoi(getenv("DSB_GROUP_HEAD")) : 8u * grid) : 0u));
 }
 
-static int batch_run_locked(dsb_ctx *c);
+static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn);
 extern "C" int dsb_batch_run(dsb_ctx *c)
 {
 	if (!c) return DSB_EINVAL;
 	// Contexts that share a device take turns with their kernels: two batches side by side run 1.25x as long as one after
 	// the other (two persistent launches halve each other's wave slots and both end in their tails), while the uploads and
 	// fetches of the waiting context still overlap the running one's kernels -- which is what the second context is for.
-	if (c->staged && !getenv("DSB_NO_TURN")) { std::lock_guard<std::mutex> g(c->staged->run_mu); return batch_run_locked(c); }
-	return batch_run_locked(c);
+	if (c->staged && !getenv("DSB_NO_TURN")) { std::unique_lock<std::mutex> g(c->staged->run_mu); return batch_run_locked(c, &g); }
+	return batch_run_locked(c, nullptr);
 }
-static int batch_run_locked(dsb_ctx *c)
+static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn)
 {
 	HIPCHK(hipSetDevice(c->device));
 	InSlot &s = c->in[c->cur];
@@ -1415,6 +1416,7 @@ static int batch_run_locked(dsb_ctx *c)
 		if (dbg) memset(c->dbg_host, 0, 32 * 65536 * sizeof(uint32_t));
 		launch_classify(k_classify, c, c->stream, slots, dx1, s, (uint32_t)n, nullptr, (const uint32_t *)c->d_order, c->arena, c->d_counters, dbgp, (uint32_t)n_heavy, 0u, 0, use_scan);
 		HIPCHK(hipEventRecord(c->ev_cls, c->stream));
+		HIPCHK(hipEventRecord(c->ev_cls_wait, c->stream));
 		if (n_heavy) { HIPCHK(hipStreamWaitEvent(c->stream, c->ev_heavy, 0)); if (c->timing.n_heavy_mw) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_heavy3, 0)); }
 		if (dbg) {
 			// watchdog: poll the stream; dump the progress words of every slot if the kernel runs long
@@ -1448,6 +1450,10 @@ static int batch_run_locked(dsb_ctx *c)
 	hipLaunchKernelGGL(k_collect_retry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const DsbReadOut *)c->d_rout, (uint32_t)n, c->d_score, c->d_counters + 6, retry_mask, 0);
 	launch_classify(k_classify_second, c, c->stream, (unsigned)c->n_slots_big, dx2, s, 0u, (const unsigned int *)(c->d_counters + 6), (const uint32_t *)c->d_score, c->arena_big, c->d_counters + 7, nullptr, 0u, 0u, 2, use_scan);
 	HIPCHK(hipEventRecord(c->ev[3], c->stream));
+	// The device's turn ends with the main launch: what may still follow it -- the early launch's last reads (tandem repeats: a
+	// handful of wavefronts), the pass over the reads given up as heavy, the second run -- leaves most of the device idle, and the
+	// other context's next batch starts with its HBM-bound seed lookup.  (DSB_TURN_WHOLE_RUN=1: the turn lasts to the end, as before.)
+	if (turn && !getenv("DSB_TURN_WHOLE_RUN")) { HIPCHK(hipEventSynchronize(c->ev_cls_wait)); turn->unlock(); }
 	HIPCHK(hipEventSynchronize(c->ev[3]));
 	{
 		// The hit buffer holds 16 n + 4096 records (the reference's lists are unbounded).  The device counts every
