@@ -82,7 +82,8 @@ def kseq_records(data: bytes):
 @pytest.fixture(scope="module")
 def harness(built, tmp_path_factory):
     exe = tmp_path_factory.mktemp("cli") / "parse_harness"
-    subprocess.check_call(["gcc", "-O2", "-std=gnu99", "-I" + os.path.join(ROOT, "include"), "-o", str(exe),
+    # DSB_HARNESS_CFLAGS="-fsanitize=address,undefined -g": the reader under the sanitizers (tests/tools/cli_sanitize.sh)
+    subprocess.check_call(["gcc", "-O2", "-std=gnu99"] + os.environ.get("DSB_HARNESS_CFLAGS", "").split() + ["-I" + os.path.join(ROOT, "include"), "-o", str(exe),
                            os.path.join(ROOT, "tests", "cli", "parse_harness.c"), "-L" + os.path.join(ROOT, "desamba_amd"), "-ldesamba_amd",
                            "-Wl,-rpath," + os.path.join(ROOT, "desamba_amd"), "-lpthread", "-lz", "-ldl"])
     return str(exe)
