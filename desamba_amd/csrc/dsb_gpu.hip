@@ -770,6 +770,7 @@ struct dsb_ctx {
 	unsigned int *d_counters = nullptr;            // u32: [0] work, [1] hits, [2..3] u64 table-1 probes, [4] early work, [6] listed reads, [7] work of the second run, [8] third run list, [9] its work; u64 x 4 at +16 (main launch), +24 (early launch), +32 (second runs): occ, MEM searches, SA lookups, reference bases
 	DsbSlotArena arena; int n_slots = 0, n_extra = 0;   // n_extra: slots behind the n_slots of the main launch, for the early launch of the heaviest reads (batches of >= 4096 reads)
 	DsbSlotArena arena_big; int n_slots_big = 0;  // second run of reads that outgrew an arena or their loop budget
+	unsigned mw_reads = 16;                          // reads of the early launch that get eight wavefronts each: grows when batches end in their tails (dsb_batch_run)
 	uint32_t *d_score = nullptr, *d_order = nullptr, *d_heavy = nullptr; size_t cap_score = 0, cap_order = 0, cap_heavy = 0;
 	DsbSeed *d_seeds = nullptr; DsbSeedInfo *d_sinfo = nullptr; size_t cap_seeds = 0, cap_sinfo = 0;   // seed lists of the batch (k_seed_scan)
 	uint8_t *d_summ = nullptr; int summ_shift = 0;   // summary of exist table 0 in use (the staged index's, or none with synthetic tables)
@@ -1369,8 +1370,9 @@ static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn)
 		hipLaunchKernelGGL(k_seed_probe_reads, dim3(n_heavy * DSB_HPROBE_SPLIT), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const uint32_t *)c->d_order, c->d_pk, c->d_bits, c->d_summ, c->summ_shift);
 		HIPCHK(hipEventRecord(c->ev_hprobe, c->stream));
 		HIPCHK(hipEventRecord(c->ev_order, c->stream));             // order_ms covers scoring, ordering and these probes
-		// the very heaviest of them (DSB_HEAVY_MW, default 16) get eight wavefronts each (k_classify_heavy) on a third stream
-		unsigned n_mw = 16;
+		// the very heaviest of them (DSB_HEAVY_MW; by default 16, more once the batches of this ctx have ended in their tails,
+		// see the end of this function) get eight wavefronts each (k_classify_heavy) on a third stream
+		unsigned n_mw = c->mw_reads;
 		if (const char *e = getenv("DSB_HEAVY_MW")) n_mw = (unsigned)atoi(e);
 		if (n_mw > n_heavy) n_mw = n_heavy;
 		c->timing.n_heavy_mw = n_mw;
@@ -1506,6 +1508,11 @@ static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn)
 	HIPCHK(hipMemcpy(&c->p1, c->d_counters + 2, 8, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(&c->timing.n_retry, c->d_counters + 6, 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(&c->timing.n_requeue, c->d_counters + 12, 4, hipMemcpyDeviceToHost));
+	// A batch that made the device wait for its early launches (no read handed over, nothing run again: the wait was for the
+	// heaviest reads themselves -- on the demo index one read in a thousand lies in a tandem repeat and takes 150 ms on a
+	// wavefront, longer than the main launch) gets more of its heaviest reads onto eight wavefronts next time: 16 -> 32 -> 64.
+	// Their helper wavefronts hold wave slots, which costs a batch without such reads 1 %: so only on evidence, and per ctx.
+	if (c->timing.tail_ms > 3.0f && c->timing.n_requeue == 0 && c->timing.n_retry == 0 && c->timing.n_early && c->mw_reads < 64) c->mw_reads *= 2;
 	HIPCHK(hipMemcpy(wk, c->d_counters + 16, 96, hipMemcpyDeviceToHost));
 	c->timing.windows = s.total_windows; c->timing.probes_t1 = c->p1; c->timing.bases = s.total_bases;
 	c->timing.seed_scan = use_scan ? 1 : 0;
