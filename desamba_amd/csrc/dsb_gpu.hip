@@ -770,7 +770,7 @@ struct dsb_ctx {
 	unsigned int *d_counters = nullptr;            // u32: [0] work, [1] hits, [2..3] u64 table-1 probes, [4] early work, [6] listed reads, [7] work of the second run, [8] third run list, [9] its work; u64 x 4 at +16 (main launch), +24 (early launch), +32 (second runs): occ, MEM searches, SA lookups, reference bases
 	DsbSlotArena arena; int n_slots = 0, n_extra = 0;   // n_extra: slots behind the n_slots of the main launch, for the early launch of the heaviest reads (batches of >= 4096 reads)
 	DsbSlotArena arena_big; int n_slots_big = 0;  // second run of reads that outgrew an arena or their loop budget
-	unsigned mw_reads = 16;                          // reads of the early launch that get eight wavefronts each: grows when batches end in their tails (dsb_batch_run)
+	unsigned mw_reads = 16; bool mw_grown = false; int mw_calm = 0;   // reads of the early launch that get eight wavefronts each: follows what the batches of this ctx show (end of dsb_batch_run)
 	uint32_t *d_score = nullptr, *d_order = nullptr, *d_heavy = nullptr; size_t cap_score = 0, cap_order = 0, cap_heavy = 0;
 	DsbSeed *d_seeds = nullptr; DsbSeedInfo *d_sinfo = nullptr; size_t cap_seeds = 0, cap_sinfo = 0;   // seed lists of the batch (k_seed_scan)
 	uint8_t *d_summ = nullptr; int summ_shift = 0;   // summary of exist table 0 in use (the staged index's, or none with synthetic tables)
@@ -1512,7 +1512,12 @@ static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn)
 	// heaviest reads themselves -- on the demo index one read in a thousand lies in a tandem repeat and takes 150 ms on a
 	// wavefront, longer than the main launch) gets more of its heaviest reads onto eight wavefronts next time: 16 -> 32 -> 64.
 	// Their helper wavefronts hold wave slots, which costs a batch without such reads 1 %: so only on evidence, and per ctx.
-	if (c->timing.tail_ms > 3.0f && c->timing.n_requeue == 0 && c->timing.n_retry == 0 && c->timing.n_early && c->mw_reads < 64) c->mw_reads *= 2;
+	// ... and a ctx whose batches have never waited drops them after four calm batches (the headline index: +1 %); a wait brings
+	// them back.
+	if (c->timing.tail_ms > 3.0f && c->timing.n_requeue == 0 && c->timing.n_retry == 0 && c->timing.n_early) {
+		if (c->mw_reads < 64) c->mw_reads = c->mw_reads ? c->mw_reads * 2 : 16;
+		c->mw_grown = true; c->mw_calm = 0;
+	} else if (c->timing.tail_ms < 0.5f && !c->mw_grown && c->mw_reads && c->timing.n_early && ++c->mw_calm >= 4) c->mw_reads = 0;
 	HIPCHK(hipMemcpy(wk, c->d_counters + 16, 96, hipMemcpyDeviceToHost));
 	c->timing.windows = s.total_windows; c->timing.probes_t1 = c->p1; c->timing.bases = s.total_bases;
 	c->timing.seed_scan = use_scan ? 1 : 0;
