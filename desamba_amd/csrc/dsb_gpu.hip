@@ -770,6 +770,7 @@ struct dsb_ctx {
 	unsigned int *d_counters = nullptr;            // u32: [0] work, [1] hits, [2..3] u64 table-1 probes, [4] early work, [6] listed reads, [7] work of the second run, [8] third run list, [9] its work; u64 x 4 at +16 (main launch), +24 (early launch), +32 (second runs): occ, MEM searches, SA lookups, reference bases
 	DsbSlotArena arena; int n_slots = 0, n_extra = 0;   // n_extra: slots behind the n_slots of the main launch, for the early launch of the heaviest reads (batches of >= 4096 reads)
 	DsbSlotArena arena_big; int n_slots_big = 0;  // second run of reads that outgrew an arena or their loop budget
+	uint32_t hint_len = 0;                           // the read length the caller announced (dsb_opts.max_read_len): arenas are never built for less
 	unsigned mw_reads = 16; bool mw_grown = false; int mw_calm = 0;   // reads of the early launch that get eight wavefronts each: follows what the batches of this ctx show (end of dsb_batch_run)
 	uint32_t *d_score = nullptr, *d_order = nullptr, *d_heavy = nullptr; size_t cap_score = 0, cap_order = 0, cap_heavy = 0;
 	DsbSeed *d_seeds = nullptr; DsbSeedInfo *d_sinfo = nullptr; size_t cap_seeds = 0, cap_sinfo = 0;   // seed lists of the batch (k_seed_scan)
@@ -872,12 +873,13 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 		// hints: arenas and batch buffers are allocated now instead of inside the first batch
 		if (c->opts.max_read_len && c->opts.max_batch_reads) {
 			const uint32_t L = c->opts.max_read_len; const size_t n = c->opts.max_batch_reads; const int k = c->dx.ek_len;
+			c->hint_len = L;
 			const uint64_t nwin = L >= 40 ? L - k + 1 : 0;
 			if (c->opts.max_batch_bases) {
 				// a batch of n reads with B bases in all, the longest of L: upper bounds of the sums upload_views forms read by read
 				const uint64_t B = c->opts.max_batch_bases;
 				rc = ensure_buffers(c, n, L, 2 * B + n * (uint64_t)(DSB_QPAD_L + DSB_QPAD_R + 256), B / 16 + 4 * (uint64_t)n, B / 32 + 4 * (uint64_t)n, B / 2 + 64 * (uint64_t)n);
-				for (InSlot &s : c->in) { if (!rc) rc = grow(&s.d_rd, &s.cap_rd, n + 1); if (!rc) rc = grow(&s.d_ascii, &s.cap_ascii, (size_t)B + 64); }
+				for (InSlot &s : c->in) { if (!rc) rc = grow(&s.d_rd, &s.cap_rd, n + 1); if (!rc) rc = grow(&s.d_ascii, &s.cap_ascii, (size_t)B + 64); if (!rc) rc = grow(&s.d_scan_order, &s.cap_scan_order, n + 1); }
 			} else
 			rc = ensure_buffers(c, n, L, n * ((DSB_QPAD_L + 2 * (uint64_t)L + DSB_QPAD_R + 255) & ~(uint64_t)255), n * 2 * ((L + 31) / 32 + 1), n * 2 * ((nwin + 63) / 64), n * (((uint64_t)L >> 1) + 64));
 		}
@@ -984,10 +986,15 @@ extern "C" void dsb_host_free(void *p) { if (p) hipHostFree(p); }
 template <class T> static int grow(T **p, size_t *cap, size_t need)
 {
 	if (need <= *cap) return 0;
+	// (an allocation on the per-batch path: hipFree / hipMalloc wait for the device and were seen to stall a sibling context's
+	// batch for seconds -- the hints of dsb_ctx_create exist to keep this from happening; DSB_UPLOAD_TRACE shows each one)
+	const bool tr = getenv("DSB_UPLOAD_TRACE") != nullptr; struct timespec t0, t1; if (tr) clock_gettime(CLOCK_MONOTONIC, &t0);
+	const size_t old = *cap;
 	if (*p) hipFree(*p);
 	size_t n = need + need / 8 + 1024;
 	if (hipMalloc((void **)p, n * sizeof(T)) != hipSuccess) { *p = nullptr; *cap = 0; return DSB_ENOMEM; }
 	*cap = n;
+	if (tr) { clock_gettime(CLOCK_MONOTONIC, &t1); fprintf(stderr, "[upload] a device buffer grew from %zu to %zu elements of %zu bytes (needed: %zu) in %.3f s\n", old, n, sizeof(T), need, (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)); }
 	return 0;
 }
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -1036,6 +1043,7 @@ static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int wan
 	const bool oversized = a.base && a.max_len > 4 * (uint64_t)max_len + 65536 && a.stride * ((size_t)*cur_slots + have_extra) > ((size_t)4 << 30);
 	if (fits && !oversized && (*cur_slots >= want_slots || a.max_len > max_len)) return 0;   // (fewer slots than wanted are kept if they were a budget decision for longer reads)
 	if (check_only) return 1;                      // would have to be built: the caller comes again with the memory budget
+	if (getenv("DSB_UPLOAD_TRACE")) fprintf(stderr, "[upload] an arena is (re)built: has max_len %u, %d + %d slots, sms_cap %u; wanted max_len %u, %d + %d slots, sms_cap %u%s\n", a.base ? a.max_len : 0u, *cur_slots, have_extra, a.base ? a.sms_cap : 0u, max_len, want_slots, extra_slots, sms_cap, oversized ? " (oversized)" : "");
 	if (a.base && !oversized && a.max_len > max_len) max_len = a.max_len;
 	if (a.base) { hipFree(a.base); a.base = nullptr; budget += a.stride * ((size_t)*cur_slots + have_extra); }
 	DsbSlotArena n = a;
@@ -1077,6 +1085,10 @@ static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_b
 	int want = c->opts.n_slots > 0 ? c->opts.n_slots : 256 * 12;
 	if ((size_t)want > n) want = (int)(n ? n : 1);
 	if (want < c->n_slots) want = c->n_slots;
+	// The arenas are built for the length the caller announced even when this batch's reads are shorter: the four-read batch that
+	// warms a new ctx up (longest read 1500) used to count a 100-kbase arena as "oversized", give it back and leave the first real
+	// batch to build it again -- on the per-batch path, behind the sibling context's kernels: seconds (PacBio-mixed reads, CLI).
+	if (max_len < c->hint_len) max_len = c->hint_len;
 	uint32_t cap1 = dsb_sms_cap_for(max_len);
 	const bool cap_forced = getenv("DSB_SMS_CAP") != NULL;                      // diagnostics: a small arena forces second runs
 	if (cap_forced) { cap1 = (uint32_t)atol(getenv("DSB_SMS_CAP")); if (cap1 < 64) cap1 = 64; }

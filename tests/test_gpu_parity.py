@@ -621,3 +621,23 @@ def test_short_reads_64_per_wavefront(gpu, demo, oracle, tmp_path, monkeypatch):
     monkeypatch.setenv("DSB_NO_GROUP", "1")
     hits2, sam2 = classify_all(D, ctx, recs)
     assert sam2 == sam
+
+
+@pytest.mark.gpu
+def test_hinted_ctx_allocates_nothing_per_batch(demo, capfd, monkeypatch):
+    """dsb_ctx_create with hints sizes everything; no batch may allocate afterwards.  (Round 3: the four-read warm-up batch
+    of a ctx hinted for 100-kbase reads counted its arenas as oversized and gave them back -- the first real batch rebuilt
+    them on the per-batch path, which stalls a sibling context for seconds.)"""
+    import desamba_amd as D
+    monkeypatch.setenv("DSB_UPLOAD_TRACE", "1")
+    idx = D.Index(demo["index"])
+    ctx = D.Ctx(idx, 0, max_read_len=100064, max_batch_reads=8192, max_batch_bases=8192 * 12000)
+    capfd.readouterr()                                   # (what the set-up allocated)
+    recs = D.read_fastq(os.path.join(GOLDEN, "synth", "pb.fq")) + D.read_fastq(demo["fastq"], 200)      # mixed lengths, all far below the hint
+    for part in (recs[: len(recs) // 2], recs[len(recs) // 2:], recs):
+        res = ctx.classify(D.make_reads(part))
+        assert all(res.reads[i].status == 0 for i in range(len(part)))
+    err = capfd.readouterr().err
+    assert "[upload]" in err                             # the trace is on
+    assert "grew" not in err and "(re)built" not in err, err
+    ctx.close(); idx.close()
