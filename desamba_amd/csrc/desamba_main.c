@@ -611,8 +611,12 @@ static void read_gz(rd_t *r, inflater_t *f)
 static void peek_input(app_t *a)
 {
 	const char *path = a->argv[a->first_file];
-	int fd = open(path, O_RDONLY); struct stat st;
-	if (fd < 0 || fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) { if (fd >= 0) close(fd); return; }
+	struct stat st;
+	/* (only regular files are looked at -- and only they are opened: opening a FIFO here and closing it again would take the
+	   writer's reader away, the writer would die of SIGPIPE and the real reader would wait for it for ever) */
+	if (stat(path, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size == 0) return;
+	int fd = open(path, O_RDONLY);
+	if (fd < 0) return;
 	static batch_t pb; int last = 0; uint32_t hist = 0; size_t used = 0, total = 0; int gz = is_gzip(fd);
 	const int compat_on = g_compat.on; g_compat.on = 0;           /* (a look only: the slots of the FASTA quirk are not touched) */
 	char *t = NULL, *buf = NULL; size_t len = 0;
@@ -644,8 +648,12 @@ static void peek_input(app_t *a)
 		if (nf > (double)a->batch_max_reads) nf = (double)a->batch_max_reads;
 		nf = nf * 1.3 + (double)a->wave_bytes / bpr + 16;                 /* the last batch of a file may take a quarter more; a batch ends with a whole wave */
 		if (nf > (double)total / bpr * 1.05 + 16) nf = (double)total / bpr * 1.05 + 16;
-		if (nf < 4294967295.0 && hist * 1.25 < 4294967295.0) {
-			a->o.max_batch_reads = (uint32_t)nf; a->o.max_batch_bases = (uint64_t)(nf * bases_pr * 1.1) + 4096; a->o.max_read_len = (uint32_t)(hist * 1.25) + 64;
+		/* the longest read of the whole input from the longest of the sample: reads of one length (a simulated set, short reads) get
+		   a quarter on top, mixed lengths (longest > 2 x mean: PacBio, real ONT) twice the sample's longest -- an arena that has to be
+		   rebuilt for a longer read later costs seconds */
+		const double len_margin = (double)hist > 2.0 * bases_pr ? 2.0 : 1.25;
+		if (nf < 4294967295.0 && hist * len_margin < 4294967295.0) {
+			a->o.max_batch_reads = (uint32_t)nf; a->o.max_batch_bases = (uint64_t)(nf * bases_pr * 1.1) + 4096; a->o.max_read_len = (uint32_t)(hist * len_margin) + 64;
 		}
 		if (a->trace) fprintf(stderr, "[trace] input: %.0f bytes of text and %.0f bases per read, longest %u (first %zu reads) -> buffers for batches of %u reads, %.2f Gbases\n", bpr, bases_pr, hist, pb.n,
 		                      a->o.max_batch_reads, a->o.max_batch_bases / 1e9);
@@ -895,9 +903,9 @@ static int classify_main(int argc, char **argv)
 	const char *index_dir = argv[optind++];
 	a.argc = argc; a.argv = argv; a.first_file = optind;
 	for (int i = optind; i < argc; i++) {
-		int fd = open(argv[i], O_RDONLY);
-		if (fd < 0) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", argv[i]); exit(1); }
-		close(fd);
+		/* (the check the reference makes when it opens the file, made before the index is loaded; not by opening: a FIFO's
+		   writer would lose its reader again and die) */
+		if (access(argv[i], R_OK) != 0) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", argv[i]); exit(1); }
 	}
 	app_defaults(&a);
 	setvbuf(a.out, NULL, _IOFBF, 8 << 20);

@@ -1089,6 +1089,8 @@ static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_b
 	// warms a new ctx up (longest read 1500) used to count a 100-kbase arena as "oversized", give it back and leave the first real
 	// batch to build it again -- on the per-batch path, behind the sibling context's kernels: seconds (PacBio-mixed reads, CLI).
 	if (max_len < c->hint_len) max_len = c->hint_len;
+	// ... and an arena that has to grow for a longer read grows by a quarter more than needed (the next longer read is coming)
+	if (c->arena.base && max_len > c->arena.max_len) { const uint64_t g = (uint64_t)max_len + max_len / 4; max_len = g > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)g; }
 	uint32_t cap1 = dsb_sms_cap_for(max_len);
 	const bool cap_forced = getenv("DSB_SMS_CAP") != NULL;                      // diagnostics: a small arena forces second runs
 	if (cap_forced) { cap1 = (uint32_t)atol(getenv("DSB_SMS_CAP")); if (cap1 < 64) cap1 = 64; }

@@ -641,3 +641,26 @@ def test_hinted_ctx_allocates_nothing_per_batch(demo, capfd, monkeypatch):
     assert "[upload]" in err                             # the trace is on
     assert "grew" not in err and "(re)built" not in err, err
     ctx.close(); idx.close()
+
+
+@pytest.mark.gpu
+def test_cli_reads_from_a_fifo(gpu, demo, golden_md5, tmp_path):
+    """A FIFO as input (the reference reads whatever gzopen opens).  Round 3: the look at the input before the contexts are
+    made opened the FIFO and closed it again -- the writer died of SIGPIPE and the run waited for it for ever."""
+    import subprocess
+    import threading
+    fifo = tmp_path / "reads.fifo"
+    os.mkfifo(fifo)
+    out = tmp_path / "fifo.sam"
+    data = open(demo["fastq"], "rb").read()
+
+    def feed():
+        with open(fifo, "wb") as f:
+            f.write(data)
+    t = threading.Thread(target=feed, daemon=True)
+    t.start()
+    cli = os.path.join(ROOT, "desamba_amd", "bin", "deSAMBA")
+    p = subprocess.run([cli, "classify", demo["index"], str(fifo), "-o", str(out)], stderr=subprocess.PIPE, timeout=120)
+    t.join(10)
+    assert p.returncode == 0, p.stderr
+    assert hashlib.md5(open(out, "rb").read()).hexdigest() == golden_md5
