@@ -46,7 +46,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime starts (see dsb_hw_queues in dsb_gpu.hip)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime starts (the HIP runtime reads it at its first call)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.3 TB/s achievable)
 CLI = os.path.join(ROOT, "desamba_amd", "bin", "deSAMBA")

@@ -618,6 +618,7 @@ static void peek_input(app_t *a)
 	int fd = open(path, O_RDONLY);
 	if (fd < 0) return;
 	static batch_t pb; int last = 0; uint32_t hist = 0; size_t used = 0, total = 0; int gz = is_gzip(fd);
+	const unsigned long n_badqual0 = a->n_badqual;                /* (the reader parses this wave again: its bad records are counted there) */
 	const int compat_on = g_compat.on; g_compat.on = 0;           /* (a look only: the slots of the FASTA quirk are not touched) */
 	char *t = NULL, *buf = NULL; size_t len = 0;
 	if (!gz) {
@@ -662,6 +663,7 @@ static void peek_input(app_t *a)
 	if (t) munmap(t, len);
 	free(buf); close(fd);
 	memset(&a->tr, 0, sizeof a->tr);
+	a->n_badqual = n_badqual0;
 	g_compat.on = compat_on;
 }
 
@@ -677,24 +679,34 @@ static void *reader_main(void *arg)
 	inflater_t *inf = calloc((size_t)(nf > 0 ? nf : 1), sizeof *inf);
 	int *fds = xmalloc((size_t)(nf > 0 ? nf : 1) * sizeof *fds); size_t *sizes = xmalloc((size_t)(nf > 0 ? nf : 1) * sizeof *sizes);
 	int ahead = a->n_inflate > 1 ? (a->n_inflate < 4 ? a->n_inflate : 4) : 1;   /* inflaters running before their file's turn */
-	for (int i = 0; i < nf; i++) {
-		const char *path = a->argv[a->first_file + i];
-		fds[i] = open(path, O_RDONLY); struct stat st;
-		if (fds[i] < 0 || fstat(fds[i], &st) != 0) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", path); exit(1); }
-		sizes[i] = (size_t)st.st_size;
-		inf[i].a = a; inf[i].path = path; inf[i].fd = fds[i];
-		pthread_mutex_init(&inf[i].mu, NULL); pthread_cond_init(&inf[i].cv, NULL);
-		if (!S_ISREG(st.st_mode)) inf[i].stream = 1;
-		else if (is_gzip(fds[i])) {
-			inf[i].zlen = sizes[i];
-			inf[i].z = mmap(NULL, sizes[i], PROT_READ, MAP_SHARED, fds[i], 0);
-			if (inf[i].z == MAP_FAILED) die("[classify] cannot map the input file");
-		}
-	}
+	for (int i = 0; i < nf; i++) { fds[i] = -1; sizes[i] = 0; inf[i].a = a; inf[i].path = a->argv[a->first_file + i]; inf[i].fd = -1; pthread_mutex_init(&inf[i].mu, NULL); pthread_cond_init(&inf[i].cv, NULL); }
 	libdeflate_find();
 	for (int i = 0; i < nf; i++) {
-		for (int j = i; j < nf && j < i + ahead; j++)
+		/* A file is opened (and a .gz mapped) only when its inflater starts or at its turn, as the reference opens one file at a time
+		 * (src/cly_mt.c:551-558): at most `ahead` + 1 descriptors are open however many files are listed, and what is not a regular
+		 * file -- a FIFO, "-" = stdin (xzopen, src/lib/utils.c:64-68) -- is opened strictly in order, at its turn: opening the next
+		 * FIFO early would block on a writer that is itself waiting for this one to be read. */
+		for (int j = i; j < nf && j < i + ahead; j++) {
+			if (fds[j] < 0) {
+				const char *path = inf[j].path; struct stat st;
+				if (!strcmp(path, "-")) { if (j != i) continue; fds[j] = dup(0); inf[j].stream = 1; if (fds[j] < 0) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", path); exit(1); } }
+				else {
+					if (stat(path, &st) != 0) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", path); exit(1); }
+					if (!S_ISREG(st.st_mode) && j != i) continue;
+					fds[j] = open(path, O_RDONLY);
+					if (fds[j] < 0 || fstat(fds[j], &st) != 0) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", path); exit(1); }
+					sizes[j] = (size_t)st.st_size;
+					if (!S_ISREG(st.st_mode)) inf[j].stream = 1;
+					else if (is_gzip(fds[j])) {
+						inf[j].zlen = sizes[j];
+						inf[j].z = mmap(NULL, sizes[j], PROT_READ, MAP_SHARED, fds[j], 0);
+						if (inf[j].z == MAP_FAILED) die("[classify] cannot map the input file");
+					}
+				}
+				inf[j].fd = fds[j];
+			}
 			if ((inf[j].z || inf[j].stream) && !inf[j].started) { inf[j].started = 1; pthread_create(&inf[j].th, NULL, inflater_main, &inf[j]); }
+		}
 		fprintf(stderr, "Processing file: [%s].\n", a->argv[a->first_file + i]);
 		compat_new_file();
 		if (inf[i].started) { read_gz(&r, &inf[i]); pthread_join(inf[i].th, NULL); if (inf[i].z) munmap((void *)inf[i].z, inf[i].zlen); }
@@ -905,7 +917,7 @@ static int classify_main(int argc, char **argv)
 	for (int i = optind; i < argc; i++) {
 		/* (the check the reference makes when it opens the file, made before the index is loaded; not by opening: a FIFO's
 		   writer would lose its reader again and die) */
-		if (access(argv[i], R_OK) != 0) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", argv[i]); exit(1); }
+		if (strcmp(argv[i], "-") != 0 && access(argv[i], R_OK) != 0) { fprintf(stderr, "[xzopen] fail to open file '%s'\n", argv[i]); exit(1); }
 	}
 	app_defaults(&a);
 	setvbuf(a.out, NULL, _IOFBF, 8 << 20);
@@ -980,6 +992,9 @@ int analysis_main(int argc, char **argv, const char *version);   /* desamba_anal
 #ifndef DSB_CLI_NO_MAIN
 int main(int argc, char **argv)
 {	/* dispatcher, src/main.c:35-53: `classify`, `index` and `analysis ana_meta[_base]` are in scope of this build */
+	/* two contexts per device share eight streams: with HIP's default of 4 hardware queues an upload waits behind the other
+	 * context's persistent kernel (10-15 GB/s instead of 50); read by the HIP runtime at its first call, so set here, first */
+	setenv("GPU_MAX_HW_QUEUES", "16", 0);
 	if (argc >= 2 && strcmp(argv[1], "index") == 0) return index_main(argc - 1, argv + 1);
 	if (argc >= 2 && strcmp(argv[1], "analysis") == 0) return analysis_main(argc - 1, argv + 1, dsb_version());
 	if (argc < 2 || strcmp(argv[1], "classify") != 0) {

@@ -794,8 +794,9 @@ struct dsb_ctx {
 // eight streams between them (kernels x 3, uploads), and a transfer on a stream that shares its hardware queue with the
 // other context's persistent k_classify launch waits for that launch to end: measured, the upload of a batch beside
 // the other batch's kernels runs at 10-15 GB/s with 4 queues and at 50+ GB/s with 16.  The variable is read when the HIP
-// runtime initialises (first HIP call), so it is set when this library is loaded -- unless the user has set it.
-__attribute__((constructor)) static void dsb_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// runtime initialises (first HIP call), so it is the PROCESS that sets it before its first HIP call -- the CLI's main() and
+// bench.py do; INTEGRATION.md tells embedders.  (Round 3 set it from a constructor of this library: a setenv in a dlopen'ed
+// library races with getenv in a threaded host and changes the configuration of a process that did not ask for it.)
 
 extern "C" int dsb_device_count(void)
 {

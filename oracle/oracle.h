@@ -6,7 +6,7 @@
  * Parity status: PINNED.  The restatement reproduces the reference's own demo
  * run byte for byte (SAM md5 1da908b61be240c40334b58d3c12ba2a) and
  * is cross-checked against the compiled reference (oracle/_ref/deSAMBA) on
- * synthetic reads (tests/test_oracle_vs_ref.py).
+ * synthetic reads (tests/test_oracle_golden.py::test_against_live_reference).
  *
  * Canonical semantics at the reference's undefined-behaviour sites (SURVEY.md
  * section 8 a-UB), chosen so the result of a read never depends on earlier reads:

@@ -291,3 +291,54 @@ def test_fasta_compat_matches_the_reference_reader(harness, demo, tmp_path, monk
     monkeypatch.delenv("DSB_FASTA_COMPAT")
     o = subprocess.run([harness, str(1 << 24)] + files, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
     assert o.count(b"\n") == n_all
+
+
+def _fq(prefix, n):
+    return b"".join(b"@%s%d\nACGTACGTAC\n+\n5555555555\n" % (prefix, i) for i in range(n))
+
+
+def test_files_are_opened_one_window_at_a_time(harness, tmp_path):
+    """more input files than the descriptor limit allows open at once (plain and gzip mixed): the reference opens one file at a
+    time (src/cly_mt.c:551-558); the reader here opens a file only when its inflater starts or at its turn"""
+    import resource
+    paths = []; exp = []
+    for k in range(40):
+        data = _fq(b"f%d_" % k, 3)
+        p = tmp_path / ("f%02d.fq%s" % (k, ".gz" if k % 3 == 1 else ""))
+        if k % 3 == 1:
+            with gzip.open(p, "wb") as f:
+                f.write(data)
+        else:
+            p.write_bytes(data)
+        paths.append(str(p)); exp += [n for n, _, _ in kseq_records(data)]
+    def low_limit():
+        resource.setrlimit(resource.RLIMIT_NOFILE, (16, 16))
+    out = subprocess.run([harness, "4096"] + paths, check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, preexec_fn=low_limit)
+    assert [l.split(b"\t")[0] for l in out.stdout.split(b"\n")[:-1]] == exp
+
+
+def test_fifos_fed_one_after_the_other(harness, tmp_path):
+    """several named pipes written by ONE writer, one after the other: the reader must not open the second before the first is
+    read to its end (open() of a FIFO blocks until its writer comes, and the writer is busy with the first)"""
+    import threading
+    fifos = [str(tmp_path / ("p%d" % i)) for i in range(3)]
+    for f in fifos:
+        os.mkfifo(f)
+    datas = [_fq(b"a", 4000), gzip.compress(_fq(b"b", 3000)), _fq(b"c", 10)]          # (> 64 KB: more than a pipe holds)
+    def writer():
+        for f, d in zip(fifos, datas):
+            with open(f, "wb") as h:
+                h.write(d)
+    th = threading.Thread(target=writer, daemon=True); th.start()
+    out = subprocess.run([harness, "65536"] + fifos, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=60).stdout
+    th.join(10)
+    names = [l.split(b"\t")[0] for l in out.split(b"\n")[:-1]]
+    assert names == [b"a%d" % i for i in range(4000)] + [b"b%d" % i for i in range(3000)] + [b"c%d" % i for i in range(10)]
+
+
+def test_dash_is_stdin(harness, tmp_path):
+    """`-` names the standard input (xzopen, src/lib/utils.c:64-68), plain or gzip"""
+    plain = _fq(b"s", 50); other = tmp_path / "o.fq"; other.write_bytes(_fq(b"o", 5))
+    for data in (plain, gzip.compress(plain)):
+        out = subprocess.run([harness, "4096", str(other), "-"], input=data, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=60).stdout
+        assert [l.split(b"\t")[0] for l in out.split(b"\n")[:-1]] == [b"o%d" % i for i in range(5)] + [b"s%d" % i for i in range(50)]

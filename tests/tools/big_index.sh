@@ -6,7 +6,7 @@
 #   tests/tools/big_index.sh [outdir] [Mbp]
 cd "$(dirname "$0")/../.."
 OUT=${1:-gpurun_out}; MBP=${2:-380}; D=data/big; mkdir -p "$OUT" $D/index
-R=oracle/_ref/deSAMBA_ubfree; G=desamba_amd/bin/deSAMBA; I=$D/index; T=$(nproc)
+R=oracle/_ref/deSAMBA_ubfree; G=desamba_amd/bin/deSAMBA; I=$D/index; T=$(tests/tools/host_cpus.sh)
 TIMEFORMAT="%R"
 if [ ! -f $I/deSAMBA.ref_p ]; then
 	python3 tools/synth_ref.py $D/syn.fa $MBP 1 2>&1

@@ -6,7 +6,7 @@
 cd "$(dirname "$0")/../.."
 OUT=${1:-gpurun_out}; N=${2:-262144}; mkdir -p "$OUT"
 python -c "import __graft_entry__ as g; g.demo_dir()" > "$OUT/demo.log" 2>&1
-R=oracle/_ref/deSAMBA_ubfree; G=desamba_amd/bin/deSAMBA; I=data/demo/index; T=$(nproc)
+R=oracle/_ref/deSAMBA_ubfree; G=desamba_amd/bin/deSAMBA; I=data/demo/index; T=$(tests/tools/host_cpus.sh)
 gcc -O2 -o /tmp/iobench tools/iobench.c -lpthread
 python tools/gen_fastq.py $I /dev/shm/s.fq 8192 50000 0.15 1001 ont 16
 echo "== host I/O (0.8 GB file, then a 6.6 GB one)"

@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/../.."
 OUT=${1:-gpurun_out}; mkdir -p "$OUT"
 python -c "import __graft_entry__ as g; g.demo_dir()" > "$OUT/demo.log" 2>&1
-R=oracle/_ref/deSAMBA_ubfree; G=desamba_amd/bin/deSAMBA; I=data/demo/index; T=$(nproc)
+R=oracle/_ref/deSAMBA_ubfree; G=desamba_amd/bin/deSAMBA; I=data/demo/index; T=$(tests/tools/host_cpus.sh)
 TIMEFORMAT="%R"
 SEED_SHIFT=${DSB_PARITY_SEED_SHIFT:-0}                 # other read sets: DSB_PARITY_SEED_SHIFT=100 tests/tools/full_parity.sh
 for cfg in "ont50k 65536 50000 0.15 1 ont" "ngs150 1000000 150 0.01 7 ngs" "pacbio 65536 12000 0.12 9 pacbio" "ont8k_e25 20000 8000 0.25 5 ont"; do

@@ -13,6 +13,6 @@ for hp in "default 64" "default 256" "50000000 256" "default 512"; do
 done
 unset DSB_HEAVY_PREDS DSB_HEAVY_MW DSB_HEAVY_FIRST
 $PWD/desamba_amd/bin/deSAMBA classify $I /dev/shm/y.fq -o /dev/shm/y_gpu.sam > /dev/null 2>&1
-oracle/_ref/deSAMBA_ubfree classify -t $(nproc) $I /dev/shm/y.fq -o /dev/shm/y_ref.sam > /dev/null 2>&1
+oracle/_ref/deSAMBA_ubfree classify -t $(tests/tools/host_cpus.sh) $I /dev/shm/y.fq -o /dev/shm/y_ref.sam > /dev/null 2>&1
 cmp -s /dev/shm/y_gpu.sam /dev/shm/y_ref.sam && echo "SAM identical to the reference (default settings)" || echo "SAM DIFFERS"
 rm -f /dev/shm/y.fq /dev/shm/y_gpu.sam /dev/shm/y_ref.sam
