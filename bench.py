@@ -71,6 +71,52 @@ def self_launch(a):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
+DEVICE_SOURCES = ["dsb_gpu.hip", "dsb_classify_dev.h", "dsb_wave.h", "dsb_device.h", "dsb_probe.h", "dsb_seed_scan.h"]
+
+
+def device_source_md5():
+    """md5 over the sources of the classify kernels: names the device code a PMC profile under profiles/ was taken on
+    (tools/pmc_run.sh writes the same digest into the profile; a profile of other code is never quoted)"""
+    h = hashlib.md5()
+    for f in DEVICE_SOURCES:
+        h.update(open(os.path.join(ROOT, "desamba_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def pmc_traffic(name, kernel, **match):
+    """(bytes per launch, source) from profiles/<name> if it was taken on this device code and workload; else (None, why)"""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        prof = json.load(open(path))
+    except (OSError, ValueError):
+        return None, "no profile %s" % name
+    wl = prof.get("workload", {})
+    if wl.get("device_source_md5") != device_source_md5():
+        return None, "profiles/%s was taken on other device code (md5 %s, this build %s): not quoted" % (name, wl.get("device_source_md5"), device_source_md5())
+    for k, v in match.items():
+        if wl.get(k) != v:
+            return None, "profiles/%s: %s = %r, this run %r: not quoted" % (name, k, wl.get(k), v)
+    cn = prof["counters"].get(kernel)
+    if not cn or "FETCH_SIZE" not in cn or "WRITE_SIZE" not in cn:
+        return None, "profiles/%s holds no FETCH_SIZE / WRITE_SIZE of %s" % (name, kernel)
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own passes; KB -> bytes; random 64-byte gathers, so the guide's x2 correction
+    # for 128-byte streaming requests does not apply
+    return (cn["FETCH_SIZE"] + cn["WRITE_SIZE"]) * 1024.0, "profiles/%s (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes, per launch; device source md5 %s matches this build)" % (name, device_source_md5())
+
+
+def gather_ceiling(table_mib):
+    """tools/gather_bench on a table of that size, here and now on this GPU: what random 64-byte lines reach (GB/s), or None"""
+    exe = os.path.join(ROOT, "tools", "gather_bench")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, str(table_mib)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=120).stdout.decode()
+        v = [float(m) for m in re.findall(r"=\s*([0-9.]+) GB/s", out)]
+        return max(v) if v else None
+    except (OSError, subprocess.SubprocessError):
+        return None
+
+
 def host_cpus():
     """CPUs this process may run on, and the CPU quota of its control group (None: unlimited)"""
     n = len(os.sched_getaffinity(0)); quota = None
@@ -119,9 +165,10 @@ class Gen:
         if not self.h:
             raise RuntimeError("readgen_open(%s)" % index_dir)
 
-    def fill(self, buf, cap, n, length, err, seed, threads):
+    def fill(self, buf, cap, n, length, err, seed, threads, profile=0):
+        """profile 0: reads of one length (ONT / NGS error mix); 1: PacBio-mixed (log-normal lengths 500 .. 80000, `length` ignored)"""
         off = (C.c_uint64 * n)(); ln = (C.c_uint32 * n)()
-        nb = self.L.readgen_fill(self.h, buf, cap, n, length, err, seed, 0, threads, off, ln)
+        nb = self.L.readgen_fill(self.h, buf, cap, n, length, err, seed, profile, threads, off, ln)
         if nb < 0:
             raise RuntimeError("readgen_fill: buffer too small")
         return nb, off, ln
@@ -202,6 +249,24 @@ def cpu_baseline(index_dir, sample_fq, n_sample, bases, gpu_sam, t1_reads):
                     os.remove(x)
     os.remove(out)
     return base, parity
+
+
+def oracle_probe_counts(index_dir, fq_text, n_reads=48):
+    """What the reference's scan consumes (SURVEY.md 8d's definition of the seed lookup's algorithmic bytes): P0 = windows probed in
+    filter table 0, P1 = probes that go on to table 1, counted by the CPU restatement (oracle/) on the first reads of the CPU
+    sample -- the checker beside the measurement, never on a GPU path.  -> {p0_per_base, p1_per_base, reads} or None"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        ora = oracle_lib.Oracle(index_dir)
+    except Exception:
+        return None
+    lines = fq_text.split(b"\n"); p0 = p1 = bases = n = 0; hist = 0
+    for i in range(1, min(len(lines), 4 * n_reads), 4):
+        seq = lines[i]
+        ora.classify(seq, hist); hist = max(hist, len(seq))
+        c = ora.counters(); p0 += c[0]; p1 += c[1]; bases += len(seq); n += 1
+    return {"p0_per_base": p0 / max(bases, 1), "p1_per_base": p1 / max(bases, 1), "reads": n} if n else None
 
 
 def cli_end_to_end(index_dir, gen_args, n_reads, devices, lib_sam_md5=None, lib_n=0, reps=2):
@@ -313,18 +378,10 @@ class Measure:
                     "work_per_bp": {"occ": acc["occ"] / max(acc["bases"], 1), "mem_searches": acc["mem"] / max(acc["bases"], 1), "sa_lookups": acc["sa"] / max(acc["bases"], 1),
                                     "ref_bases": acc["rb"] / max(acc["bases"], 1)}}
         roof_cls["frac"] = roof_cls["achieved"] / HBM_PEAK_GBS
-        # HBM-side traffic per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command (separate passes; KB ->
-        # bytes; random 64-B gathers, so the guide's x2 correction for 128-B streaming requests does not apply), committed
-        # under profiles/ -- quoted only when that profile was taken on this workload with this library build
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_%s.json" % profile_tag)))
-            wl = prof.get("workload", {})
-            if wl.get("reads_per_gpu") == R and wl.get("read_len") == self.Lr and wl.get("library") == self.D.lib().dsb_version().decode():
-                cn = prof["counters"]
-                roof_seed["traffic"] = (cn[kseed]["FETCH_SIZE"] + cn[kseed]["WRITE_SIZE"]) * 1024.0
-                roof_cls["traffic"] = (cn["k_classify"]["FETCH_SIZE"] + cn["k_classify"]["WRITE_SIZE"]) * 1024.0
-        except Exception:
-            pass
+        # HBM-side traffic per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command, committed under profiles/ --
+        # quoted only when that profile was taken on this workload with THIS device code (md5 of the kernel sources)
+        roof_seed["traffic"], roof_seed["traffic_source"] = pmc_traffic("r04_pmc_traffic_%s.json" % profile_tag, kseed, reads_per_gpu=R, read_len=self.Lr)
+        roof_cls["traffic"], roof_cls["traffic_source"] = pmc_traffic("r04_pmc_traffic_%s.json" % profile_tag, "k_classify", reads_per_gpu=R, read_len=self.Lr)
         return roof_cls, roof_seed, classify_s >= probe_s
 
     def kernel_ms(self):
@@ -395,6 +452,76 @@ class Measure:
         self.ctx.close()
 
 
+def resident_batch(D, L, idx, index_dir, local, n, length, err, seed, profile, threads, workload, parity_reads=0):
+    """One batch of n synthetic reads simulated from the index, resident in HBM: the whole device path four times, the median of the
+    last three.  parity_reads > 0: the first so many reads also through the reference's UB-pinned build on the same index directory
+    (SAM compared read by read) and through the stock build (timed: the CPU figure beside it)."""
+    max_l = 80000 if profile == 1 else length
+    cap = n * (2 * max_l + 48) + (1 << 20) if profile == 0 else n * 2 * 13500 + n * 48 + (64 << 20)
+    p = L.dsb_host_alloc(cap)
+    gen = Gen(index_dir)
+    try:
+        nb, off, ln = gen.fill(p, cap, n, length, err, seed, threads, profile)
+    finally:
+        gen.close()
+    longest = max(ln[i] for i in range(0, n, max(1, n // 4096))) if profile == 1 else length
+    ctx = D.Ctx(idx, local, max_read_len=(80000 if profile == 1 else length), max_batch_reads=n)
+    ctx.upload_text(p, nb, off, ln, n)
+    ms = []; tm = None
+    for _ in range(4):
+        ctx.run(); tm = ctx.timing(); ms.append(tm.total_ms)
+    med = sorted(ms[1:])[1]
+    res = ctx.fetch(strict=False)
+    bases = tm.bases
+    out = {"workload": workload, "reads": n, "bases": bases, "reads_per_s": n / (med / 1e3), "gbp_per_s": bases / (med / 1e3) / 1e9, "ms": med,
+           "kernel_ms": {"k_encode": tm.encode_ms, "order": tm.order_ms, "seed": tm.seed_probe_ms, "k_classify": tm.classify_ms, "tail": tm.tail_ms},
+           "reads_mapped_frac": sum(1 for i in range(0, n, 64) if res.reads[i].n > 0) / (len(range(0, n, 64)) or 1),
+           "reads_with_device_status": sum(1 for i in range(n) if res.reads[i].status), "longest_read_sampled": longest}
+    if parity_reads and os.path.exists(UBF):
+        ns = min(parity_reads, n)
+        raw = C.string_at(p, off[ns - 1] + 2 * ln[ns - 1] + 8)
+        names = []; pos = 0
+        for i in range(ns):
+            e = raw.index(b"\n", pos); names.append(raw[pos + 1:e]); pos = off[i] + 2 * ln[i] + 4
+        reads = D.make_reads([(names[i], raw[off[i]:off[i] + ln[i]], None) for i in range(ns)])
+        gpu = sam_by_read(D.format_sam(idx, reads, res))
+        fq = os.path.join(SHM, "dsb_bench_c5.fq")
+        with open(fq, "wb") as f:
+            f.write(raw[:pos])
+        cores, quota = host_cpus(); t = max(1, int(round(quota))) if quota and int(round(quota)) < cores else cores
+        run_ref(UBF, index_dir, fq, fq + ".ub.sam", t)                    # (also warms the page cache for the timed stock run)
+        ub = sam_by_read(fq + ".ub.sam")
+        sec = run_ref(REF, index_dir, fq, fq + ".ref.sam", t) if os.path.exists(REF) else None
+        stock = sam_by_read(fq + ".ref.sam") if sec is not None else {}
+        out["parity_sample"] = {"reads": ns, "gpu_vs_ubpinned_differing_reads": n_differ({k: gpu.get(k) for k in ub}, ub),
+                                "stock_vs_ubpinned_differing_reads": sum(1 for k in ub if stock.get(k) != ub[k]) if stock else None,
+                                "mapped_reads": sum(1 for k in ub if ub[k][0].split(b"\t")[1] != b"4")}
+        if sec:
+            out["cpu_baseline"] = {"value": ns / sec, "unit": "reads/s", "cores": t, "kind": "reference", "seconds": sec,
+                                   "sample": "first %d reads of the batch, `classify -t %d`, the reference's own timer, one run after a warming run of the UB-pinned build" % (ns, t)}
+        for x in (fq, fq + ".ub.sam", fq + ".ref.sam"):
+            if os.path.exists(x):
+                os.remove(x)
+    ctx.close(); L.dsb_host_free(p)
+    return out
+
+
+def proxy_index(a, D, local):
+    """BASELINE configs[4] stands for a bacterial-scale index that is not in the mount: its proxy is a synthetic collection of
+    a.proxy_mbp million bases indexed here by this repo's builder (k = 17 / 18 filter tables, natural 64-bit rank counts from 4.3 G rows on)"""
+    d = os.path.join(ROOT, "data", "bench_proxy"); idxd = os.path.join(d, "index")
+    shutil.rmtree(d, ignore_errors=True); os.makedirs(d)
+    fa = os.path.join(d, "syn.fa")
+    t0 = time.perf_counter()
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "synth_ref.py"), fa, str(a.proxy_mbp), "13", "3", "60", "12"], check=True, stderr=subprocess.DEVNULL)
+    t_syn = time.perf_counter() - t0
+    st = D.build_index(fa, idxd, device=local)
+    os.remove(fa)
+    files = sum(os.path.getsize(os.path.join(idxd, f)) for f in os.listdir(idxd))
+    return idxd, {"seconds": st.total_s, "bases": st.n_bases, "sequences": st.n_refs, "kmers_31": st.n_kmer, "unitigs": st.n_unitig, "bwt_rows": st.n_rows,
+                  "index_files_bytes": files, "filter_table_bytes": os.path.getsize(os.path.join(idxd, "deSAMBA.exk0")), "reference_generation_s": t_syn}
+
+
 def strain_index(a, D, rank, local, barrier):
     """the viral-RefSeq-sized index of the headline: made by rank 0 with this repo's builder, opened by every rank"""
     d = os.path.join(ROOT, "data", "bench_strain"); idxd = os.path.join(d, "index"); info = None
@@ -438,6 +565,10 @@ def main():
     ap.add_argument("--no-short-reads", action="store_true", help="skip the 1 M x 150 bp measurement (BASELINE configs[2] shape)")
     ap.add_argument("--no-seed-hbm", action="store_true", help="skip the seed-lookup measurement on synthetic multi-GiB filter tables")
     ap.add_argument("--seed-hbm-mib", type=int, default=2048, help="size of each synthetic filter table (MiB, power of two 128 .. 16384)")
+    ap.add_argument("--no-proxy", action="store_true", help="skip the BASELINE configs[4] proxy (a >= 1-Gbp index built in the run, PacBio-mixed reads)")
+    ap.add_argument("--proxy-mbp", type=int, default=1000)
+    ap.add_argument("--proxy-reads", type=int, default=65536)
+    ap.add_argument("--proxy-parity", type=int, default=2048, help="reads of the proxy's parity sample against the reference's UB-pinned build")
     ap.add_argument("--slots", type=int, default=0, help="reads in flight per GPU (0 = library default)")
     a = ap.parse_args()
 
@@ -555,9 +686,34 @@ def main():
                 f.write(fq_text)
             out["cpu_baseline"], out["parity_sample"] = cpu_baseline(index_dir, sample, ns, ns * Lr, gpu_sam, a.t1_sample)
             os.remove(sample)
+            # the seed lookup's numerator the survey's way: the probes the REFERENCE's scan makes (oracle-counted on the first reads of
+            # the sample, scaled to the launch), beside the probes the kernel issued (device counters)
+            oc = oracle_probe_counts(index_dir, fq_text)
+            if oc:
+                rs = out["roofline_seed_lookup"]; bases_launch = float(R) * Lr
+                by = bases_launch * (1.0 + 64.0 * (oc["p0_per_base"] + oc["p1_per_base"]))
+                issued = (rs["algorithmic_bytes"] - bases_launch) / 64.0 / bases_launch
+                rs["oracle_numerator"] = dict(oc, algorithmic_bytes=by, achieved=by / (rs["ms"] / 1e3) / 1e9, frac=by / (rs["ms"] / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                              issued_probes_per_base=issued, issued_over_oracle=issued / max(oc["p0_per_base"] + oc["p1_per_base"], 1e-9),
+                                              what="L + 64 (P0 + P1) with P0, P1 counted by the CPU restatement of the reference's scan on the first %d reads of the sample" % oc["reads"])
             if e2e and out["cpu_baseline"]:
                 e2e["vs_cpu_baseline"] = e2e["reads_per_s"] / world / out["cpu_baseline"]["value"]
+    # ---- BASELINE configs[2]: 1 M synthetic 150 bp reads (1 % error) on the HEADLINE index, one resident batch
+    if rank == 0 and not a.no_short_reads:
+        out["config3_short_reads"] = resident_batch(D, L, idx, index_dir, local, 1 << 20, 150, 0.01, 4242, 0, gen_threads * world,
+                                                    "1048576 synthetic 150 bp reads, 1 % error, the headline index (%s), one batch resident in HBM" % ("viral-RefSeq-sized synthetic strain collection" if a.headline == "strain" else "demo"))
     m.close(); idx.close()
+    # ---- BASELINE configs[4] proxy: a >= 1-Gbp index built here, PacBio-mixed reads, one resident batch + a parity sample against the reference
+    if rank == 0 and not a.no_proxy:
+        pdir, pinfo = proxy_index(a, D, local)
+        pidx = D.Index(pdir)
+        c5 = resident_batch(D, L, pidx, pdir, local, a.proxy_reads, 12000, 0.13, 3, 1, gen_threads * world,
+                            "%d synthetic PacBio-mixed reads (log-normal lengths, mean 12 kbp, 13 %% error) on a %d-Mbp synthetic index built in this run (BASELINE configs[4] proxy), one batch resident in HBM" % (a.proxy_reads, a.proxy_mbp),
+                            parity_reads=a.proxy_parity)
+        c5["index_build"] = pinfo
+        out["config5_proxy"] = c5
+        pidx.close()
+        shutil.rmtree(os.path.join(ROOT, "data", "bench_proxy"), ignore_errors=True)
     barrier()                                   # every rank has given its device memory back: the CLI takes all GPUs
     if rank == 0 and not a.no_cli:
         n_cli = a.cli_reads * world
@@ -607,36 +763,18 @@ def main():
             seed_hbm = {"kernel": "k_seed_scan" if tm3.seed_scan else "k_seed_probe", "bound": "hbm", "tables": "2 x %d MiB synthetic, 20 %% of the bits set (k = 18)" % a.seed_hbm_mib,
                         "ms": ms, "algorithmic_bytes": by, "achieved": by / (ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / (ms / 1e3) / 1e9 / HBM_PEAK_GBS,
                         "probes_per_base": tm3.windows / max(tm3.bases, 1), "table1_probes_per_base": tm3.probes_t1 / max(tm3.bases, 1), "traffic": None}
-            try:
-                prof = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_seed_hbm.json")))
-                wl = prof.get("workload", {})
-                if wl.get("reads_per_gpu") == R and wl.get("read_len") == Lr and wl.get("library") == D.lib().dsb_version().decode() and wl.get("table_mib") == a.seed_hbm_mib:
-                    cn = prof["counters"][seed_hbm["kernel"]]
-                    seed_hbm["traffic"] = (cn["FETCH_SIZE"] + cn["WRITE_SIZE"]) * 1024.0
-            except Exception:
-                pass
+            seed_hbm["traffic"], seed_hbm["traffic_source"] = pmc_traffic("r04_pmc_seed_hbm.json", seed_hbm["kernel"], reads_per_gpu=R, read_len=Lr, table_mib=a.seed_hbm_mib)
             ctx3.close()
+            # the ceiling of the access pattern, measured in this run on this GPU: random 64-byte lines of a table as large as both filter tables
+            ceil = gather_ceiling(2 * a.seed_hbm_mib)
+            seed_hbm["gather_ceiling"] = {"GB/s": ceil, "what": "tools/gather_bench %d: one 4-byte word of a random 64-byte line per load, best of 4 / 8 / 16 loads in flight per lane" % (2 * a.seed_hbm_mib)}
+            seed_hbm["frac_of_ceiling"] = seed_hbm["achieved"] / ceil if ceil else None
             out["roofline_seed_lookup_hbm"] = seed_hbm
 
         # ---- BASELINE configs[2] shape: 1 M synthetic 150 bp reads (1 % error) on the demo index, one resident batch
         if not a.no_short_reads:
-            n2 = 1 << 20; L2 = 150
-            cap2 = n2 * (2 * L2 + 48) + (1 << 20)
-            p2 = L.dsb_host_alloc(cap2)
-            gen = Gen(demo_dir)
-            nb2, off2, ln2 = gen.fill(p2, cap2, n2, L2, 0.01, 4242, gen_threads * world)
-            gen.close()
-            ctx4 = D.Ctx(idxd, local, max_read_len=L2, max_batch_reads=n2)
-            ctx4.upload_text(p2, nb2, off2, ln2, n2)
-            ms = []; tm4 = None
-            for _ in range(4):
-                ctx4.run(); tm4 = ctx4.timing(); ms.append(tm4.total_ms)
-            ms = sorted(ms[1:])[1]
-            r4 = ctx4.fetch(strict=False)
-            out["config2_short_reads"] = {"workload": "1048576 synthetic 150 bp reads, 1 % error, demo index, one batch resident in HBM", "reads_per_s": n2 / (ms / 1e3), "gbp_per_s": n2 * L2 / (ms / 1e3) / 1e9, "ms": ms,
-                                          "kernel_ms": {"k_encode": tm4.encode_ms, "order": tm4.order_ms, "seed": tm4.seed_probe_ms, "k_classify": tm4.classify_ms, "tail": tm4.tail_ms},
-                                          "reads_mapped_frac": sum(1 for i in range(0, n2, 64) if r4.reads[i].n > 0) / (n2 / 64.0)}
-            ctx4.close(); L.dsb_host_free(p2)
+            out["config2_short_reads"] = resident_batch(D, L, idxd, demo_dir, local, 1 << 20, 150, 0.01, 4242, 0, gen_threads * world,
+                                                        "1048576 synthetic 150 bp reads, 1 % error, demo index, one batch resident in HBM")
         md.close(); idxd.close()
         if not a.no_cli:
             n_cli = max(R, min(a.demo_cli_reads, int(mem_limit() * 0.4 / rec_bytes)))

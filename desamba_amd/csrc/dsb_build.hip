@@ -139,6 +139,7 @@ extern "C" int dsb_index_build(const char *kmer_srt, const char *fasta, const ch
 	if (dsb_build_read_fasta(fasta, in)) return DSB_EIO;
 	if (kmer_srt && *kmer_srt && dsb_build_read_kmers(kmer_srt, in)) return DSB_EIO;
 	const double t_parse = wall() - t0;
+	if (const char *e = getenv("DSB_FORCE_EK_LEVEL")) in.force_ek_level = atoi(e);
 	HipBE be; be.n_cu = prop.multiProcessorCount;
 	const int rc = dsb_build_run(be, in, out);
 	if (be.failed) return DSB_ENODEV;

@@ -122,6 +122,7 @@ struct DsbBuildIn {
 	std::vector<uint8_t> code;            // text codes of all reference sequences, concatenated
 	std::vector<DsbBuildRef> refs;
 	std::vector<uint64_t> kmers;          // sorted unique 31-mers from a kmer.srt; empty = enumerate them from the text
+	int force_ek_level = -1;              // tests: filter tables of 2^(27 + level) bytes whatever the number of k-mers (DSB_FORCE_EK_LEVEL, read once by the caller)
 };
 
 struct DsbBuildOut {                      // the payload of every index file (write_idx, src/idx.c:1046-1101; write_bwt, src/bwt.c:203-258)
@@ -393,6 +394,7 @@ int dsb_build_run(B &be, const DsbBuildIn &in, DsbBuildOut &out)
 		static const int lens[8] = {16, 17, 17, 18, 18, 19, 19, 20};
 		int lv = 7;
 		for (int q = 0; q < 8; q++) if (n < (1ULL << (31 + q)) / 9) { lv = q; break; }
+		if (in.force_ek_level >= 0 && in.force_ek_level <= 7) lv = in.force_ek_level;      // (k = 17, 19, 20 on a small reference: tests/test_index_build.py)
 		ek_size = 1ULL << (27 + lv); ek_len = lens[lv]; ek_mask = (1ULL << (30 + lv)) - 1;
 	}
 	uint32_t *ek0 = be.template alloc<uint32_t>(ek_size / 4), *ek1 = be.template alloc<uint32_t>(ek_size / 4);

@@ -20,25 +20,10 @@
 #define DSB_NS dsb_g64
 #endif
 
-// DSB_HOST_EMU (tests/emu only): the same functions compiled for the host as a 1-lane group, so the
-// per-read logic can be run under gdb / sanitizers on a machine without a GPU.  Never part of the product.
-#undef DV
-#undef DN
-#undef DSB_WAVE
-#ifdef DSB_HOST_EMU
-#define DV static inline
-#define DN static
-#define DSB_WAVE 1
-#define __popcll __builtin_popcountll
-#else
-#define DV __device__ __forceinline__
-#ifdef DSB_INLINE_ALL
-#define DN __device__ __forceinline__
-#else
-#define DN __device__ __noinline__
-#endif
-#define DSB_WAVE DSB_GROUP
-#endif
+// Everything hardware-specific (cross-lane operations, LDS-typed pointers and atomics, typed global loads) is named in dsb_wave.h;
+// tests/emu compiles this same file for the host with tests/emu/dsb_emu_shim.h in its place (-DDSB_HOST_EMU: a 1-lane group, or
+// 64 lanes as cooperative fibers), so the per-read logic runs under gdb / sanitizers on a machine without a GPU.  No function
+// below knows which of the two it is compiled for; code that only makes sense on a full wavefront asks `DSB_WAVE == 64`.
 #ifndef DSB_DEV_COMMON
 #define DSB_DEV_COMMON
 #define MAXV(a,b) (((a) > (b))?(a):(b))
@@ -50,11 +35,6 @@
 #define D_U64MAX 0xffffffffffffffffULL
 #define SPENT(w) (++(w).steps > (w).step_limit)        /* group-uniform code only */
 #define LSPENT(l) (++(l).lsteps > (l).step_limit)      /* per-lane code (fast_island): l is an LCtx */
-#ifdef DSB_HOST_EMU
-#define DSB_CLOCK() 0ULL
-#else
-#define DSB_CLOCK() wall_clock64()
-#endif
 // stage timers (100 MHz ticks), accumulated per slot when DSB_DEBUG is set
 #define TICK(w, k) do { if ((w).dbg) { uint64_t _t = DSB_CLOCK(); (w).tacc[k] += _t - (w).tlast; (w).tlast = _t; } } while (0)
 // the fine timers sit inside the per-node loops of the extensions: compiled in only with -DDSB_TIMERS (DSB_HIPCC_FLAGS=-DDSB_TIMERS
@@ -73,7 +53,11 @@
 #define TXC(w, k) do { } while (0)
 #endif
 #define MARK(w, code) do { if ((w).dbg && DSB_LANE == 0) { (w).dbg[0] = (code); (w).dbg[1] = (w).steps; } } while (0)
+#ifdef DSB_LDS_DIET              /* experiment: 9.8 KB of LDS per wavefront = 16 wavefronts per CU (with -DDSB_WAVES_PER_EU=4) */
+#define DSB_WTAB_SLOTS 2176u
+#else
 #define DSB_WTAB_SLOTS 3072u     /* 12 KB of LDS: <= 2048 window positions, load factor <= 0.67 */
+#endif
 #define DSB_WTAB_MAXQ 2048u
 #define DSB_WTAB_EMPTY 0xffffffffu
 #endif
@@ -87,11 +71,7 @@
 #ifndef DSB_LANE_STEPS
 #define DSB_LANE_STEPS 256u        /* search steps a lane may spend on its read in fast_classify_lane */
 #endif
-#ifdef DSB_HOST_EMU
-#define DSB_BOOST_IF_HEAVY(w) do { } while (0)
-#else
-#define DSB_BOOST_IF_HEAVY(w) do { if (!(w).boosted && (w).dp_preds > DSB_BOOST_PREDS) { __builtin_amdgcn_s_setprio(3); (w).boosted = 1; } } while (0)
-#endif
+#define DSB_BOOST_IF_HEAVY(w) do { if (!(w).boosted && (w).dp_preds > DSB_BOOST_PREDS) { dsb_setprio3(); (w).boosted = 1; } } while (0)
 #endif
 // ... and beyond heavy_limit predecessors a single-wavefront launch gives the read up (DSB_ST_HEAVY): spending the loop budget
 // makes the extension loops stop at their next SPENT test, so the hand-over costs nothing per node
@@ -99,97 +79,23 @@
 
 namespace DSB_NS {
 
-// ---- group primitives: the threads working on one read (DSB_GROUP of them) ------------------------
-// wave_sync     make the group's earlier stores visible to all of its threads
-// grp_first     smallest thread index whose predicate is true (DSB_GROUP if none)
-// grp_max_i     maximum over the group
-// grp_excl_scan exclusive prefix sum over thread index, and the total
-// All are called by every thread of the group from group-uniform control flow.
+// ---- the wavefront primitives (see the contract at the top of dsb_wave.h) ---------------------------------------------------
 #ifdef DSB_HOST_EMU
-DV void wave_sync() {}
-DV int grp_first(uint32_t *, int, bool p) { return p ? 0 : DSB_WAVE; }
-DV int grp_max_i(uint32_t *, int, int v) { return v; }
-DV uint32_t grp_excl_scan_u(uint32_t *, int, uint32_t v, uint32_t *total) { *total = v; return 0; }
-template <class T> static inline T dsb_shfl(T v, int) { return v; }
-#define dsb_ballot64(p) ((p) ? 1ULL : 0ULL)
-#define DSB_RFL(v) (v)
-#define DSB_RFL64(v) (v)
-#elif DSB_GROUP == 64
-DV void wave_sync()
-{	// The 64 lanes of one wavefront exchange data through memory (LDS or global).  A wavefront's memory
-	// instructions issue in order through one L1, so a store by one lane is seen by a later load of another
-	// lane of the same wavefront without waiting for it to reach L2: wavefront-scope fences only stop the
-	// compiler from reordering.  (A workgroup-scope pair here costs an s_waitcnt vmcnt(0) per call.)
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-DV int grp_first(uint32_t *, int, bool p) { uint64_t m = __ballot(p); return m ? (int)__builtin_ctzll(m) : 64; }
-// Wave-wide max and exclusive prefix sum with DPP row operations (no LDS crossbar, no waits): within quads,
-// across the row of 16, then row_bcast:15 / row_bcast:31 carry row totals upwards; lane 63 holds the result.
-#define DSB_DPP(old, src, ctrl, rmask, bmask, bc) __builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, rmask, bmask, bc)
-DV int grp_max_i(uint32_t *, int, int v)
-{
-	int r = v, t;
-	t = DSB_DPP(r, r, 0xb1, 0xf, 0xf, false); r = t > r ? t : r;       // quad_perm:[1,0,3,2]
-	t = DSB_DPP(r, r, 0x4e, 0xf, 0xf, false); r = t > r ? t : r;       // quad_perm:[2,3,0,1]
-	t = DSB_DPP(r, r, 0x124, 0xf, 0xf, false); r = t > r ? t : r;      // row_ror:4
-	t = DSB_DPP(r, r, 0x128, 0xf, 0xf, false); r = t > r ? t : r;      // row_ror:8 -> every lane: max of its row
-	t = DSB_DPP(r, r, 0x142, 0xa, 0xf, false); r = t > r ? t : r;      // row_bcast:15 into rows 1, 3
-	t = DSB_DPP(r, r, 0x143, 0xc, 0xf, false); r = t > r ? t : r;      // row_bcast:31 into rows 2, 3
-	return __builtin_amdgcn_readlane(r, 63);
-}
-DV uint32_t grp_excl_scan_u(uint32_t *, int, uint32_t v, uint32_t *total)
-{
-	uint32_t s = v;
-	s += (uint32_t)DSB_DPP(0, v, 0x111, 0xf, 0xf, true);                 // row_shr:1
-	s += (uint32_t)DSB_DPP(0, v, 0x112, 0xf, 0xf, true);                 // row_shr:2
-	s += (uint32_t)DSB_DPP(0, v, 0x113, 0xf, 0xf, true);                 // row_shr:3 -> own + 3 lower neighbours of the row
-	s += (uint32_t)DSB_DPP(0, s, 0x114, 0xf, 0xe, true);                 // row_shr:4, banks 1..3
-	s += (uint32_t)DSB_DPP(0, s, 0x118, 0xf, 0xc, true);                 // row_shr:8, banks 2..3 -> inclusive scan of the row
-	s += (uint32_t)DSB_DPP(0, s, 0x142, 0xa, 0xf, true);                 // row_bcast:15 into rows 1, 3
-	s += (uint32_t)DSB_DPP(0, s, 0x143, 0xc, 0xf, true);                 // row_bcast:31 into rows 2, 3 -> inclusive scan of the wave
-	*total = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
-	return s - v;
-}
-// every use reads one lane, the same for the whole wave: v_readlane
-template <class T> DV T dsb_shfl(T v, int l) { static_assert(sizeof(T) == 4, "32-bit values only"); return (T)__builtin_amdgcn_readlane((int)v, l); }
-#define dsb_ballot64(p) __ballot(p)
-#define DSB_RFL(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
-#define DSB_RFL64(v) (((uint64_t)DSB_RFL((uint32_t)((uint64_t)(v) >> 32)) << 32) | (uint64_t)DSB_RFL((uint32_t)(v)))
+#include "dsb_emu_shim.h"
 #else
-#error "one wavefront per read: DSB_GROUP must be 64"
-#endif
-
-// words in LDS, addressed as LDS (ds_read / ds_cmpst / ds_add), not through generic pointers
-#ifdef DSB_HOST_EMU
-typedef uint32_t lds_u32; typedef uint64_t lds_u64;
-#else
-typedef __attribute__((address_space(3))) uint32_t lds_u32; typedef __attribute__((address_space(3))) uint64_t lds_u64;
+#include "dsb_wave.h"
 #endif
 
 // Work counters of a launch (the terms of the algorithmic bytes): [0] occ() evaluations, [1] MEM searches
 // (one hash_index pair each), [2] SA-sample + unitig + ref-pos lookups (get_uni), [3] reference bases fetched (get_ref).
 // Four words in LDS per wavefront, flushed to global memory when the wavefront leaves the kernel.  A function counts in a
 // register and adds once when it returns; `uni` marks code that all lanes run redundantly (lane 0 counts for them).
-#ifdef DSB_HOST_EMU
-struct Cnt { uint32_t *c; uint32_t uni; };
-DV void cnt_add(const Cnt &k, int which, uint32_t v) { if (k.c) k.c[which] += v; }
-#else
 struct Cnt { lds_u32 *c; uint32_t uni; };
 DV void cnt_add(const Cnt &k, int which, uint32_t v)
 {
-	if (k.uni && __lane_id() != 0) return;
-	__hip_atomic_fetch_add(k.c + which, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	if (k.uni && DSB_LANE != 0) return;
+	lds_add(k.c + which, v);
 }
-#endif
-
-// the index descriptor lives in LDS (k_classify copies its kernel argument there): typed so that x->field is a ds_read
-#ifdef DSB_HOST_EMU
-typedef const DsbDevIndex *DsbXP;
-#else
-typedef const __attribute__((address_space(3))) DsbDevIndex *DsbXP;
-#endif
 
 // Several wavefronts on one read (k_classify_heavy): wave 0 runs the read, the other waves of its workgroup sleep at a
 // barrier and are woken for the old-predecessor pass of the batched sparse DP (sdp_batch_old_mw), the one piece of a
@@ -211,11 +117,7 @@ struct DsbMw {
 struct DpBatch { uint32_t n0, K; int old_best[DSB_DPB]; uint32_t nd_t[DSB_DPB], nd_q[DSB_DPB], nd_l[DSB_DPB]; };
 // (one per wavefront, in LDS: it is read and written per node of the extension loops, and as a local of a function that hands
 // it to non-inlined callees it would live in scratch memory, a global-memory round trip per access)
-#ifdef DSB_HOST_EMU
-typedef DpBatch DpBatchL;
-#else
-typedef __attribute__((address_space(3))) DpBatch DpBatchL;
-#endif
+typedef DSB_LDS_AS DpBatch DpBatchL;
 
 struct SDir { DsbSeed *seed_v; uint32_t l_seed_v; uint8_t *bin_read; const uint64_t *bits; uint32_t direction, total_score; };
 // what one island walk needs of a strand (fast_island): by value, whether the strand record lies in LDS (the read of the
@@ -259,13 +161,6 @@ struct WCtx {
             // loop-iteration budget: every unbounded loop charges it and bails when exhausted
 	SDir sd[2];
 };
-#ifdef DSB_HOST_EMU
-#define DSB_LDS_AS
-#define DSB_LANE 0
-#else
-#define DSB_LDS_AS __attribute__((address_space(3)))
-#define DSB_LANE ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
-#endif
 typedef DSB_LDS_AS WCtx WCtxL;
 typedef DSB_LDS_AS SDir SDirL;
 DV void sdir_set(SDirL *d, DsbSeed *seed_v, uint32_t l_seed_v, uint8_t *bin_read, const uint64_t *bits, uint32_t direction, uint32_t total_score)
@@ -294,13 +189,8 @@ DV void lctx_done(WCtxL &w, const LCtx &l) { w.n_anc = l.n_anc; w.status = l.sta
 // Serial sections: stretches of the per-read logic with no lane-level parallelism run on lane 0 alone, so that
 // their loads and stores are one-address memory instructions instead of 64 copies of the same address going
 // through the CU's address pipeline; serial_end() broadcasts the scalars such a section may change.
-#ifdef DSB_HOST_EMU
-#define DSB_SERIAL(w) if (true)
-DV void serial_end(WCtxL &) {}
-#else
 #define DSB_SERIAL(w) if (DSB_LANE == 0)
 DV void serial_end(WCtxL &) { wave_sync(); }      // (the context is in LDS: what lane 0 wrote is what every lane reads)
-#endif
 
 // ---- hashes (src/lib/utils.c:1067-1091) ---------------------------------------------------
 DV uint64_t d_hash64_1(uint64_t key)
@@ -316,35 +206,12 @@ DV uint64_t d_hash64_2(uint64_t key)
 	return key;
 }
 
-// Index data lives in global memory: typed loads (global_load instead of FLAT, which also occupies the LDS queue).
-#ifdef DSB_HOST_EMU
-#define DSB_G64(p, i) (((const uint64_t *)(p))[i])
-#define DSB_G32(p, i) (((const uint32_t *)(p))[i])
-static inline uint64_t dsb_g64u(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
-static inline uint32_t dsb_g32u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
-#else
-#define DSB_G64(p, i) (((const __attribute__((address_space(1))) uint64_t *)(p))[i])
-#define DSB_G32(p, i) (((const __attribute__((address_space(1))) uint32_t *)(p))[i])
-typedef uint64_t dsb_u64u __attribute__((aligned(1)));
-typedef uint32_t dsb_u32u __attribute__((aligned(1)));
-DV uint64_t dsb_g64u(const uint8_t *p) { return *(const __attribute__((address_space(1))) dsb_u64u *)p; }      // unaligned
-DV uint32_t dsb_g32u(const uint8_t *p) { return *(const __attribute__((address_space(1))) dsb_u32u *)p; }
-#endif
-
 // ---- rank query, one 64-B line (reference: occ, src/bwt.c:43-65) ---------------------------
 DV uint64_t fm_occ(DsbXP x, uint64_t r, uint32_t &c)
 {
-	// the index lives in global memory: say so (a generic pointer makes these FLAT loads, which also occupy the LDS queue)
-#ifdef DSB_HOST_EMU
-	const uint4 *bp = reinterpret_cast<const uint4 *>(x->fm + (r >> 7));
-#else
-	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-	const __attribute__((address_space(1))) u32x4 *bp = (const __attribute__((address_space(1))) u32x4 *)(x->fm + (r >> 7));
-#endif
-	const auto b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
-	uint4 a0, a1, a2, a3;
-	a0.x = b0.x; a0.y = b0.y; a0.z = b0.z; a0.w = b0.w; a1.x = b1.x; a1.y = b1.y; a1.z = b1.z; a1.w = b1.w;
-	a2.x = b2.x; a2.y = b2.y; a2.z = b2.z; a2.w = b2.w; a3.x = b3.x; a3.y = b3.y; a3.z = b3.z; a3.w = b3.w;
+	// (the index lives in global memory: dsb_ld_line says so -- a generic pointer would make these FLAT loads, which also occupy the LDS queue)
+	uint4 a[4]; dsb_ld_line(x->fm + (r >> 7), a);
+	const uint4 a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
 	uint32_t off = (uint32_t)r & 127u;
 	uint64_t p0[2] = {((uint64_t)a1.y << 32) | a1.x, ((uint64_t)a1.w << 32) | a1.z};
 	uint64_t p1[2] = {((uint64_t)a2.y << 32) | a2.x, ((uint64_t)a2.w << 32) | a2.z};
@@ -823,11 +690,6 @@ template <class BP> DV uint32_t run_ones_down(BP bits, int start, uint32_t maxc)
 
 // BP: where the hit-bit words are read from -- a generic pointer (global memory), or LDS (the usual case: staged by
 // seed_vector; ds_read instead of FLAT loads on the scan's critical path)
-#ifdef DSB_HOST_EMU
-typedef const uint64_t *lds_bits_p;
-#else
-typedef const __attribute__((address_space(3))) uint64_t *lds_bits_p;
-#endif
 template <class BP>
 DN void seed_vector_scan(BP bits_, uint32_t n_, DsbSeed *sv_, uint32_t direction_, uint32_t *ns_out, uint32_t *total_out)
 {
@@ -987,22 +849,14 @@ DN void fast_classify(WCtxL &w, SDirL *s_d_, uint32_t read_len)
 		wave_sync();
 		for (uint32_t t = (uint32_t)lane; t < n_top; t += DSB_WAVE) {
 			const uint32_t b = MINV((uint32_t)sv_b[top_idx[t]].len, 63u);
-#ifdef DSB_HOST_EMU
-			hist[b]++;
-#else
-			__hip_atomic_fetch_add(hist + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
+			lds_add(hist + b, 1u);
 		}
 		wave_sync();
 		if (lane == 0) { uint32_t acc = 0; for (int b = 63; b >= 0; b--) { hist[64 + b] = acc; acc += hist[b]; } }
 		wave_sync();
 		for (uint32_t t = (uint32_t)lane; t < n_top; t += DSB_WAVE) {
 			const uint32_t b = MINV((uint32_t)sv_b[top_idx[t]].len, 63u);
-#ifdef DSB_HOST_EMU
-			const uint32_t pos = hist[64 + b]++;
-#else
-			const uint32_t pos = __hip_atomic_fetch_add(hist + 64 + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
+			const uint32_t pos = lds_add(hist + 64 + b, 1u);
 			ord[pos] = t;
 		}
 		wave_sync();
@@ -1018,11 +872,7 @@ DN void fast_classify(WCtxL &w, SDirL *s_d_, uint32_t read_len)
 		l.spset = w.lane_spset + (size_t)lane * DSB_SPHASH;
 		const int st0 = l.status;
 		for (;;) {
-#ifdef DSB_HOST_EMU
-			const uint32_t t = red[0]++;
-#else
-			const uint32_t t = __hip_atomic_fetch_add((lds_u32 *)red, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
+			const uint32_t t = lds_add((lds_u32 *)red, 1u);
 			if (t >= n_top) break;
 			const uint32_t start = l.n_anc; const int st_before = l.status;
 			const uint32_t ti = lpt ? ord[t] : t;                              // the island this lane walks now
@@ -1035,7 +885,7 @@ DN void fast_classify(WCtxL &w, SDirL *s_d_, uint32_t read_len)
 		}
 		// each lane bumped its own copy of the set generation: continue from the largest so that no lane's stale
 		// entries can look current; a lane that ran out of its loop budget marks the read (the reference has no budget)
-		const uint32_t gen = (uint32_t)grp_max_i(red, lane, (int)l.sp_gen), ls = (uint32_t)grp_max_i(red, lane, (int)(l.lsteps >> 1));
+		const uint32_t gen = (uint32_t)grp_max_i((int)l.sp_gen), ls = (uint32_t)grp_max_i((int)(l.lsteps >> 1));
 		const bool spent = dsb_ballot64((l.status & DSB_ST_TIMEOUT) != 0) != 0;
 		w.sp_gen = gen; w.lsteps = ls << 1; w.status = st0 | (spent ? DSB_ST_TIMEOUT : 0);
 	}
@@ -1052,29 +902,27 @@ DN void fast_classify(WCtxL &w, SDirL *s_d_, uint32_t read_len)
 		const uint32_t main_n = w.n_anc;
 		const uint32_t n_round = MINV((uint32_t)DSB_WAVE, n_top - base);
 		bool committed = false;
-#if !defined(DSB_HOST_EMU) && DSB_GROUP == 64
-		{
-			const uint64_t V = __ballot(valid), F = __ballot(valid && flag), O = __ballot(valid && ovf);
-			uint32_t prev = __shfl_up(my_sidx, 1);
+		if (DSB_WAVE == 64) {
+			const uint64_t V = dsb_ballot64(valid), F = dsb_ballot64(valid && flag), O = dsb_ballot64(valid && ovf);
+			uint32_t prev = dsb_shfl_up1(my_sidx);
 			bool adj = lane == 0 ? (my_sidx == skip_seed) : (my_sidx == prev + 1);
-			const uint64_t ADJ = __ballot(valid && adj);
+			const uint64_t ADJ = dsb_ballot64(valid && adj);
 			if (O == 0) {
 				uint64_t S = ADJ & 1ULL;                                    // lane 0: skipped by the previous chunk's carry
 				const uint64_t C = ADJ & (F << 1) & ~1ULL;
 				for (int l = 1; l < 64; l++) if (((C >> l) & 1ULL) && !((S >> (l - 1)) & 1ULL)) S |= 1ULL << l;
 				const bool keep = valid && !((S >> lane) & 1ULL);
-				uint32_t total, off = grp_excl_scan_u(red, lane, keep ? my_n : 0u, &total);
+				uint32_t total, off = grp_excl_scan_u(keep ? my_n : 0u, &total);
 				if (main_n + total <= w.anc_cap_main) {
 					const DsbAnchor *src = lane_anc + (size_t)(ri & 0x3fu) * DSB_LANE_ANC_CAP + ((ri >> 6) & 0x3ffu);
 					if (keep) for (uint32_t k = 0; k < my_n; k++) main_anc[main_n + off + k] = src[k];
 					w.n_anc = main_n + total;
 					const uint64_t KF = F & V & ~S;                             // committed seeds that raise the skip flag
-					if (KF) { int last = 63 - (int)__builtin_clzll(KF); skip_seed = __shfl(my_sidx, last) + 1; }
+					if (KF) { int last = 63 - (int)__builtin_clzll(KF); skip_seed = dsb_shfl(my_sidx, last) + 1; }
 					committed = true;
 				}
 			}
 		}
-#endif
 		if (!committed) {
 			for (uint32_t l = 0; l < n_round; l++) {
 				const uint32_t sidx = top_idx[base + l], ri_l = info[base + l];
@@ -1221,11 +1069,7 @@ DN void chain_sort_M3(WCtxL &w)
 	if (n <= DSB_RANKSORT_MAX && w.wtab) {
 		// the usual size: keys in LDS (the window table is idle), every lane ranks its own anchors against all keys
 		// (stable: ties by index) and moves them straight to their sorted place; the two anchor arrays swap roles
-#ifdef DSB_HOST_EMU
-		uint64_t *keys = reinterpret_cast<uint64_t *>(w.wtab);
-#else
-		__attribute__((address_space(3))) uint64_t *keys = (__attribute__((address_space(3))) uint64_t *)w.wtab;
-#endif
+		lds_u64 *keys = (lds_u64 *)w.wtab;
 		for (int32_t i = lane; i < n; i += DSB_WAVE) keys[i] = ((uint64_t)A[i].ref_ID << 33) | ((uint64_t)A[i].direction << 32) | A[i].ref_offset;
 		wave_sync();
 		for (int32_t i = lane; i < n; i += DSB_WAVE) {
@@ -1258,11 +1102,6 @@ DN void chain_sort_M3(WCtxL &w)
 // duplicate), then the DP's score and predecessor -- with the lanes over the predecessors of one anchor at a time
 // (chain_dp_M3_wave); larger sets take the serial form on lane 0 from global memory (chain_dp_M3<false>).
 #define DSB_CHAINDP_LDS (DSB_WTAB_SLOTS / 6)              /* 512 */
-#ifdef DSB_HOST_EMU
-typedef uint32_t lds_w32;
-#else
-typedef __attribute__((address_space(3))) uint32_t lds_w32;
-#endif
 // (P32: lds_w32 * for the arrays in LDS, uint32_t * for larger anchor sets whose arrays lie in the idle half of the
 // anchor arena -- global memory, same code, the loads of a chunk of predecessors are coalesced; C = array stride)
 template <class P32>
@@ -1309,12 +1148,12 @@ DN void chain_dp_M3_wave(WCtxL &w, P32 LQ, const uint32_t C)
 				if (valid) { p_q = LQ[p]; p_t = LT[p]; p_ml = (uint32_t)LMS[p] & 0xffffu; p_s = (int)LS[p]; }
 				const bool skip = (p_q + p_ml > max_q) || (p_t + p_ml > max_t);
 				const bool brk = valid && !skip && ((p_q + 1000 < max_q) || (p_t + 1000 < max_t));
-				const int first_brk = grp_first(w.red, lane, brk);
+				const int first_brk = grp_first(brk);
 				const int indel = (int)(p_q - p_t - (max_q - max_t)); const int ai = ABSV(indel);
 				const bool ok = valid && !skip && !brk && ai <= 200 && lane < first_brk;
 				const int ns = ok ? (int)(p_s + (int)ca_ml - (ai >> 4) - (int)((max_q - p_q) >> 8)) : (-2147483647 - 1);
-				const int m = grp_max_i(w.red, lane, ns);
-				if (m > ams) { ams = m; best_pre = hi - grp_first(w.red, lane, ok && ns == m); }
+				const int m = grp_max_i(ns);
+				if (m > ams) { ams = m; best_pre = hi - grp_first(ok && ns == m); }
 				if (first_brk < DSB_WAVE) break;
 			}
 			if (lane == 0) { LP[ca] = (uint32_t)best_pre; LS[ca] = (uint32_t)ams; }
@@ -1490,7 +1329,7 @@ DN void chain_top_select(WCtxL &w)
 		K[i] = ((uint64_t)(c->with_top_anchor ? 0u : 1u) << 32) | (uint64_t)(uint32_t)(0x7fffffffLL - (long long)sa);
 		tops += c->with_top_anchor ? 1u : 0u;
 	}
-	uint32_t n_tops; grp_excl_scan_u(w.red, lane, tops, &n_tops);
+	uint32_t n_tops; grp_excl_scan_u(tops, &n_tops);
 	wave_sync();
 	const uint32_t keep = n_tops >= 5u ? n_tops : MINV(5u, n);
 	for (uint32_t i = (uint32_t)lane; i < n; i += DSB_WAVE) {
@@ -1539,26 +1378,6 @@ DV void sc_hash_idx(DsbScHash *sc, DsbChain *hit, uint32_t n_hit)
 			sc[con++].next = 0;
 		}
 }
-// which of the 256 buckets hold anything (bit key of m[key >> 6]): the extensions ask once per match node, and a read has a
-// handful of chains -- nine buckets in ten are empty, which a register tells without the round trip to the table
-struct ScMask { uint64_t m[4]; };
-DV ScMask sc_mask(const DsbScHash *sc)
-{
-	ScMask r;
-#ifdef DSB_HOST_EMU
-	for (int g = 0; g < 4; g++) { r.m[g] = 0; for (int i = 0; i < 64; i++) if (sc[64 * g + i].next != 0) r.m[g] |= 1ULL << i; }
-#else
-#pragma unroll
-	for (int g = 0; g < 4; g++) r.m[g] = dsb_ballot64(sc[64 * g + DSB_LANE].next != 0);
-#endif
-	return r;
-}
-DV bool sc_mask_has(const ScMask &k, int dis)
-{
-	const uint32_t key = (uint32_t)dis & 0xffu;
-	const uint64_t m = key < 128 ? (key < 64 ? k.m[0] : k.m[1]) : (key < 192 ? k.m[2] : k.m[3]);
-	return ((m >> (key & 63u)) & 1ULL) != 0;
-}
 DV bool combine_chain(DsbChain *c_st, int chain_ID, DsbScHash *sc, int dis, bool isleft, int c_q_pos, DsbChain **combined)
 {
 	uint16_t key = (dis) & 0xff;
@@ -1582,6 +1401,25 @@ DV bool combine_chain(DsbChain *c_st, int chain_ID, DsbScHash *sc, int dis, bool
 	return false;
 }
 
+// combine_chain's test alone (nothing is changed): would the node at diagonal `dis` absorb a later chain?  The block-wise
+// extensions ask it for all nodes of a block at once (one lane each: the bucket loads of 64 nodes are one round trip, and nine
+// buckets in ten are empty) and call combine_chain itself only for the first node, in order, that says yes.
+DV bool combine_test(const DsbChain *c_st, int chain_ID, const DsbScHash *sc, int dis, bool isleft, int c_q_pos)
+{
+	uint16_t key = (dis) & 0xff;
+	const DsbChain *c_h = c_st + chain_ID;
+	while (sc[key].next != 0) {
+		const uint16_t seed_ID = sc[key].seed_ID & 0x7fff; const int s_or_e = sc[key].seed_ID >> 15;
+		const DsbChain *c = c_st + seed_ID - 1;
+		const int dis_con = (isleft) ? (c->t_ed - c->q_ed) : (c->t_st - c->q_st);
+		const int q_pos_con = (!isleft) ? (c->q_st) : (c->q_ed - 9);
+		if (dis == dis_con && c_h != c && (int)isleft != s_or_e && ABS_U(c_q_pos, q_pos_con) < 8 &&
+		    c_h->ref_ID == c->ref_ID && c_h->direction == c->direction && c->sum_score != 0 && seed_ID - 1 > chain_ID) return true;
+		key = sc[key].next;
+	}
+	return false;
+}
+
 // ---- 9-mer lookup (build_hash_table_M2 + the chain walks of sdp_match, src/cly.c:2173-2224,2354-2388).
 // The reference hashes every 9-mer of the read once and filters each lookup by the query window
 // [q_bg, q_ed].  Every window is at most 2001 positions wide (600-bp extension steps look 2000 bases around
@@ -1598,13 +1436,7 @@ DV uint64_t ld_u64(const uint8_t *p)
 // the byte windows of the sparse matching are either in global memory (generic pointers) or staged in LDS; the code
 // below is instantiated for both so that the staged case compiles to ds_read
 typedef const uint8_t *gp8;
-#ifdef DSB_HOST_EMU
-typedef const uint8_t *lp8;
-#else
-typedef const __attribute__((address_space(3))) uint8_t *lp8;
-typedef uint64_t dsb_lds_u64u __attribute__((aligned(1)));
-DV uint64_t ld_u64(lp8 p) { return *(const __attribute__((address_space(3))) dsb_lds_u64u *)p; }
-#endif
+// (lp8: the same bytes in LDS, typed -- dsb_wave.h has its ld_u64)
 DV uint32_t wtab_slot(uint32_t kmer, uint32_t slots) { return (uint32_t)(((uint64_t)(kmer * 2654435761u) * slots) >> 32); }
 // slots used for a window of n_q positions: load factor <= 0.5 for small windows, the whole table for big ones
 DV uint32_t wtab_size(uint32_t n_q) { uint32_t s = 2 * n_q; return s < 64u ? 64u : (s > DSB_WTAB_SLOTS ? DSB_WTAB_SLOTS : s); }
@@ -1635,13 +1467,7 @@ DN void wtab_build(lds_u32 *tab, int lane, P8 q_str, uint32_t q_bg, uint32_t n_q
 			k = (k << 2) | t8[u];
 			uint32_t e = (k << 12) | r, sl = wtab_slot(k, slots);
 			for (;;) {
-#ifdef DSB_HOST_EMU
-				uint32_t old = tab[sl]; if (old == DSB_WTAB_EMPTY) tab[sl] = e;
-#else
-				uint32_t old = DSB_WTAB_EMPTY;
-				__hip_atomic_compare_exchange_strong(tab + sl, &old, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-				if (old == DSB_WTAB_EMPTY) break;
+				if (lds_cas(tab + sl, DSB_WTAB_EMPTY, e) == DSB_WTAB_EMPTY) break;
 				sl = sl + 1 == slots ? 0 : sl + 1;
 			}
 		}
@@ -1658,17 +1484,11 @@ DN void wtab_build(lds_u32 *tab, int lane, P8 q_str, uint32_t q_bg, uint32_t n_q
 DN void wtab_build_pk(lds_u32 *tab, int lane, const uint64_t *P, uint32_t n_words, uint32_t q_bg, uint32_t n_q)
 {
 	const uint32_t slots = wtab_size(n_q);
-#ifdef DSB_HOST_EMU
-	for (uint32_t i = lane; i < slots; i += DSB_WAVE) tab[i] = DSB_WTAB_EMPTY;
-#else
-	{	// (the table is 16-byte aligned and its size a multiple of four words)
-		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-		const u32x4 e4 = {DSB_WTAB_EMPTY, DSB_WTAB_EMPTY, DSB_WTAB_EMPTY, DSB_WTAB_EMPTY};
+	{	// (the table is 16-byte aligned)
 		const uint32_t s4 = slots & ~3u;
-		for (uint32_t i = 4 * lane; i < s4; i += 4 * DSB_WAVE) *(__attribute__((address_space(3))) u32x4 *)(tab + i) = e4;
-		if ((uint32_t)lane < slots - s4) tab[s4 + lane] = DSB_WTAB_EMPTY;
+		for (uint32_t i = 4 * lane; i < s4; i += 4 * DSB_WAVE) lds_fill4(tab + i, DSB_WTAB_EMPTY);
+		for (uint32_t i = s4 + (uint32_t)lane; i < slots; i += DSB_WAVE) tab[i] = DSB_WTAB_EMPTY;
 	}
-#endif
 	const uint32_t C = (n_q + DSB_WAVE - 1) / DSB_WAVE;                 // <= 32 positions per lane (n_q <= DSB_WTAB_MAXQ)
 	const uint32_t r0 = (uint32_t)lane * C, r1 = MINV(n_q, r0 + C);
 	uint64_t W0 = 0, W1 = 0, W2 = 0; uint32_t wi = 0;
@@ -1688,13 +1508,7 @@ DN void wtab_build_pk(lds_u32 *tab, int lane, const uint64_t *P, uint32_t n_word
 		const uint32_t k = (uint32_t)(hi >> 46);
 		uint32_t e = (k << 12) | r, sl = wtab_slot(k, slots);
 		for (;;) {
-#ifdef DSB_HOST_EMU
-			uint32_t old = tab[sl]; if (old == DSB_WTAB_EMPTY) tab[sl] = e;
-#else
-			uint32_t old = DSB_WTAB_EMPTY;
-			__hip_atomic_compare_exchange_strong(tab + sl, &old, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-			if (old == DSB_WTAB_EMPTY) break;
+			if (lds_cas(tab + sl, DSB_WTAB_EMPTY, e) == DSB_WTAB_EMPTY) break;
 			sl = sl + 1 == slots ? 0 : sl + 1;
 		}
 	}
@@ -1899,7 +1713,7 @@ DV void sdp_match_groups(const SdpArgsT<P8> &a, uint32_t g_lo, uint32_t g_hi, ui
 		if (valid) cur = sdp_ref_load<FWD, P8>(a, i);
 		DsbSms keep[DSB_SDP_KEEP];
 		uint32_t cnt = valid ? sdp_visit<FWD, true, P8>(lsteps, step_limit, st, a, i, cur, keep, DSB_SDP_KEEP) : 0;
-		uint32_t total, off = grp_excl_scan_u(red, lane, cnt, &total);
+		uint32_t total, off = grp_excl_scan_u(cnt, &total);
 		if (total == 0) continue;
 		if (n_sms + total > sms_cap) { st |= DSB_ST_SMS_OVF; break; }
 		DsbSms *dst = sms + n_sms + off;
@@ -1926,7 +1740,7 @@ DN uint32_t sdp_match_t(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms)
 	uint32_t lsteps = w.lsteps, mirror_bad = 0; int st = 0; const uint32_t step_limit = w.step_limit;
 	sdp_match_groups<FWD, P8>(a, 0, n_pos, n_pos, lane, red, sms, sms_cap, lsteps, step_limit, st, n_sms, mirror_bad);
 	// (the budget and the status bits of the lanes become the wavefront's: the largest count, the union of the bits)
-	const uint32_t ls = (uint32_t)grp_max_i(red, lane, (int)(lsteps >> 1));
+	const uint32_t ls = (uint32_t)grp_max_i((int)(lsteps >> 1));
 	const bool any_to = dsb_ballot64((st & DSB_ST_TIMEOUT) != 0) != 0, any_ovf = dsb_ballot64((st & DSB_ST_SMS_OVF) != 0) != 0;
 	w.lsteps = ls << 1;
 	if (any_to | any_ovf) w.status |= (any_to ? DSB_ST_TIMEOUT : 0) | (any_ovf ? DSB_ST_SMS_OVF : 0);
@@ -1977,17 +1791,8 @@ DN uint32_t sdp_match_inv(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms, const 
 	const uint32_t n_pos = (a.t_len - 9 + 1 - 4 + 3) / 4;             // i = 4, 8, ... < t_len - 9 + 1; <= DSB_INV_MAXPOS (caller)
 	TX0(w, t_b);
 	// (A) empty table and filter
-#ifdef DSB_HOST_EMU
-	for (uint32_t i = lane; i < DSB_INV_SLOTS; i += DSB_WAVE) rt[i] = DSB_INV_NONE;
-	for (uint32_t i = lane; i < DSB_INV_FWORDS; i += DSB_WAVE) flt[i] = 0;
-#else
-	{
-		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-		const u32x4 e4 = {DSB_INV_NONE, DSB_INV_NONE, DSB_INV_NONE, DSB_INV_NONE}, z4 = {0u, 0u, 0u, 0u};
-		for (uint32_t i = 4 * lane; i < DSB_INV_SLOTS; i += 4 * DSB_WAVE) *(__attribute__((address_space(3))) u32x4 *)(rt + i) = e4;
-		for (uint32_t i = 4 * lane; i < DSB_INV_FWORDS; i += 4 * DSB_WAVE) *(__attribute__((address_space(3))) u32x4 *)(flt + i) = z4;
-	}
-#endif
+	for (uint32_t i = 4 * lane; i < DSB_INV_SLOTS; i += 4 * DSB_WAVE) lds_fill4(rt + i, DSB_INV_NONE);
+	for (uint32_t i = 4 * lane; i < DSB_INV_FWORDS; i += 4 * DSB_WAVE) lds_fill4(flt + i, 0u);
 	if (lane == 0) cntp[0] = 0;
 	wave_sync();
 	// (B) the reference 9-mers
@@ -1997,19 +1802,8 @@ DN uint32_t sdp_match_inv(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms, const 
 		if (kmer >= (1ULL << 18)) continue;                             // pad bits: matches nothing
 		const uint32_t k = (uint32_t)kmer, prod = k * 2654435761u, h = prod >> 18, e = (k << 9) | pI;
 		uint32_t sl = prod >> 23;
-#ifdef DSB_HOST_EMU
-		flt[h >> 5] |= 1u << (h & 31);
-		while (rt[sl] != DSB_INV_NONE) sl = (sl + 1) & (DSB_INV_SLOTS - 1);
-		rt[sl] = e;
-#else
-		__hip_atomic_fetch_or(flt + (h >> 5), 1u << (h & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		for (;;) {
-			uint32_t old = DSB_INV_NONE;
-			__hip_atomic_compare_exchange_strong(rt + sl, &old, e, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			if (old == DSB_INV_NONE) break;
-			sl = (sl + 1) & (DSB_INV_SLOTS - 1);
-		}
-#endif
+		lds_or(flt + (h >> 5), 1u << (h & 31));
+		while (lds_cas(rt + sl, DSB_INV_NONE, e) != DSB_INV_NONE) sl = (sl + 1) & (DSB_INV_SLOTS - 1);
 	}
 	wave_sync();
 	// (C) the read positions: a run of consecutive ones per lane, 32 at a time out of three packed words
@@ -2035,11 +1829,7 @@ DN uint32_t sdp_match_inv(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms, const 
 					const uint32_t e = rt[sl];
 					if (e == DSB_INV_NONE) break;
 					if ((e >> 9) != k) continue;
-#ifdef DSB_HOST_EMU
-					const uint32_t idx = cntp[0]++;
-#else
-					const uint32_t idx = __hip_atomic_fetch_add(cntp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
+					const uint32_t idx = lds_add(cntp, 1u);
 					if (idx < DSB_INV_PAIRS) pairs[idx] = ((e & 0x1ffu) << 12) | (rb + j);
 				}
 			}
@@ -2071,7 +1861,7 @@ DN uint32_t sdp_match_inv(WCtxL &w, const SdpArgsT<P8> a, uint32_t n_sms, const 
 			const uint64_t xb = ld_u64(AQ(a, q_pos - 1) - 7) ^ ld_u64(c_t - 1 - 7), xf = ld_u64(AQ(a, q_pos + 9)) ^ ld_u64(c_t + 9);
 			ok = sdp_emit1<FWD, P8>(a, i, c_t, q_pos, xb, xf, o);
 		}
-		uint32_t total, off = grp_excl_scan_u(red, lane, ok ? 1u : 0u, &total);
+		uint32_t total, off = grp_excl_scan_u(ok ? 1u : 0u, &total);
 		if (total == 0) continue;
 		if (n_sms + total > sms_cap) { ovf = true; break; }
 		if (ok) {
@@ -2139,15 +1929,7 @@ DV void sdp_match(WCtxL &w, uint32_t q_bg, uint32_t q_ed, const uint8_t *q_str, 
 	w.n_sms = sdp_match_n(w, w.n_sms, q_bg, q_ed, q_str, t_str, t_len, t_st, isForward, nullptr, w.pk[tbl]) & 0x7fffffffu;
 }
 
-// the ring lives in LDS: typed accesses (ds_read_b128 / ds_write_b128)
-#ifdef DSB_HOST_EMU
-DV uint4 ring_ld(const uint4 *ring, uint32_t i) { return ring[i]; }
-DV void ring_st(uint4 *ring, uint32_t i, uint4 v) { ring[i] = v; }
-#else
-typedef uint32_t dsb_u32x4 __attribute__((ext_vector_type(4)));
-DV uint4 ring_ld(const uint4 *ring, uint32_t i) { dsb_u32x4 v = ((const __attribute__((address_space(3))) dsb_u32x4 *)ring)[i]; uint4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
-DV void ring_st(uint4 *ring, uint32_t i, uint4 r) { dsb_u32x4 v; v.x = r.x; v.y = r.y; v.z = r.z; v.w = r.w; ((__attribute__((address_space(3))) dsb_u32x4 *)ring)[i] = v; }
-#endif
+// (the ring lives in LDS: ring_ld / ring_st are typed accesses, ds_read_b128 / ds_write_b128)
 DV void ring_put(WCtxL &w, uint32_t idx, uint32_t t_pos, uint32_t q_pos, uint32_t len, uint32_t score)
 {
 	uint4 r; r.x = t_pos; r.y = q_pos; r.z = len; r.w = score;
@@ -2158,18 +1940,17 @@ DV void ring_put(WCtxL &w, uint32_t idx, uint32_t t_pos, uint32_t q_pos, uint32_
 struct NodeBlock { uint32_t base, valid; DsbSms mine; };
 DV DsbSms node_get(WCtxL &w, NodeBlock &b, uint32_t idx)
 {
-#if DSB_GROUP == 64 && !defined(DSB_HOST_EMU)
-	if (idx < b.base || idx >= b.base + b.valid) {
-		b.base = idx; b.valid = MINV((uint32_t)64, w.n_sms - idx);
-		if ((uint32_t)DSB_LANE < b.valid) b.mine = w.sms[idx + DSB_LANE];
+	if (DSB_WAVE == 64) {
+		if (idx < b.base || idx >= b.base + b.valid) {
+			b.base = idx; b.valid = MINV((uint32_t)64, w.n_sms - idx);
+			if ((uint32_t)DSB_LANE < b.valid) b.mine = w.sms[idx + DSB_LANE];
+		}
+		DsbSms r; int src = (int)(idx - b.base);
+		r.t_pos = dsb_shfl(b.mine.t_pos, src); r.q_pos = dsb_shfl(b.mine.q_pos, src); r.len = dsb_shfl(b.mine.len, src); r.score = 0;
+		return r;
 	}
-	DsbSms r; int src = (int)(idx - b.base);
-	r.t_pos = dsb_shfl(b.mine.t_pos, src); r.q_pos = dsb_shfl(b.mine.q_pos, src); r.len = dsb_shfl(b.mine.len, src); r.score = 0;
-	return r;
-#else
 	DsbSms r = w.sms[idx]; r.score = 0;
 	return r;
-#endif
 }
 
 // best predecessor score of a new node among nodes [0, cur): the sparse-DP inner loops of
@@ -2226,13 +2007,13 @@ DV int sdp_best_pred(WCtxL &w, const DsbSms &cs, int32_t cur)
 				}
 			}
 			// the reference stops at the first predecessor (newest first) that meets the distance cut
-			int first_brk = (MODE == 0) ? DSB_WAVE : grp_first(w.red, DSB_LANE, valid && brk);
+			int first_brk = (MODE == 0) ? DSB_WAVE : grp_first(valid && brk);
 			if (valid && !skip && !brk && DSB_LANE < first_brk) best = MAXV(best, ns);
 			if (first_brk < DSB_WAVE) stop = true;
 		}
 		if (stop) break;
 	}
-	return grp_max_i(w.red, DSB_LANE, best);
+	return grp_max_i(best);
 }
 
 
@@ -2282,7 +2063,8 @@ DV void sdp_judge(const DsbSms &cs, const DsbSms &ps, uint32_t lim_q, uint32_t l
 	}
 }
 
-template <int MODE>
+// RING: the newest DSB_RING nodes in front of the batch are in the LDS ring (the node-by-node extensions keep it; the block-wise ones do not)
+template <int MODE, bool RING>
 DN void sdp_batch_old(WCtxL &w, DpBatchL &b)
 {
 	// per node of the batch (group-uniform, kept in scalar registers): limits and the terms of sdp_judge that do
@@ -2309,7 +2091,7 @@ DN void sdp_batch_old(WCtxL &w, DpBatchL &b)
 		if (u >= (ng_)) break;                                                                                   \
 		int32_t pi = (hi_) - u * DSB_WAVE - DSB_LANE;                                                              \
 		if (pi < 0) { dst[u].t_pos = 0; dst[u].q_pos = (MODE == 2) ? 0u : 0xfffffff0u; dst[u].len = 0; dst[u].score = 0; } \
-		else if (pi > n0 - DSB_RING) { uint4 r = ring_ld(w.ring, pi & (DSB_RING - 1)); dst[u].t_pos = r.x; dst[u].q_pos = r.y; dst[u].len = r.z; dst[u].score = r.w; } \
+		else if (RING && pi > n0 - DSB_RING) { uint4 r = ring_ld(w.ring, pi & (DSB_RING - 1)); dst[u].t_pos = r.x; dst[u].q_pos = r.y; dst[u].len = r.z; dst[u].score = r.w; } \
 		else dst[u] = w.sms[pi];                                                                                 \
 	}
 	// The newest group of 64 predecessors goes first and alone: an extension leaves all but its last few dozen nodes more than
@@ -2395,7 +2177,7 @@ DN void sdp_batch_old(WCtxL &w, DpBatchL &b)
 				bool ok = !skip & !brk & (ai <= 200);
 				uint64_t bm = dsb_ballot64(brk);
 				if (bm) {	// the reference stops at the newest predecessor that meets the distance cut
-					int first_brk = grp_first(w.red, DSB_LANE, brk);
+					int first_brk = grp_first(brk);
 					ok = ok & (DSB_LANE < first_brk);
 					stopm |= 1u << j;
 				}
@@ -2409,10 +2191,9 @@ DN void sdp_batch_old(WCtxL &w, DpBatchL &b)
 	w.dp_preds += preds;
 	DSB_HEAVY_CHECK(w);
 #pragma unroll
-	for (int j = 0; j < DSB_DPB; j++) b.old_best[j] = ((uint32_t)j < b.K) ? grp_max_i(w.red, DSB_LANE, best[j]) : 0;
+	for (int j = 0; j < DSB_DPB; j++) b.old_best[j] = ((uint32_t)j < b.K) ? grp_max_i(best[j]) : 0;
 }
 
-#ifndef DSB_HOST_EMU
 // The old-predecessor pass of sdp_batch_old on W wavefronts.  Round r: wave v takes the chunk of 4 x 64 predecessors
 // number r * W + v (newest first).  Every wave works out, for each node of the batch, the best score among the predecessors
 // of its chunk that the reference's newest-first scan would reach if it entered the chunk, and whether the scan stops inside
@@ -2512,7 +2293,7 @@ DN void sdp_batch_old_mw(DsbMw *mw, uint4 *ring, uint32_t *red, const int lane, 
 						ns = (int)(S[u] + nl[j] - (uint32_t)(ai >> 3) - (uint32_t)ovl);   // (unsigned: a lane that fails the first test carries a huge ovl)
 					}
 					bool ok = !skip & !brk & (ai <= 200);
-					if (dsb_ballot64(brk)) { const int first_brk = grp_first(red, lane, brk); ok = ok & (lane < first_brk); cutm |= 1u << j; }
+					if (dsb_ballot64(brk)) { const int first_brk = grp_first(brk); ok = ok & (lane < first_brk); cutm |= 1u << j; }
 					if (ok && ns > v[j]) v[j] = ns;
 				}
 			}
@@ -2520,7 +2301,7 @@ DN void sdp_batch_old_mw(DsbMw *mw, uint4 *ring, uint32_t *red, const int lane, 
 		// exchange the cut flags of this round
 		const uint32_t par = round & 1u;
 		if (lane == 0) mw->cut[par][wv] = cutm;
-		__syncthreads();
+		block_sync();
 		uint32_t newer = 0, all = 0;
 		for (int u = 0; u < W; u++) { const uint32_t c = mw->cut[par][u]; if (u < wv) newer |= c; all |= c; }
 #pragma unroll
@@ -2531,12 +2312,11 @@ DN void sdp_batch_old_mw(DsbMw *mw, uint4 *ring, uint32_t *red, const int lane, 
 	}
 #undef DSB_FETCH_PREDS_MW
 #pragma unroll
-	for (int j = 0; j < DSB_DPB; j++) { const int m = grp_max_i(red, lane, best[j]); if (lane == 0) mw->best[wv][j] = m; }
-	__syncthreads();
+	for (int j = 0; j < DSB_DPB; j++) { const int m = grp_max_i(best[j]); if (lane == 0) mw->best[wv][j] = m; }
+	block_sync();
 	if (preds_out) *preds_out = preds;
 }
 
-#endif
 // best predecessor score of node `cur` (right/left extension), through the batch
 template <int MODE>
 DV int sdp_best_pred_b(WCtxL &w, DpBatchL &b, const DsbSms &cs, int32_t cur, const NodeBlock &nb, const uint32_t n_sms, uint4 *const ring, uint32_t &steps, uint32_t &bn0, uint32_t &bK)
@@ -2548,31 +2328,27 @@ DV int sdp_best_pred_b(WCtxL &w, DpBatchL &b, const DsbSms &cs, int32_t cur, con
 		b.n0 = bn0; b.K = bK;
 		for (uint32_t j = 0; j < bK; j++) {
 			const uint32_t idx = (uint32_t)cur + j;
-#if DSB_GROUP == 64 && !defined(DSB_HOST_EMU)
 			// the block of 64 nodes the caller holds in its lanes (node_get) has most of them: no load
-			if (idx >= nb.base && idx < nb.base + nb.valid) {
+			if (DSB_WAVE == 64 && idx >= nb.base && idx < nb.base + nb.valid) {
 				const int src = (int)(idx - nb.base);
 				b.nd_t[j] = dsb_shfl(nb.mine.t_pos, src); b.nd_q[j] = dsb_shfl(nb.mine.q_pos, src); b.nd_l[j] = dsb_shfl(nb.mine.len, src);
 				continue;
 			}
-#endif
 			const DsbSms g_ = w.sms[cur + j];
 			b.nd_t[j] = g_.t_pos; b.nd_q[j] = g_.q_pos; b.nd_l[j] = g_.len;
 		}
-#ifndef DSB_HOST_EMU
 		if (w.mw && bn0 >= DSB_MW_MIN_PREDS) {
 			// several wavefronts on this read: wake the helpers for the pass over the old predecessors
 			DsbMw *mw = w.mw;
 			if (DSB_LANE < DSB_DPB) { const int sj = (uint32_t)DSB_LANE < b.K ? DSB_LANE : 0; mw->nd_t[DSB_LANE] = b.nd_t[sj]; mw->nd_q[DSB_LANE] = b.nd_q[sj]; mw->nd_l[DSB_LANE] = b.nd_l[sj]; }
 			if (DSB_LANE == 0) { mw->cmd = (uint32_t)MODE; mw->n0 = b.n0; mw->K = b.K; mw->sms = w.sms; }
-			__syncthreads();
+			block_sync();
 			uint32_t preds = 0;
 			sdp_batch_old_mw<MODE>(mw, w.ring, w.red, DSB_LANE, 0, w.n_waves, &preds);
 			w.dp_preds += preds;
 			for (uint32_t j = 0; j < DSB_DPB; j++) { int m = -2147483647 - 1; for (int u = 0; u < w.n_waves; u++) m = MAXV(m, mw->best[u][j]); b.old_best[j] = j < b.K ? m : 0; }
 		} else
-#endif
-		{ TX0(w, t_o); sdp_batch_old<MODE>(w, b); TX1(w, 2, t_o); TXC(w, 6); }
+		{ TX0(w, t_o); sdp_batch_old<MODE, true>(w, b); TX1(w, 2, t_o); TXC(w, 6); }
 		// once per batch: a read whose DP went quadratic is handed over (DSB_HEAVY_CHECK spent the budget) or gets issue priority
 		if (w.status & DSB_ST_HEAVY) steps = w.step_limit;
 		DSB_BOOST_IF_HEAVY(w);
@@ -2589,14 +2365,125 @@ DV int sdp_best_pred_b(WCtxL &w, DpBatchL &b, const DsbSms &cs, int32_t cur, con
 			uint4 r = ring_ld(ring, (uint32_t)(cur - 1 - l) & (DSB_RING - 1)); DsbSms ps; ps.t_pos = r.x; ps.q_pos = r.y; ps.len = r.z; ps.score = r.w;
 			sdp_judge<MODE>(cs, ps, lim_q, lim_t, skip, brk, ns);
 		}
-		const int fb = grp_first(w.red, DSB_LANE, valid && !skip && brk);
+		const int fb = grp_first(valid && !skip && brk);
 		const int mine = (valid && !skip && !brk && DSB_LANE < fb) ? ns : (-2147483647 - 1);
-		const int mx = grp_max_i(w.red, DSB_LANE, mine);
+		const int mx = grp_max_i(mine);
 		if (mx > best) best = mx;
 		if (fb < DSB_WAVE) cut = true;
 	}
 	int ob = b.old_best[cur - (int32_t)bn0];
 	if (!cut && ob > best) best = ob;
+	return best;
+}
+
+// ---- the sparse DP of the right / left extensions, a block of new nodes at a time -------------------------------------------------
+// A 600-base step of an extension appends ~16 match nodes (repeats: hundreds).  Rounds 1-3 scored them one after the other, the
+// lanes over the predecessors of ONE node (sdp_best_pred_b above: ~300 vector instructions, four reductions and three LDS / L2 round
+// trips per node, most lanes idle because a node has a few dozen predecessors within reach) -- a quarter of k_classify's wave time
+// on the viral-RefSeq-sized index.  Here a block of <= 64 new nodes is scored with ONE NODE PER LANE:
+//  * old predecessors (nodes in front of the block), newest first, 64 at a time: lane i of a chunk loads node hi - i, the chunk's
+//    nodes are handed round with v_readlane and every lane judges the node for its own new node; a lane is done at the first
+//    predecessor that meets the distance cut (src/cly.c:2626, 2772: the reference's newest-first scan breaks there), the pass
+//    ends when every lane is done -- for all but repeat windows within the first chunk;
+//  * predecessors inside the block, in ascending order, a node's score broadcast once it is final: scanning newest first and
+//    stopping at the first predecessor p that meets the cut takes the maximum over the predecessors newer than p; in ascending order
+//    that is "forget what you have when a predecessor meets the cut" -- which also discards the old predecessors, all of them older.
+// Same maxima as the reference's loop, everything in registers.  MODE 1 = right, 2 = left (sdp_judge).
+template <int MODE>
+DN int sdp_block_scores(WCtxL &w, const uint32_t n0_, const uint32_t m_, const DsbSms cs)
+{
+	// (arguments of a non-inlined function arrive in vector registers and count as divergent: the block's bounds are the same in all lanes)
+	const uint32_t n0 = DSB_RFL(n0_), m = DSB_RFL(m_);
+	const int lane = DSB_LANE; const DsbSms *const sms = w.sms;
+	const bool mine = (uint32_t)lane < m;
+	uint32_t lim_q, lim_t; sdp_limits<MODE>(cs, lim_q, lim_t);
+	// the terms of sdp_judge that belong to the lane's own node (as in sdp_batch_old): with oq / ot = how far the predecessor's end
+	// runs past the node's start, skip <=> max(oq, ot) > 6 and the overlap penalty is max(oq, ot, 0) -- as long as no coordinate
+	// involved is "negative" (the reference compares them as unsigned numbers; a chain can start at q = -1): then the literal form
+	const uint32_t lq = lim_q, lt = lim_t, dl = lq - lt, nl = cs.len;
+	const uint32_t nq = MODE == 2 ? lq + 6 : cs.q_pos, nt = MODE == 2 ? lt + 6 : cs.t_pos;
+	const bool node_wrapped = dsb_ballot64(mine && (int)(lq | lt | nq | nt | (lt + 600)) < 0) != 0;
+	int best = (int)cs.len; bool done = !mine;
+	uint32_t preds = 0;
+#define DSB_BLK_PLAIN(pt, pq, pl, psc, BRK, OK, NS)                                                                          \
+	const uint32_t A_ = MODE == 2 ? (pq) : (pq) + (pl) + 8, B_ = MODE == 2 ? (pt) : (pt) + (pl) + 8, C_ = MODE == 2 ? (pt) : (pt) + 600; \
+	const int oq_ = MODE == 2 ? (int)(nq - A_) : (int)(A_ - nq), ot_ = MODE == 2 ? (int)(nt - B_) : (int)(B_ - nt);          \
+	const int in_ = (int)((pq) - (pt) - dl); const int ai_ = ABSV(in_);                                                       \
+	int ov_ = MAXV(oq_, ot_); ov_ = MAXV(ov_, 0);                                                                             \
+	const bool sk_ = ov_ > 6;                                                                                                 \
+	const bool BRK = !sk_ & ((MODE == 2) ? (lt + 600 < C_) : (C_ < lt));                                                      \
+	const int NS = (int)((psc) + nl - (uint32_t)(ai_ >> 3) - (uint32_t)ov_);                                                  \
+	const bool OK = !sk_ & !BRK & (ai_ <= 200);
+	// old predecessors, newest first: the first chunk of 64 one node per lane ...
+	int32_t hi = (int32_t)n0 - 1;
+	if (hi >= 0) {
+		const int32_t pi = hi - lane;
+		DsbSms o; o.t_pos = o.q_pos = o.len = o.score = 0;
+		if (pi >= 0) o = sms[pi];
+		const int cnt = hi + 1 < DSB_WAVE ? hi + 1 : DSB_WAVE;
+		const uint32_t oA = MODE == 2 ? o.q_pos : o.q_pos + o.len + 8, oB = MODE == 2 ? o.t_pos : o.t_pos + o.len + 8, oC = MODE == 2 ? o.t_pos : o.t_pos + 600;
+		const bool plain = !node_wrapped && dsb_ballot64(pi >= 0 && (int)(oA | oB | oC) < 0) == 0;
+		if (plain) {
+			for (int k = 0; k < cnt; k++) {
+				const uint32_t pt = dsb_shfl(o.t_pos, k), pq = dsb_shfl(o.q_pos, k), pl = dsb_shfl(o.len, k), psc = dsb_shfl(o.score, k);
+				DSB_BLK_PLAIN(pt, pq, pl, psc, brk, ok, ns)
+				best = (!done & ok & (ns > best)) ? ns : best;
+				done |= brk;
+				preds += DSB_WAVE;                                 // (what the hand-over limit prices is the wavefront's time: a round costs the same however many lanes hold a node)
+				if (dsb_ballot64(!done) == 0) break;
+			}
+		} else {
+			for (int k = 0; k < cnt; k++) {
+				DsbSms ps; ps.t_pos = dsb_shfl(o.t_pos, k); ps.q_pos = dsb_shfl(o.q_pos, k); ps.len = dsb_shfl(o.len, k); ps.score = dsb_shfl(o.score, k);
+				bool skip, brk; int ns; sdp_judge<MODE>(cs, ps, lim_q, lim_t, skip, brk, ns);
+				if (!done) { if (brk) done = true; else if (!skip && ns > best) best = ns; }
+				preds += DSB_WAVE;
+				if (dsb_ballot64(!done) == 0) break;
+			}
+		}
+		hi -= DSB_WAVE;
+	}
+	// ... and for the nodes that have not met their distance cut there (repeats: more than 64 nodes within 600 bases), the rest of the
+	// list with the lanes over the predecessors, eight nodes at a time (sdp_batch_old)
+	uint64_t left = dsb_ballot64(!done);
+	if (hi >= 0 && left) {
+		DpBatchL &b = *w.dpb;
+		while (left) {
+			int id[DSB_DPB]; uint32_t K = 0;
+			for (int j = 0; j < DSB_DPB; j++) { id[j] = -1; if (left) { id[j] = (int)__builtin_ctzll(left); left &= left - 1; K++; } }
+			for (int j = 0; j < DSB_DPB; j++) if (lane == id[j]) { b.nd_t[j] = cs.t_pos; b.nd_q[j] = cs.q_pos; b.nd_l[j] = cs.len; }
+			if (lane == 0) { b.n0 = (uint32_t)hi + 1; b.K = K; for (uint32_t j = K; j < DSB_DPB; j++) { b.nd_t[j] = 0; b.nd_q[j] = 0; b.nd_l[j] = 0; } }
+			wave_sync();
+			sdp_batch_old<MODE, false>(w, b);
+			wave_sync();
+			for (int j = 0; j < DSB_DPB; j++) if (lane == id[j]) { const int ob = b.old_best[j]; if (ob > best) best = ob; }
+			wave_sync();
+		}
+	}
+	// predecessors inside the block, in ascending order
+	if (m > 1) {
+		const uint32_t cA = MODE == 2 ? cs.q_pos : cs.q_pos + cs.len + 8, cB = MODE == 2 ? cs.t_pos : cs.t_pos + cs.len + 8, cC = MODE == 2 ? cs.t_pos : cs.t_pos + 600;
+		const bool plain = !node_wrapped && dsb_ballot64(mine && (int)(cA | cB | cC) < 0) == 0;
+		if (plain) {
+			for (uint32_t c = 0; c + 1 < m; c++) {
+				const uint32_t pt = dsb_shfl(cs.t_pos, (int)c), pq = dsb_shfl(cs.q_pos, (int)c), pl = dsb_shfl(cs.len, (int)c), psc = (uint32_t)dsb_shfl(best, (int)c);
+				DSB_BLK_PLAIN(pt, pq, pl, psc, brk, ok, ns)
+				const bool later = mine & ((uint32_t)lane > c);
+				best = (later & brk) ? (int)cs.len : ((later & ok & (ns > best)) ? ns : best);
+			}
+		} else {
+			for (uint32_t c = 0; c + 1 < m; c++) {
+				DsbSms ps; ps.t_pos = dsb_shfl(cs.t_pos, (int)c); ps.q_pos = dsb_shfl(cs.q_pos, (int)c); ps.len = dsb_shfl(cs.len, (int)c); ps.score = (uint32_t)dsb_shfl(best, (int)c);
+				if (mine && (uint32_t)lane > c) {
+					bool skip, brk; int ns; sdp_judge<MODE>(cs, ps, lim_q, lim_t, skip, brk, ns);
+					if (brk) best = (int)cs.len; else if (!skip && ns > best) best = ns;
+				}
+			}
+		}
+	}
+#undef DSB_BLK_PLAIN
+	w.dp_preds += preds + m * DSB_WAVE;
+	DSB_HEAVY_CHECK(w);
 	return best;
 }
 
@@ -2619,8 +2506,14 @@ DV void fill_window(const WCtxL &w, uint8_t *win, int n)
 // Per lane in LDS (the window table's 12 KB): 12 packed query words and 12 match nodes.  Gaps that do not fit (window
 // > ~220 query positions or > 320 reference bases, > 12 match nodes, windows touching the ends of the read or of the
 // reference text: 10-20 % of the gaps) are left to the cooperative form.
+#ifdef DSB_LDS_DIET
+#define DSB_GL_QW 9
+#define DSB_GL_NODES 8
+#else
 #define DSB_GL_QW 12
 #define DSB_GL_NODES 12
+#endif
+static_assert((DSB_GL_QW + DSB_GL_NODES) * 64u * 8u <= 4u * DSB_WTAB_SLOTS, "gap_lane: its per-lane words live in the window table's LDS");
 #define DSB_GL_MAXT 320
 #define DSB_GL_NONE (-2147483647 - 1)
 #define DSB_GL_K 10000
@@ -2780,21 +2673,13 @@ DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int k
 			if (cost) { const uint32_t lg = 31u - (uint32_t)__builtin_clz(cost); bk = 4u * lg + (lg >= 2 ? (cost >> (lg - 2)) & 3u : 0u) + 1u; }
 			bk = bk > 63u ? 63u : bk;
 			G[gi].pad = bk;
-#ifdef DSB_HOST_EMU
-			hist[bk]++;
-#else
-			__hip_atomic_fetch_add(hist + bk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
+			lds_add(hist + bk, 1u);
 		}
 		wave_sync();
 		if (lane == 0) { uint32_t acc = 0; for (int b = 63; b >= 0; b--) { hist[64 + b] = acc; acc += hist[b]; } }
 		wave_sync();
 		for (uint32_t gi = (uint32_t)lane; gi < n_gap; gi += DSB_WAVE) {
-#ifdef DSB_HOST_EMU
-			const uint32_t pos = hist[64 + G[gi].pad]++;
-#else
-			const uint32_t pos = __hip_atomic_fetch_add(hist + 64 + G[gi].pad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
+			const uint32_t pos = lds_add(hist + 64 + G[gi].pad, 1u);
 			perm[pos] = gi;
 		}
 		wave_sync();
@@ -2811,7 +2696,6 @@ DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int k
 		// all of a usual gap) is requested while this gap is worked on: pf_* hold what was asked for during the previous gap.
 		const uint64_t cur_q = pf_q; const uint32_t cur_t = pf_t; const int32_t cur_qlo = pf_qlo; const uint64_t cur_toff = pf_toff; const bool cur_has_q = pf_has_q, cur_has_t = pf_has_t;
 		pf_has_q = pf_has_t = false;
-#ifndef DSB_HOST_EMU
 		if (gi + 1 < n_gap) {
 			const DsbGap n = G[gi + 1];
 			const int n_mch = (int)n.pl, n_tlen = (int)(n.ct - ((n.pt - 3) + (uint32_t)n_mch) + 3);
@@ -2826,7 +2710,6 @@ DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int k
 				}
 			}
 		}
-#endif
 		const int pre_mch = (int)g.pl;
 		const int pre_refoffset = g.pt - 3;
 		const int total_ref_len = g.ct - (pre_refoffset + pre_mch) + 3;
@@ -2867,8 +2750,7 @@ DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int k
 		n_sms++;                                                     // the last node
 		if (n_sms > w.x->sms_cap) { w.status |= DSB_ST_SMS_OVF; n_sms = w.x->sms_cap; }
 		{
-#ifndef DSB_HOST_EMU
-			if (n_sms <= (uint32_t)DSB_WAVE && DSB_GROUP == 64) {
+			if (n_sms <= (uint32_t)DSB_WAVE && DSB_WAVE == 64) {
 				// small gap (the usual case): one node per lane, the whole DP in registers.  Lane ci's node is
 				// broadcast, lanes < ci judge their own node as its predecessor (sdp_best_pred<0> semantics:
 				// no distance cut), wave max; nothing is written back -- the list is local to this gap.
@@ -2891,12 +2773,11 @@ DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int k
 							}
 						}
 					}
-					int max_score = grp_max_i(w.red, lane, cand);
+					int max_score = grp_max_i(cand);
 					if ((uint32_t)lane == ci) me.score = (uint32_t)max_score;
 					score = MAXV(max_score, score);
 				}
 			} else
-#endif
 			{
 				S[0] = first; S[n_sms - 1].q_pos = last.q_pos; S[n_sms - 1].t_pos = last.t_pos; S[n_sms - 1].len = last.len;
 				wave_sync();
@@ -2917,8 +2798,9 @@ DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int k
 	return score - 10000;
 }
 
-// sdp_right_M2 (src/cly.c:2532-2677)
-DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChain *c_st, int chain_ID, uint32_t l_read, DsbScHash *sc_hash, int score_ori)
+// sdp_right_M2 (src/cly.c:2532-2677), node by node: the form k_classify_heavy runs (its helper wavefronts share the pass over the old
+// predecessors of a node batch, sdp_batch_old_mw); every other launch takes the block-wise form below
+DN int sdp_right_M2_mw(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChain *c_st, int chain_ID, uint32_t l_read, DsbScHash *sc_hash, int score_ori)
 {
 	DsbXP x = w.x;
 	score_ori += 10000;
@@ -3005,8 +2887,8 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 	return total_max_score - 10000;
 }
 
-// sdp_left_M2 (src/cly.c:2679-2819)
-DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChain *c_st, int chain_ID, uint32_t l_read, DsbScHash *sc_hash, int score_ori)
+// sdp_left_M2 (src/cly.c:2679-2819), node by node (k_classify_heavy)
+DN int sdp_left_M2_mw(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChain *c_st, int chain_ID, uint32_t l_read, DsbScHash *sc_hash, int score_ori)
 {
 	DsbXP x = w.x;
 	score_ori += 10000;
@@ -3091,7 +2973,204 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 	return total_max_score - 10000;
 }
 
-// get_score_M2 (src/cly.c:2821-2849)
+// ---- the extensions, block-wise (every launch but k_classify_heavy) ------------------------------------------------------------
+// The loop of src/cly.c:2532-2677 / 2679-2819 takes the match nodes one by one: score, chain merge test, running maximum, stop
+// test.  Here the nodes a 600-base step appended are taken <= 64 at a time: all their scores at once (sdp_block_scores), the merge
+// test of all of them at once (combine_test: it depends on the chains, not on scores), and then the reference's per-node decisions
+// in order from values handed round with v_readlane -- a dozen scalar instructions per node.  A block is cut short where the
+// reference's loop leaves it: at the first node that merges a chain (the list starts over) or that lies > 1000 bases beyond the best.
+// What one block decides (ext_block): how many of its nodes the reference's loop takes, and how it goes on.
+#define DSB_EXT_NEXT 0       /* all nodes of the block taken: the next block, or the next window */
+#define DSB_EXT_STOP 1       /* the extension ends */
+#define DSB_EXT_MERGED 2     /* a chain was merged at the last node taken: the caller starts the list over */
+struct ExtState { int total_max_score; uint32_t best_t, best_q, best_len; uint32_t steps; int merge_score; uint32_t merge_len; DsbChain *combined; };
+template <int MODE>
+DV int ext_block(WCtxL &w, ExtState &e, const uint32_t n0, const uint32_t m, DsbChain *c_st, int chain_ID, DsbScHash *sc_hash, const uint32_t step_limit)
+{
+	const int lane = DSB_LANE; DsbSms *const sms = w.sms;
+	const bool mine = (uint32_t)lane < m;
+	DsbSms cs; cs.t_pos = cs.q_pos = cs.len = cs.score = 0;
+	if (mine) cs = sms[n0 + lane];
+	const int sc = sdp_block_scores<MODE>(w, n0, m, cs);
+	if (mine) sms[n0 + lane].score = (uint32_t)sc;
+	const bool cand = mine && (int)cs.len >= 8 && combine_test(c_st, chain_ID, sc_hash, (int)(cs.t_pos - cs.q_pos), MODE == 2, (int)(MODE == 2 ? cs.q_pos + cs.len : cs.q_pos));
+	const uint64_t cmask = dsb_ballot64(cand);
+	wave_sync();                                                // (the scores: the next block's old predecessors)
+	if (w.status & DSB_ST_HEAVY) { e.steps = step_limit; }        // the read is being handed over (DSB_HEAVY_CHECK)
+	DSB_BOOST_IF_HEAVY(w);
+	for (uint32_t j = 0; j < m; j++) {
+		if (++e.steps > step_limit) { w.status |= DSB_ST_TIMEOUT; return DSB_EXT_STOP; }
+		const int s_j = dsb_shfl(sc, (int)j); const uint32_t t_j = dsb_shfl(cs.t_pos, (int)j);
+		if ((cmask >> j) & 1ULL) {
+			const uint32_t q_j = dsb_shfl(cs.q_pos, (int)j), l_j = dsb_shfl(cs.len, (int)j);
+			if (combine_chain(c_st, chain_ID, sc_hash, (int)(t_j - q_j), MODE == 2, (int)(MODE == 2 ? q_j + l_j : q_j), &e.combined)) { e.merge_score = s_j; e.merge_len = l_j; return DSB_EXT_MERGED; }
+		}
+		if (e.total_max_score < s_j) { e.total_max_score = s_j; e.best_t = t_j; e.best_q = dsb_shfl(cs.q_pos, (int)j); e.best_len = dsb_shfl(cs.len, (int)j); }
+		if (MODE == 1 ? (t_j > e.best_t + 1000) : (t_j + 1000 < e.best_t)) return DSB_EXT_STOP;
+	}
+	return DSB_EXT_NEXT;
+}
+
+// sdp_right_M2 (src/cly.c:2532-2677)
+DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChain *c_st, int chain_ID, uint32_t l_read, DsbScHash *sc_hash, int score_ori)
+{
+	DsbXP x = w.x;
+	score_ori += 10000;
+	DsbChain *c_h = c_st + chain_ID;
+	w.n_sms = 0;
+	uint8_t *ref = w.win_right;
+	fill_window(w, ref, 1000 + 128);
+	wave_sync();
+	DsbSms *p = push_sms(w);
+	p->score = score_ori; p->q_pos = c_h->q_ed; p->t_pos = c_h->t_ed; p->len = 1 - 9;
+	ExtState e; e.total_max_score = score_ori; e.best_t = c_h->t_ed; e.best_q = c_h->q_ed; e.best_len = (uint32_t)(1 - 9);     // fields of the best node so far (node 0)
+	e.steps = w.steps; e.combined = nullptr; e.merge_score = 0; e.merge_len = 0;
+	uint32_t current_sms = 1, n_sms = 1;
+	uint64_t t_offset_global = x->refinfo[c_h->ref_ID].seq_offset, t_length = x->refinfo[c_h->ref_ID].seq_l;
+	uint32_t c_t_offset = c_h->t_ed - 3;
+	int last_search = false;
+	uint32_t ch_q_st = c_h->q_st, ch_q_ed = c_h->q_ed;       // (they change when a chain is combined in: read again there)
+	const uint32_t step_limit = w.step_limit; DsbSms *const sms = w.sms;
+	wave_sync();
+	while (1) {
+		if (++e.steps > step_limit) { w.status |= DSB_ST_TIMEOUT; break; }
+		if (n_sms == current_sms) {
+			uint32_t next_step = t_length - c_t_offset;
+			if (next_step < 12) break;
+			uint32_t max_search_ref;
+			if (l_read - ch_q_ed < 600) {
+				if (last_search == true) break;
+				last_search = true;
+				max_search_ref = l_read - ch_q_ed + 60;
+			} else max_search_ref = t_length - c_t_offset;
+			max_search_ref = MINV(600u, max_search_ref);
+			get_ref_wave(x->refbin, x->ref_bases, DSB_LANE, ref, c_t_offset + t_offset_global, max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50);
+			wave_sync();
+			TXC(w, 7);
+			int search_q_ed = (int)e.best_q + 1000;
+			search_q_ed = MINV((uint32_t)search_q_ed, l_read);
+			int search_q_st = MAXV((uint32_t)(search_q_ed - 2000), ch_q_st - 8);
+			SUB0(w);
+			sdp_match(w, search_q_st, search_q_ed, q_str, ref, max_search_ref, key_len, tbl, c_t_offset, true);
+			SUB1(w, 10);
+			c_t_offset += max_search_ref - 9 - 3;
+			n_sms = w.n_sms;
+			if (n_sms == current_sms) break;
+			if (sms[current_sms].t_pos > e.best_t + 1000) break;
+		}
+		const uint32_t m = MINV((uint32_t)DSB_WAVE, n_sms - current_sms);
+		SUB0(w);
+		const int how = ext_block<1>(w, e, current_sms, m, c_st, chain_ID, sc_hash, step_limit);
+		SUB1(w, 11);
+		if (how == DSB_EXT_STOP) break;
+		if (how == DSB_EXT_MERGED) {
+			w.steps = e.steps;
+			e.total_max_score = MAXV(score_ori, e.merge_score) - (int)e.merge_len + sdp_middle_M2(w, e.combined->cur, q_str, tbl, key_len);
+			e.steps = w.steps;
+			ch_q_st = c_h->q_st; ch_q_ed = c_h->q_ed;
+			score_ori = e.total_max_score;
+			w.n_sms = 0;
+			p = push_sms(w); n_sms = 1;
+			p->score = e.total_max_score; p->q_pos = c_h->q_ed; p->t_pos = c_h->t_ed; p->len = -9;
+			e.best_t = c_h->t_ed; e.best_q = c_h->q_ed; e.best_len = (uint32_t)(-9);
+			current_sms = 1;
+			c_t_offset = c_h->t_ed;
+			wave_sync();
+			continue;
+		}
+		current_sms += m;
+	}
+	w.steps = e.steps;
+	c_h->q_ed = e.best_q + e.best_len + 9;
+	c_h->t_ed = e.best_t + e.best_len + 9;
+	return e.total_max_score - 10000;
+}
+
+// sdp_left_M2 (src/cly.c:2679-2819)
+DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChain *c_st, int chain_ID, uint32_t l_read, DsbScHash *sc_hash, int score_ori)
+{
+	DsbXP x = w.x;
+	score_ori += 10000;
+	DsbChain *c_h = c_st + chain_ID;
+	w.n_sms = 0;
+	uint8_t *ref = w.win_left;
+	fill_window(w, ref, 1000 + 128);
+	wave_sync();
+	DsbSms *p = push_sms(w);
+	p->score = score_ori; p->q_pos = c_h->q_st; p->t_pos = c_h->t_st; p->len = 0;          // (a[0].len is never read by the left DP)
+	ExtState e; e.total_max_score = score_ori; e.best_t = c_h->t_st; e.best_q = c_h->q_st; e.best_len = 0;
+	e.steps = w.steps; e.combined = nullptr; e.merge_score = 0; e.merge_len = 0;
+	uint32_t current_sms = 1, n_sms = 1;
+	uint64_t t_offset_global = x->refinfo[c_h->ref_ID].seq_offset;
+	uint32_t c_t_offset = c_h->t_st + 3;
+	int last_search = false;
+	uint32_t ch_q_st = c_h->q_st;                             // (changes when a chain is combined in: read again there)
+	const uint32_t step_limit = w.step_limit; DsbSms *const sms = w.sms;
+	wave_sync();
+	while (1) {
+		if (++e.steps > step_limit) { w.status |= DSB_ST_TIMEOUT; break; }
+		if (n_sms == current_sms) {
+			uint32_t next_step = c_t_offset;
+			if (next_step < 12) break;
+			uint32_t max_search_ref;
+			if (ch_q_st < 600) {
+				if (last_search == true) break;
+				last_search = true;
+				max_search_ref = ch_q_st + 60;
+			} else max_search_ref = c_t_offset;
+			max_search_ref = MINV(600u, max_search_ref);
+			if (t_offset_global == 0 && c_t_offset < 50 + max_search_ref)
+				{ get_ref_wave(x->refbin, x->ref_bases, DSB_LANE, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref), max_search_ref); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref); }
+			else
+				{ get_ref_wave(x->refbin, x->ref_bases, DSB_LANE, ref, (int64_t)(c_t_offset + t_offset_global - max_search_ref - 50), max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50); }
+			wave_sync();
+			int search_q_st = (int)e.best_q - 1000;
+			search_q_st = MAXV(search_q_st, 0);
+			int search_q_ed = MINV((uint32_t)(search_q_st + 2000), ch_q_st - 1);
+			TXC(w, 9);
+			TX0(w, t_lm);
+			sdp_match(w, search_q_st, search_q_ed, q_str, ref + 50, max_search_ref, key_len, tbl, c_t_offset - max_search_ref, false);
+			TX1(w, 3, t_lm);
+			c_t_offset = c_t_offset - max_search_ref + 9 + 3;
+			n_sms = w.n_sms;
+			if (n_sms == current_sms) break;
+			if (sms[current_sms].t_pos + 1000 < e.best_t) break;
+		}
+		const uint32_t m = MINV((uint32_t)DSB_WAVE, n_sms - current_sms);
+		TX0(w, t_ld);
+		const int how = ext_block<2>(w, e, current_sms, m, c_st, chain_ID, sc_hash, step_limit);
+		TX1(w, 4, t_ld);
+		if (how == DSB_EXT_STOP) break;
+		if (how == DSB_EXT_MERGED) {
+			w.steps = e.steps;
+			e.total_max_score = MAXV(score_ori, e.merge_score) - (int)e.merge_len + sdp_middle_M2(w, e.combined->cur, q_str, tbl, key_len);
+			e.steps = w.steps;
+			ch_q_st = c_h->q_st;
+			score_ori = e.total_max_score;
+			w.n_sms = 0;
+			p = push_sms(w); n_sms = 1;
+			p->score = e.total_max_score; p->q_pos = c_h->q_st; p->t_pos = c_h->t_st; p->len = 0;
+			e.best_t = c_h->t_st; e.best_q = c_h->q_st;
+			current_sms = 1;
+			c_t_offset = c_h->t_st;
+			wave_sync();
+			continue;
+		}
+		current_sms += m;
+	}
+	w.steps = e.steps;
+	c_h->q_st = e.best_q;
+	c_h->t_st = e.best_t;
+	return e.total_max_score - 10000;
+}
+
+// get_score_M2 (src/cly.c:2821-2849).  MW: the workgroup has helper wavefronts (k_classify_heavy): the extensions go node by node
+#ifdef DSB_EXT_PERNODE         /* A/B builds: every launch takes the node-by-node extensions of rounds 1-3 */
+#define DSB_EXT_MW(MW) true
+#else
+#define DSB_EXT_MW(MW) (MW)
+#endif
+template <bool MW>
 DN void get_score_M2(WCtxL &w, SDirL *sd, uint32_t l_read, DsbScHash *sc_hash)
 {
 	TICK(w, 8);
@@ -3108,10 +3187,10 @@ DN void get_score_M2(WCtxL &w, SDirL *sd, uint32_t l_read, DsbScHash *sc_hash)
 		int score = sdp_middle_M2(w, H[i].cur, csd->bin_read, tbl, key_len);
 		MARK(w, 53);
 		TICK(w, 5);
-		score = sdp_right_M2(w, csd->bin_read, tbl, key_len, H, i, l_read, sc_hash, score);
+		score = DSB_EXT_MW(MW) ? sdp_right_M2_mw(w, csd->bin_read, tbl, key_len, H, i, l_read, sc_hash, score) : sdp_right_M2(w, csd->bin_read, tbl, key_len, H, i, l_read, sc_hash, score);
 		MARK(w, 54);
 		TICK(w, 6);
-		score = sdp_left_M2(w, csd->bin_read, tbl, key_len, H, i, l_read, sc_hash, score);
+		score = DSB_EXT_MW(MW) ? sdp_left_M2_mw(w, csd->bin_read, tbl, key_len, H, i, l_read, sc_hash, score) : sdp_left_M2(w, csd->bin_read, tbl, key_len, H, i, l_read, sc_hash, score);
 		MARK(w, 55);
 		TICK(w, 7);
 		H[i].sum_score = score;
@@ -3119,6 +3198,7 @@ DN void get_score_M2(WCtxL &w, SDirL *sd, uint32_t l_read, DsbScHash *sc_hash)
 }
 
 // delete_small_score_rst (src/cly.c:2883-2993)
+template <bool MW>
 DN void delete_small_score_rst(WCtxL &w, SDirL *sd, uint32_t l_read)
 {
 	DsbXP x = w.x;
@@ -3135,7 +3215,7 @@ DN void delete_small_score_rst(WCtxL &w, SDirL *sd, uint32_t l_read)
 		sc_hash_idx(w.sc, w.hit, w.n_hit);
 	}
 	serial_end(w);
-	get_score_M2(w, sd, l_read, w.sc);
+	get_score_M2<MW>(w, sd, l_read, w.sc);
 	DSB_SERIAL(w) {
 	DsbChain *st_c = w.hit, *ed_c = st_c + w.n_hit, *c_c;
 	if (w.n_hit > 1) glibc_sort_chains<1>(w, w.n_hit);
@@ -3250,11 +3330,12 @@ DN void fast_classify_lane(WCtxL &w, bool valid, uint8_t *bin, uint32_t read_len
 		}
 	}
 	*n_anc_out = l.n_anc; *ovf_out = (l.status & (DSB_ST_ANC_OVF | DSB_ST_TIMEOUT)) ? 1u : 0u;
-	const uint32_t gen = (uint32_t)grp_max_i(w.red, lane, (int)l.sp_gen);
+	const uint32_t gen = (uint32_t)grp_max_i((int)l.sp_gen);
 	w.n_anc = 0; w.sp_gen = gen;
 	wave_sync();
 }
 
+template <bool MW>
 DN uint32_t classify_read(WCtxL &w, const uint64_t *bitsF, const uint64_t *bitsR, const bool have_anchors = false)
 {
 	uint32_t read_len = w.L;
@@ -3305,7 +3386,7 @@ DN uint32_t classify_read(WCtxL &w, const uint64_t *bitsF, const uint64_t *bitsR
 	}
 	TICK(w, 3);
 	w.stage = 5; MARK(w, 5);
-	delete_small_score_rst(w, sd, read_len);
+	delete_small_score_rst<MW>(w, sd, read_len);
 	TICK(w, 8);
 	w.stage = 6; MARK(w, 6);
 	DSB_SERIAL(w) detect_primary(w, read_len);

@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x
 			w.n_anc = na;                                                                                               \
 			NS::wave_sync();                                                                                            \
 		}                                                                                                               \
-		uint32_t fast = NS::classify_read(w, bits + d.bit_off, bits + d.bit_off + d.n_words, have_anc);                 \
+		uint32_t fast = NS::template classify_read<false>(w, bits + d.bit_off, bits + d.bit_off + d.n_words, have_anc);                 \
 		if (w.boosted) __builtin_amdgcn_s_setprio(0);                                                                   \
 		/* publish the hits of this read (none if it is handed over to k_classify_heavy) */                            \
 		if (w.status & DSB_ST_HEAVY) w.n_hit = 0;                                                                       \
@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(64 * MWW, DSB_WAVES_PER_EU) k_classify_heavy(D
 			w.bin = bin + d.bin_off + DSB_QPAD_L; w.L = d.len; w.status = 0; w.max_read_l = d.hist_max;
 			w.pre_seeds = seed_blob ? seed_blob + d.seed_off : nullptr; w.pre_info = sinfo + r;
 			w.pk[0] = pk + d.pk_off; w.pk[1] = w.pk[0] + ((d.len + 31) / 32 + 1);
-			const uint32_t fast = dsb_g64::classify_read(w, bits + d.bit_off, bits + d.bit_off + d.n_words);
+			const uint32_t fast = dsb_g64::classify_read<true>(w, bits + d.bit_off, bits + d.bit_off + d.n_words);
 			if (w.boosted) __builtin_amdgcn_s_setprio(0);
 			if (lane == 0) { mw.cmd = 3; s_word = w.n_hit ? atomicAdd(hout_counter, w.n_hit) : 0u; }
 			__syncthreads();                                                // releases the helper waves from this read
@@ -1083,7 +1083,7 @@ static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_b
 	if ((rc = grow(&c->d_heavy, &c->cap_heavy, n + 1))) return rc;
 	if ((rc = grow(&c->d_order, &c->cap_order, n + 1))) return rc;
 	// reads in flight: one wavefront each; default = what is resident at once (12 waves per CU: LDS), bounded by the batch
-	int want = c->opts.n_slots > 0 ? c->opts.n_slots : 256 * 12;
+	int want = c->opts.n_slots > 0 ? c->opts.n_slots : 256 * 4 * DSB_WAVES_PER_EU;
 	if ((size_t)want > n) want = (int)(n ? n : 1);
 	if (want < c->n_slots) want = c->n_slots;
 	// The arenas are built for the length the caller announced even when this batch's reads are shorter: the four-read batch that

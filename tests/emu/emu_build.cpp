@@ -35,6 +35,7 @@ extern "C" int dsb_emu_index_build(const char *kmer_srt, const char *fasta, cons
 	if (dsb_build_read_fasta(fasta, in)) return -1;
 	if (kmer_srt && *kmer_srt && dsb_build_read_kmers(kmer_srt, in)) return -1;
 	HostBE be;
+	if (const char *e = getenv("DSB_FORCE_EK_LEVEL")) in.force_ek_level = atoi(e);
 	const int rc = dsb_build_run(be, in, out);
 	if (rc) return rc;
 	if (stats) { stats[0] = out.n_kmer; stats[1] = out.n_uni; stats[2] = out.n_rows; stats[3] = in.refs.size(); }

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE: runs the DEVICE code of desamba_amd (dsb_classify_dev.h, dsb_probe.h) on the
-// host as a 1-lane wave (-DDSB_HOST_EMU), so the per-read logic can be checked against the oracle
-// with `pytest -m "not gpu"`, gdb and sanitizers.  Not linked into libdesamba_amd.so.
+// host (-DDSB_HOST_EMU) -- as a 1-lane wave (libdsbemu.so: fast, the per-read logic) or as 64 lanes on cooperative
+// fibers (-DDSB_EMU_LANES=64 + emu_fiber.cpp, libdsbemu64.so: every cross-lane operation, every lane's indexing) -- so
+// it can be checked against the oracle with `pytest -m "not gpu"`, gdb and sanitizers.  Not linked into libdesamba_amd.so.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -54,10 +55,10 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	add((size_t)DSB_SPHASH * 8); add(1024 * sizeof(int));                // 9,10
 	add((size_t)2 * DSB_ANC_CAP * 8); add((size_t)2 * DSB_ANC_CAP * 4);  // 11,12
 	add(3 * DSB_REFWIN);                                                 // 13
-	add((size_t)DSB_LANE_ANC_CAP * sizeof(DsbAnchor)); add((size_t)DSB_SPHASH * 8); add(((size_t)(e->max_len >> 1) + 64) * 4);   // 14,15,16 (1 lane)
+	add((size_t)DSB_WAVE * DSB_LANE_ANC_CAP * sizeof(DsbAnchor)); add((size_t)DSB_WAVE * DSB_SPHASH * 8); add(((size_t)(e->max_len >> 1) + 64) * 4);   // 14,15,16 (per-lane scratch)
 	add(((size_t)(e->max_len >> 1) + 64) * 4);                           // 17 island records of fast_classify
 	e->arena.assign(o + 256, 0xCD);
-	memset(e->arena.data() + off[9], 0, DSB_SPHASH * 8); memset(e->arena.data() + off[15], 0, DSB_SPHASH * 8); e->w.sp_gen = 0;
+	memset(e->arena.data() + off[9], 0, DSB_SPHASH * 8); memset(e->arena.data() + off[15], 0, (size_t)DSB_WAVE * DSB_SPHASH * 8); e->w.sp_gen = 0;
 	uint8_t *s = e->arena.data(); WCtx &w = e->w;
 	w.x = &e->dx; w.dbg = nullptr;
 	w.seeds = (DsbSeed *)(s + off[0]); w.anc = (DsbAnchor *)(s + off[1]); w.anc_tmp = (DsbAnchor *)(s + off[2]);
@@ -109,7 +110,12 @@ extern "C" int emu_classify(void *p, const char *seq, uint32_t L, int hist_max, 
 	w.bin = F; w.L = L; w.status = 0; w.max_read_l = hist_max;
 	w.mw = nullptr; w.n_waves = 1;
 	w.pre_seeds = nullptr; w.pre_info = nullptr; w.pk[0] = getenv("DSB_EMU_NO_GAP_LANE") ? nullptr : e->pk.data(); w.pk[1] = w.pk[0] ? w.pk[0] + nw : nullptr;
-	classify_read(w, e->bits.data(), e->bits.data() + n_words);
+#if DSB_EMU_LANES == 64
+	struct Job { WCtx *w; const uint64_t *bF, *bR; } job = {&w, e->bits.data(), e->bits.data() + n_words};
+	dsb_emu_run([](void *a) { Job *j = (Job *)a; classify_read<false>(*j->w, j->bF, j->bR); }, &job);
+#else
+	classify_read<false>(w, e->bits.data(), e->bits.data() + n_words);
+#endif
 	if (w.status) return -(w.status | (w.stage << 8));
 	int n = (int)w.n_hit < max_out ? (int)w.n_hit : max_out;
 	for (int i = 0; i < n; i++) {

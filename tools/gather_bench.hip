@@ -35,9 +35,17 @@ template <int U> static void run(const uint32_t *tab, uint64_t bytes, uint32_t *
 	const double n = (double)blocks * 256 * iters * U;
 	printf("table %6.0f MiB  %2d loads in flight per lane: %7.1f G lines/s = %6.0f GB/s of 64-byte lines (%.1f ms)\n", bytes / 1048576.0, U, n / ms / 1e6, n * 64 / ms / 1e6, ms);
 }
-int main()
+// `gather_bench MiB`: that table size only (a power of two), depths 4 / 8 / 16 (bench.py prints the best beside the seed lookup's rate)
+int main(int argc, char **argv)
 {
 	uint32_t *tab = nullptr, *sink = nullptr;
+	if (argc > 1) {
+		const uint64_t b = (uint64_t)atoll(argv[1]) << 20;
+		if (b < (1u << 20) || (b & (b - 1))) { fprintf(stderr, "usage: gather_bench [MiB, a power of two]\n"); return 2; }
+		CHK(hipMalloc((void **)&tab, b)); CHK(hipMalloc((void **)&sink, 4)); CHK(hipMemset(tab, 1, b));
+		run<4>(tab, b, sink); run<8>(tab, b, sink); run<16>(tab, b, sink);
+		return 0;
+	}
 	const uint64_t maxb = 16ULL << 30;
 	CHK(hipMalloc((void **)&tab, maxb)); CHK(hipMalloc((void **)&sink, 4));
 	CHK(hipMemset(tab, 1, maxb));

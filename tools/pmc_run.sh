@@ -16,7 +16,7 @@ for grp in "$@"; do
 	if [ -n "$PMC_SEED_HBM_MIB" ]; then
 		(cd /tmp && timeout -k 10 300 rocprofv3 --pmc $grp -d "$out" -o run --output-format csv -- python3 "$ROOT/tools/seed_hbm_only.py" "$reads" "$PMC_SEED_HBM_MIB" > "$out.log" 2>&1) || { echo "pass $i ($grp) failed"; tail -5 "$out.log"; }
 	else
-		(cd /tmp && timeout -k 10 300 rocprofv3 --pmc $grp -d "$out" -o run --output-format csv -- python3 "$ROOT/bench.py" --headline "${PMC_HEADLINE:-strain}" --no-cpu-baseline --no-end-to-end --no-cli --no-demo-index --steps 2 --warmup 0 --batches 1 --reads-per-gpu "$reads" > "$out.log" 2>&1) || { echo "pass $i ($grp) failed"; tail -5 "$out.log"; }
+		(cd /tmp && timeout -k 10 300 rocprofv3 --pmc $grp -d "$out" -o run --output-format csv -- python3 "$ROOT/bench.py" --headline "${PMC_HEADLINE:-strain}" --no-cpu-baseline --no-end-to-end --no-cli --no-demo-index --no-proxy --no-short-reads --steps 2 --warmup 0 --batches 1 --reads-per-gpu "$reads" > "$out.log" 2>&1) || { echo "pass $i ($grp) failed"; tail -5 "$out.log"; }
 	fi
 	i=$((i+1))
 done
@@ -37,7 +37,8 @@ for k in acc:                     # per launch: average over the dispatches of t
     for c in acc[k]:
         acc[k][c] /= max(len(disp[k][c]), 1)
 import desamba_amd as D
-json.dump({"workload": {"reads_per_gpu": reads, "read_len": 50000, "library": D.lib().dsb_version().decode(),
+import bench
+json.dump({"workload": {"reads_per_gpu": reads, "read_len": 50000, "library": D.lib().dsb_version().decode(), "device_source_md5": bench.device_source_md5(),
                         **({"table_mib": mib, "what": "%d x 50 kbp ONT reads, tools/seed_hbm_only.py on 2 x %d MiB synthetic tables; per-launch averages" % (reads, mib)} if mib else
                            {"index": os.environ.get("PMC_HEADLINE", "strain"), "what": "%d x 50 kbp ONT reads, bench.py --headline %s --steps 2 --warmup 0 --batches 1; per-launch averages" % (reads, os.environ.get("PMC_HEADLINE", "strain"))})}, "counters": acc},
           open("gpurun_out/pmc_%s.json" % tag, "w"), indent=1, sort_keys=True)
