@@ -161,3 +161,90 @@ def test_cli_index_with_and_without_a_kmer_list(tmp_path):
     subprocess.run([cli, "index", srt, fa, str(tmp_path / "b")], check=True, stderr=subprocess.DEVNULL)
     check_case("graph2", str(tmp_path / "b"))
     assert subprocess.run([cli, "index", str(tmp_path / "nope.fa"), str(tmp_path / "c")], stderr=subprocess.DEVNULL).returncode == 1
+
+
+# ---- every filter k the reference knows (src/idx.c:966-982): forced table levels on one small reference -----------------------------
+# tests/golden/eklevel (made by make_eklevel_golden.py from the reference's UB-pinned build with DSB_FORCE_EK_LEVEL): level 1 = k 17,
+# 2 x 256 MiB, 31-bit mask; level 5 = k 19, 2 x 4 GiB, 35-bit mask; level 7 = k 20, 2 x 16 GiB, 37-bit mask (rounds 1-3 only ever met k 16 / 18)
+EKL = os.path.join(ROOT, "tests", "golden", "eklevel")
+
+
+def eklevel_inputs(tmp_path):
+    fa = str(tmp_path / "ref.fa"); fq = str(tmp_path / "reads.fq")
+    open(fa, "wb").write(gzip.open(os.path.join(EKL, "ref.fa.gz")).read())
+    open(fq, "wb").write(gzip.open(os.path.join(EKL, "reads.fq.gz")).read())
+    return fa, fq
+
+
+def check_eklevel_files(out, lv, hash_tables=True):
+    want = json.load(open(os.path.join(EKL, "digests.json")))[str(lv)]
+    assert os.path.getsize(os.path.join(out, "deSAMBA.exk0")) == want["exk_bytes"] == os.path.getsize(os.path.join(out, "deSAMBA.exk1"))
+    got = {e: hashlib.md5(build_lib.canonical_bytes(out, e)).hexdigest() for e in build_lib.EXTS if e not in (".exk0", ".exk1")}
+    if hash_tables:
+        got[".exk0"] = md5_file(os.path.join(out, "deSAMBA.exk0")); got[".exk1"] = md5_file(os.path.join(out, "deSAMBA.exk1"))
+    assert got == {k: want[k] for k in got}, {k: (got[k], want[k]) for k in got if got[k] != want[k]}
+
+
+def test_forced_k17_tables_in_the_host_emulation_and_the_oracle(tmp_path, monkeypatch):
+    """level 1 (k = 17): the builder's stages on the host write the reference's files; the oracle classifies on them like the reference"""
+    import oracle_lib
+    fa, fq = eklevel_inputs(tmp_path)
+    monkeypatch.setenv("DSB_FORCE_EK_LEVEL", "1")
+    out = str(tmp_path / "idx")
+    build_lib.emu_build(fa, out)
+    check_eklevel_files(out, 1)
+    sam = str(tmp_path / "o.sam")
+    oracle_lib.Oracle(out).classify_file(fq, sam)
+    assert open(sam, "rb").read() == open(os.path.join(EKL, "level1.ubfree.sam"), "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lv", [1, 5, 7])
+def test_gpu_forced_filter_levels(lv, tmp_path, monkeypatch):
+    """dsb_index_build with k = 17 / 19 / 20 filter tables forced on a small reference: the reference's files (the 16-GiB tables of
+    level 7 by size only: their content is checked through what is classified on them), and `deSAMBA classify` on that index gives the
+    SAM of the reference on ITS index of that level -- 36- and 37-bit hash masks, 64-bit table offsets, k-mers of up to 40 bits"""
+    import shutil
+    import desamba_amd as D
+    need = 2 * (1 << (27 + lv))
+    free_disk = shutil.disk_usage(str(tmp_path)).free
+    avail = next(int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable:"))
+    if free_disk < need * 1.2 + (2 << 30) or avail < need * 1.5 + (4 << 30):
+        pytest.skip("level %d needs %.0f GiB of disk and memory: %.0f / %.0f GiB free" % (lv, need / 2**30, free_disk / 2**30, avail / 2**30))
+    fa, fq = eklevel_inputs(tmp_path)
+    monkeypatch.setenv("DSB_FORCE_EK_LEVEL", str(lv))
+    out = str(tmp_path / "idx")
+    D.build_index(fa, out)
+    monkeypatch.delenv("DSB_FORCE_EK_LEVEL")
+    check_eklevel_files(out, lv, hash_tables=(lv < 7))
+    sam = str(tmp_path / "out.sam")
+    subprocess.run([os.path.join(ROOT, "desamba_amd", "bin", "deSAMBA"), "classify", out, fq, "-o", sam], check=True, stderr=subprocess.DEVNULL)
+    assert open(sam, "rb").read() == open(os.path.join(EKL, "level%d.ubfree.sam" % lv), "rb").read()
+    shutil.rmtree(out)
+
+
+@pytest.mark.gpu
+def test_gpu_gbp_scale_index_against_the_reference(tmp_path):
+    """BASELINE configs[4] shape under the test runner: a 1.2-Gbp synthetic collection indexed by dsb_index_build (1 G BWT rows, filter
+    tables of 2 x 512 MiB with k = 17, the raw or compressed 13-mer table as the data decide), 2048 PacBio-mixed reads classified by
+    the CLI and by the reference's UB-pinned build on the same index directory: identical SAM"""
+    import shutil
+    import desamba_amd as D
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "deSAMBA_ubfree")
+    if not os.path.exists(ref_bin):
+        pytest.skip("oracle/_ref/deSAMBA_ubfree is not built")
+    if shutil.disk_usage(str(tmp_path)).free < (12 << 30):
+        pytest.skip("needs 12 GiB of disk")
+    fa = str(tmp_path / "syn.fa"); out = str(tmp_path / "idx"); fq = str(tmp_path / "r.fq")
+    subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "synth_ref.py"), fa, "1200", "17", "3", "60", "12"], check=True, stderr=subprocess.DEVNULL)
+    st = D.build_index(fa, out)
+    os.remove(fa)
+    print("1.2-Gbp index: %d sequences, %d 31-mers, %d BWT rows in %.1f s" % (st.n_refs, st.n_kmer, st.n_rows, st.total_s))
+    assert st.n_bases > 1_150_000_000 and os.path.getsize(os.path.join(out, "deSAMBA.exk0")) >= (256 << 20)
+    subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "gen_fastq.py"), out, fq, "2048", "12000", "0.13", "3", "pacbio", "8"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "desamba_amd", "bin", "deSAMBA"), "classify", out, fq, "-o", str(tmp_path / "gpu.sam")], check=True, stderr=subprocess.DEVNULL)
+    t = min(16, len(os.sched_getaffinity(0)))
+    subprocess.run([ref_bin, "classify", "-t", str(t), out, fq, "-o", str(tmp_path / "ref.sam")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    a = open(tmp_path / "gpu.sam", "rb").read(); b = open(tmp_path / "ref.sam", "rb").read()
+    assert a.count(b"\n") > 2048 and a == b
+    shutil.rmtree(out)
