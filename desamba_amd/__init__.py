@@ -50,7 +50,7 @@ class DsbTiming(C.Structure):
                 ("n_regrow", C.c_uint32), ("seed_scan", C.c_uint32),
                 ("n_occ", C.c_uint64), ("n_mem", C.c_uint64), ("n_sa", C.c_uint64), ("ref_bases", C.c_uint64),
                 ("main_occ", C.c_uint64), ("main_mem", C.c_uint64), ("main_sa", C.c_uint64), ("main_ref_bases", C.c_uint64),
-                ("n_heavy_mw", C.c_uint32), ("n_requeue", C.c_uint32)]
+                ("n_heavy_mw", C.c_uint32), ("n_requeue", C.c_uint32), ("upload_bytes", C.c_uint64)]
 
 
 class DsbBuildStats(C.Structure):
@@ -63,11 +63,11 @@ class DsbChunk(C.Structure):
 
 
 EXPORTS = ["dsb_index_open", "dsb_index_close", "dsb_index_n_ref", "dsb_index_ref_name", "dsb_index_ref_len", "dsb_index_ek_len",
-           "dsb_index_occ_host", "dsb_ctx_create", "dsb_ctx_destroy", "dsb_ctx_reset_history", "dsb_classify_batch",
+           "dsb_index_occ_host", "dsb_ctx_create", "dsb_ctx_destroy", "dsb_ctx_reset_history", "dsb_ctx_reload_env", "dsb_classify_batch",
            "dsb_batch_upload", "dsb_batch_upload_fastq", "dsb_batch_upload_text", "dsb_ctx_set_history", "dsb_host_alloc", "dsb_host_free", "dsb_host_cpus", "dsb_batch_run", "dsb_batch_fetch", "dsb_batch_timing", "dsb_batch_seeds", "dsb_batch_exist_bits",
            "dsb_format_sam", "dsb_format_des", "dsb_strerror", "dsb_version",
            "dsb_device_count", "dsb_ctx_select_slot", "dsb_ctx_create_multi", "dsb_multi_destroy", "dsb_multi_n", "dsb_multi_ctx",
-           "dsb_multi_reset_history", "dsb_multi_classify_batch", "dsb_shard_plan", "dsb_ctx_use_synthetic_filter", "dsb_synthetic_filter_bit", "dsb_index_prefix_interval", "dsb_index_build"]
+           "dsb_multi_reset_history", "dsb_multi_last_calls", "dsb_multi_classify_batch", "dsb_shard_plan", "dsb_ctx_use_synthetic_filter", "dsb_synthetic_filter_bit", "dsb_index_prefix_interval", "dsb_index_build"]
 
 _lib = None
 
@@ -90,6 +90,7 @@ def lib():
     L.dsb_ctx_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(DsbOpts), C.POINTER(C.c_void_p)]
     L.dsb_ctx_destroy.argtypes = [C.c_void_p]
     L.dsb_ctx_reset_history.argtypes = [C.c_void_p]
+    L.dsb_ctx_reload_env.argtypes = [C.c_void_p]; L.dsb_ctx_reload_env.restype = None
     L.dsb_classify_batch.argtypes = [C.c_void_p, C.POINTER(DsbRead), C.c_size_t, C.POINTER(DsbResult)]
     L.dsb_batch_upload.argtypes = [C.c_void_p, C.POINTER(DsbRead), C.c_size_t]
     L.dsb_batch_upload_fastq.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t]; L.dsb_batch_upload_fastq.restype = C.c_long
@@ -113,6 +114,7 @@ def lib():
     L.dsb_multi_n.argtypes = [C.c_void_p]
     L.dsb_multi_ctx.argtypes = [C.c_void_p, C.c_int]; L.dsb_multi_ctx.restype = C.c_void_p
     L.dsb_multi_reset_history.argtypes = [C.c_void_p]; L.dsb_multi_reset_history.restype = None
+    L.dsb_multi_last_calls.argtypes = [C.c_void_p, C.c_int]; L.dsb_multi_last_calls.restype = C.c_uint32
     L.dsb_multi_classify_batch.argtypes = [C.c_void_p, C.POINTER(DsbRead), C.c_size_t, C.POINTER(DsbResult)]
     L.dsb_shard_plan.argtypes = [C.POINTER(C.c_uint32), C.c_size_t, C.c_int, C.c_uint64, C.c_uint32, C.POINTER(DsbChunk), C.c_size_t, C.POINTER(C.c_size_t)]
     L.dsb_ctx_use_synthetic_filter.argtypes = [C.c_void_p, C.c_uint64, C.c_double]
@@ -206,6 +208,10 @@ class Ctx:
 
     def reset_history(self):
         lib().dsb_ctx_reset_history(self.h)
+
+    def reload_env(self):
+        """the DSB_* switches are read once, when the ctx is made: read them again (tests that change them on a living ctx)"""
+        lib().dsb_ctx_reload_env(self.h)
 
     def set_history(self, max_len_before):
         lib().dsb_ctx_set_history(self.h, max_len_before)
@@ -321,6 +327,10 @@ class Multi:
 
     def reset_history(self):
         lib().dsb_multi_reset_history(self.h)
+
+    def last_calls(self):
+        """dsb_classify_batch calls each context made in the last classify()"""
+        return [int(lib().dsb_multi_last_calls(self.h, i)) for i in range(int(lib().dsb_multi_n(self.h)))]
 
     def classify(self, reads, strict=True):
         res = DsbResult()

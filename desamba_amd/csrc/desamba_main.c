@@ -109,7 +109,7 @@ typedef dsb_rec_t rec_t;
 typedef struct {
 	double parse_s, wait_free_s, wait_text_s; size_t bytes, waves, waves_parallel;          /* reader */
 	double fmt_s, write_s; size_t out_bytes;                                                 /* writer */
-	double up_s[MAX_CTX], run_s[MAX_CTX], fetch_s[MAX_CTX], idle_s[MAX_CTX]; long batches[MAX_CTX];   /* device workers */
+	double up_s[MAX_CTX], run_s[MAX_CTX], fetch_s[MAX_CTX], idle_s[MAX_CTX], up_bytes[MAX_CTX], bases[MAX_CTX]; long batches[MAX_CTX];   /* device workers */
 	double inflate_s; size_t inflate_out;                                                    /* inflaters (summed over their threads) */
 } trace_t;
 
@@ -742,7 +742,7 @@ static void *gpu_main(void *arg)
 				dsb_timing tm; memset(&tm, 0, sizeof tm); dsb_batch_timing(ctx, &tm);
 				fprintf(stderr, "[gpu %d] batch %ld: %zu reads, parsed at %.3f s, upload %.3f - %.3f s, run (turn + kernels) until %.3f s of which kernels %.3f s, fetched at %.3f s\n", g->k, b->seqno, b->n,
 				        b->t_parsed - a->t0, t0 - a->t0, t1 - a->t0, t2 - a->t0, tm.total_ms / 1e3, t3 - a->t0);
-				a->tr.up_s[g->k] += t1 - t0; a->tr.run_s[g->k] += t2 - t1; a->tr.fetch_s[g->k] += t3 - t2; a->tr.idle_s[g->k] += t0 - t_idle; a->tr.batches[g->k]++;
+				a->tr.up_s[g->k] += t1 - t0; a->tr.up_bytes[g->k] += (double)tm.upload_bytes; a->tr.bases[g->k] += (double)tm.bases; a->tr.run_s[g->k] += t2 - t1; a->tr.fetch_s[g->k] += t3 - t2; a->tr.idle_s[g->k] += t0 - t_idle; a->tr.batches[g->k]++;
 			}
 			if (rc && rc != DSB_ECAP) { fprintf(stderr, "[dsb_classify_batch] %s\n", dsb_strerror(rc)); exit(1); }
 			if (b->n > b->cap_rr) { b->cap_rr = b->n * 2; b->rr = xrealloc(b->rr, b->cap_rr * sizeof *b->rr); }
@@ -876,7 +876,8 @@ static void trace_summary(const app_t *a, double sec)
 	if (t->inflate_out) fprintf(stderr, "[trace] inflate: %.2f GB of text, %.3f s of inflater time (%d threads per BGZF file, %s)\n", t->inflate_out / 1e9, t->inflate_s, a->n_inflate, ld_alloc ? "libdeflate" : "zlib");
 	fprintf(stderr, "[trace] writer: %.3f GB written, formatting %.3f s = %.2f GB/s while it runs (%d threads), fwrite %.3f s\n", t->out_bytes / 1e9, t->fmt_s, t->fmt_s > 0 ? t->out_bytes / 1e9 / t->fmt_s : 0.0, a->n_format, t->write_s);
 	for (int k = 0; k < a->n_ctx; k++)
-		fprintf(stderr, "[trace] worker %d: %ld batches, upload %.3f s, kernels (incl. waiting for the device's turn) %.3f s, fetch %.3f s, idle %.3f s of %.3f s: busy %.0f %%\n", k, t->batches[k], t->up_s[k],
+		fprintf(stderr, "[trace] worker %d: %ld batches, upload %.3f s (%.3f GB for %.3f Gbases: %.3f bytes per base), kernels (incl. waiting for the device's turn) %.3f s, fetch %.3f s, idle %.3f s of %.3f s: busy %.0f %%\n", k, t->batches[k], t->up_s[k],
+		        t->up_bytes[k] / 1e9, t->bases[k] / 1e9, t->up_bytes[k] / (t->bases[k] > 0 ? t->bases[k] : 1),
 		        t->run_s[k], t->fetch_s[k], t->idle_s[k], sec, 100.0 * (t->up_s[k] + t->run_s[k] + t->fetch_s[k]) / (sec > 0 ? sec : 1));
 }
 

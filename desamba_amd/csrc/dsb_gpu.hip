@@ -13,6 +13,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <vector>
+#include <string>
 #include <unistd.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -71,6 +72,30 @@ __global__ void __launch_bounds__(256) k_encode_bytes(const DsbReadDesc *rd, con
 	}
 	for (uint32_t i = body + threadIdx.x; i < L; i += 256) {
 		uint32_t c = d_code((uint8_t)s[i]);
+		F[i] = (uint8_t)c; R[L - 1 - i] = (uint8_t)(3u - c);
+	}
+}
+// The same from sequences the host has packed to 2 bits per base (dsb_batch_upload's gather: 4 bases per byte, first base in the top
+// bits, CLY_Bit codes, every read starting at a byte): a quarter of the pinned writes, of the transfer and of this kernel's reads.
+// 16 bases per thread and step: one 4-byte load, two 8-byte stores per strand.
+__global__ void __launch_bounds__(256) k_encode_bytes_pk(const DsbReadDesc *rd, const uint8_t *packed, uint8_t *bin)
+{
+	DsbReadDesc d = rd[blockIdx.x];
+	const uint8_t *s = packed + d.seq_off;
+	uint8_t *base = bin + d.bin_off, *F = base + DSB_QPAD_L, *R = F + d.len;
+	const uint32_t L = d.len, body = L & ~7u;
+	if (threadIdx.x < DSB_QPAD_L) base[threadIdx.x] = 0;
+	if (threadIdx.x < DSB_QPAD_R) R[L + threadIdx.x] = DSB_QPAD_R_VAL;
+	for (uint32_t i = 8u * threadIdx.x; i < body; i += 2048u) {
+		const uint32_t w = (uint32_t)s[i >> 2] << 8 | s[(i >> 2) + 1];            // 8 bases, the first in the top bits
+		uint64_t f = 0;
+#pragma unroll
+		for (int k = 0; k < 8; k++) f |= (uint64_t)((w >> (14 - 2 * k)) & 3u) << (8 * k);
+		*reinterpret_cast<dsb_u64_any *>(F + i) = f;
+		*reinterpret_cast<dsb_u64_any *>(R + (L - 8u - i)) = __builtin_bswap64(0x0303030303030303ULL - f);
+	}
+	for (uint32_t i = body + threadIdx.x; i < L; i += 256) {
+		const uint32_t c = (s[i >> 2] >> (6 - 2 * (i & 3u))) & 3u;
 		F[i] = (uint8_t)c; R[L - 1 - i] = (uint8_t)(3u - c);
 	}
 }
@@ -405,137 +430,144 @@ struct DsbSlotArena {
 	uint32_t anc_cap, hit_cap;                    // entries of the anchor / chain arrays
 };
 
-// One kernel body, two instantiations.  Work items come from an atomic counter; with `list` == nullptr
-// item k is read k, otherwise read list[k] (the longest-processing-time-first order of k_order).
+// Work items come from an atomic counter; with `list` == nullptr item k is read k, otherwise read list[k] (the
+// longest-processing-time-first order of k_order).
 #ifndef DSB_WAVES_PER_EU
 #define DSB_WAVES_PER_EU 3      /* LDS (12.6 KB per wave) admits 12 waves per CU: 168 VGPRs cost no occupancy */
 #endif
-#define DSB_DEFINE_CLASSIFY(KNAME, NS, THREADS)                                                                         \
-__global__ void __launch_bounds__(THREADS, DSB_WAVES_PER_EU) KNAME(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,   \
-        const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout,  \
-        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg, uint32_t item_base, uint32_t slot_base, unsigned long long *work_cnt, DsbSeed *seed_blob, const DsbSeedInfo *sinfo, const uint64_t *pk, uint32_t group_mode)  \
-{                                                                                                                       \
-	const int lane = threadIdx.x;                                                                                       \
-	const uint32_t slot_id = slot_base + blockIdx.x;            /* arena slot (and debug row) of this wave */          \
-	uint8_t *slot = ar.base + (size_t)slot_id * ar.stride;                                                              \
-	/* The index descriptor is read on every rank query: keep it in LDS.  (A pointer to the kernel-argument segment   \
-	   would turn each x->field into a vector load from host-coherent memory.) */                                       \
-	__shared__ DsbDevIndex sx;                                                                                          \
-	__shared__ uint4 lds_ring[DSB_RING];                                                                                \
-	__shared__ __attribute__((aligned(16))) uint32_t lds_wtab[DSB_WTAB_SLOTS];                                                                       \
-	__shared__ uint32_t lds_red[THREADS / 64 + 1];                                                                      \
-	__shared__ unsigned int s_word;                                                                                     \
-	__shared__ uint32_t lds_cnt[4];                                                                                     \
-	__shared__ dsb_g64::DpBatch lds_dpb;                                                                                \
-	if (lane < 4) lds_cnt[lane] = 0;                                                                                    \
-	if (lane == 0) sx = x;                                                                                              \
-	__syncthreads();                                                                                                    \
-	__shared__ NS::WCtx s_w;                  /* the context of the read: wave-uniform, in LDS (dsb_classify_dev.h) */   \
-	NS::WCtxL &w = *(NS::WCtxL *)&s_w;                                                                                  \
-	w.ring = lds_ring; w.dpb = (NS::DpBatchL *)&lds_dpb; w.red = lds_red; w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1;                                                                               \
-	w.x = (NS::DsbXP)&sx; w.dbg = dbg ? dbg + 4 * slot_id : nullptr;                                             \
-	for (int i = 0; i < 14; i++) w.tacc[i] = 0;                                                                         \
-	for (int i = 0; i < 10; i++) w.tx[i] = 0;                                                                           \
-	w.seeds = (DsbSeed *)(slot + ar.off_seeds);                                                                         \
-	w.anc = (DsbAnchor *)(slot + ar.off_anc); w.anc_tmp = (DsbAnchor *)(slot + ar.off_anc_tmp);                         \
-	w.hit = (DsbChain *)(slot + ar.off_hit); w.hit_tmp = (DsbChain *)(slot + ar.off_hit_tmp);                           \
-	w.sms = (DsbSms *)(slot + ar.off_sms);                                                                              \
-	w.sc = (DsbScHash *)(slot + ar.off_sc); w.wtab = lds_wtab;                                                          \
-	w.mem_slow = (DsbMem *)(slot + ar.off_mem);                                                                         \
-	w.spset = (uint64_t *)(slot + ar.off_spset);                                                                        \
-	w.score_v = (int *)(slot + ar.off_scorev);                                                                          \
-	w.sortkey = (uint64_t *)(slot + ar.off_sortkey); w.sortidx = (uint32_t *)(slot + ar.off_sortidx);                   \
-	w.win_mid = slot + ar.off_win; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;         \
-	w.lane_anc = (DsbAnchor *)(slot + ar.off_lane_anc); w.lane_spset = (uint64_t *)(slot + ar.off_lane_sp);             \
-	w.top_idx = (uint32_t *)(slot + ar.off_top); w.round_info = (uint32_t *)(slot + ar.off_round);                      \
-	w.anc_cap = ar.anc_cap; w.anc_cap_main = ar.anc_cap; w.hit_cap = ar.hit_cap; w.step_limit = x.step_limit; w.heavy_limit = x.heavy_limit; w.sp_gen = 0; w.mw = nullptr; w.n_waves = 1;                                                                            \
-	/* visited-row sets are generation-tagged: clear them once per launch */                                          \
-	for (uint32_t i = lane; i < (uint32_t)THREADS * DSB_SPHASH; i += THREADS) w.lane_spset[i] = 0;                       \
-	for (uint32_t i = lane; i < DSB_SPHASH; i += THREADS) w.spset[i] = 0;                                                \
-	__syncthreads();                                                                                                    \
-	const unsigned int n_items = n_ptr ? *n_ptr : n_fixed;                                                              \
-	if (w.dbg && lane == 0) w.dbg[0] = 300;                                                                             \
-	/* group_mode (short reads with seed lists from k_seed_scan): a work item is 64 reads -- the anchor stage of one read per  \
-	   lane (fast_classify_lane), then the reads one after the other on the whole wavefront from those anchors; a read     \
-	   whose anchors outgrew its lane scratch is done afterwards the usual way (pass 1) */                                  \
-	/* The first group_mode reads of the launch (the heaviest by the order) still go one by one: 64 of them in a row on one \
-	   wavefront would outlast the rest of the launch.  Groups are 64 consecutive positions of the order (similar reads    \
-	   keep the lanes of the anchor stage together). */                                                                    \
-	for (;;) {                                                                                                          \
-		unsigned int n_grp = 1u;                                                                                        \
-		if (group_mode && seed_blob) n_grp = __hip_atomic_load(work_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= group_mode ? 64u : 1u; \
-		n_grp = (unsigned int)__builtin_amdgcn_readfirstlane((int)n_grp);                                               \
-		if (lane == 0) s_word = atomicAdd(work_counter, n_grp);                                                         \
-		__syncthreads();                                                                                                \
-		unsigned int k = s_word + item_base;                                                                            \
-		__syncthreads();                                                                                                \
-		if (k >= n_items) {   /* every group reaches this: the grid always drains */                                   \
-			if (lane < 4 && lds_cnt[lane]) atomicAdd(work_cnt + lane, (unsigned long long)lds_cnt[lane]);               \
-			if (w.dbg && lane == 0) { w.dbg[0] = 999; for (int i = 0; i < 14; i++) dbg[4 * 65536 + 14 * slot_id + i] += (uint32_t)(w.tacc[i] / 100); for (int i = 0; i < 10; i++) dbg[8 * 65536 + 10 * slot_id + i] += (uint32_t)(i < 6 ? w.tx[i] / 100 : w.tx[i]); } \
-			break;                                                                                                      \
-		}                                                                                                               \
-		uint32_t g_nanc = 0, g_ovf = 0;                                                                                 \
-		if (n_grp > 1) {                                                                                                \
-			const bool valid = k + lane < n_items;                                                                      \
-			const unsigned int rl = valid ? (list ? list[k + lane] : k + lane) : 0u;                                    \
-			const DsbReadDesc dl = rd[rl];                                                                              \
-			uint64_t tg = w.dbg ? wall_clock64() : 0;                                                                   \
-			NS::fast_classify_lane(w, valid, bin + dl.bin_off + DSB_QPAD_L, dl.len, seed_blob + dl.seed_off, sinfo + rl, &g_nanc, &g_ovf); \
-			if (w.dbg) w.tacc[1] += wall_clock64() - tg;                                                                \
-		}                                                                                                               \
-		for (unsigned int pass = 0; pass < (n_grp > 1 ? 2u : 1u); pass++)                                               \
-		for (unsigned int gl = 0; gl < n_grp; gl++) {                                                                   \
-			const unsigned int pos = k + gl;                                                                            \
-			if (pos >= n_items) break;                                                                                  \
-			bool have_anc = false;                                                                                      \
-			if (n_grp > 1) {                                                                                            \
-				const uint32_t ovf_l = NS::dsb_shfl(g_ovf, (int)gl);                                                    \
-				if ((ovf_l != 0) != (pass == 1)) continue;                                                              \
-				have_anc = !ovf_l;                                                                                      \
-			}                                                                                                           \
-		unsigned int r = list ? list[pos] : pos;                                                                        \
-		DsbReadDesc d = rd[r];                                                                                          \
-		uint64_t t_start = wall_clock64();                                                                              \
-		uint64_t tacc0[14]; if (w.dbg) for (int i = 0; i < 14; i++) tacc0[i] = w.tacc[i];                               \
-		if (w.dbg && lane == 0) { w.dbg[2] = r; w.dbg[0] = 100; }                                                       \
-		w.bin = bin + d.bin_off + DSB_QPAD_L; w.L = d.len; w.status = 0; w.max_read_l = d.hist_max;                     \
-		w.pre_seeds = seed_blob ? seed_blob + d.seed_off : nullptr; w.pre_info = sinfo + r;                             \
-		w.pk[0] = pk + d.pk_off; w.pk[1] = w.pk[0] + ((d.len + 31) / 32 + 1);                                           \
-		if (have_anc) {   /* the anchors lane gl made for this read */                                                  \
-			const uint32_t na = NS::dsb_shfl(g_nanc, (int)gl);                                                          \
-			const DsbAnchor *src = w.lane_anc + (size_t)gl * DSB_LANE_ANC_CAP;                                          \
-			for (uint32_t i = lane; i < na; i += 64) w.anc[i] = src[i];                                                 \
-			w.n_anc = na;                                                                                               \
-			NS::wave_sync();                                                                                            \
-		}                                                                                                               \
-		uint32_t fast = NS::template classify_read<false>(w, bits + d.bit_off, bits + d.bit_off + d.n_words, have_anc);                 \
-		if (w.boosted) __builtin_amdgcn_s_setprio(0);                                                                   \
-		/* publish the hits of this read (none if it is handed over to k_classify_heavy) */                            \
-		if (w.status & DSB_ST_HEAVY) w.n_hit = 0;                                                                       \
-		if (lane == 0) s_word = w.n_hit ? atomicAdd(hout_counter, w.n_hit) : 0u;                                        \
-		__syncthreads();                                                                                                \
-		unsigned int first = s_word;                                                                                    \
-		__syncthreads();                                                                                                \
-		uint32_t n_out = w.n_hit;                                                                                       \
-		if (first + n_out > hout_cap) { w.status |= DSB_ST_OUT_OVF; n_out = 0; }                                        \
-		for (uint32_t i = lane; i < n_out; i += THREADS) {                                                              \
-			DsbChain h = w.hit[i]; DsbHitOut o;                                                                         \
-			o.ref_ID = h.ref_ID; o.t_st = h.t_st; o.t_ed = h.t_ed; o.q_st = h.q_st; o.q_ed = h.q_ed; o.sum_score = h.sum_score; o.indel = h.indel; \
-			o.direction = h.direction; o.primary = h.primary; o.pri_index = h.pri_index; o.pad = 0;                     \
-			hout[first + i] = o;                                                                                        \
-		}                                                                                                               \
-		if (w.dbg && lane == 0) { w.dbg[0] = 200; if (r < 65536u) for (int i = 0; i < 14; i++) dbg[16 * 65536 + 14 * r + i] = (uint32_t)((w.tacc[i] - tacc0[i]) / 100); } \
-		if (lane == 0) { DsbReadOut ro; ro.first = first; ro.n = n_out; ro.status = w.status | (w.status ? (w.stage << 8) : 0); \
-			ro.fast = fast | ((uint32_t)((wall_clock64() - t_start) / 100) << 1); ro.n_anc = w.n_anc; ro.pad = 0; rout[r] = ro; }                       \
-		}                                                                                                               \
-	}                                                                                                                   \
+// One kernel body for the three launches of a batch (main, early, second run): a device function, instantiated by three thin kernels
+// so that profiles list the launches apart.  One wavefront per workgroup.
+__device__ __forceinline__ void classify_kernel_body(const DsbDevIndex &x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,
+        const uint32_t *list, uint8_t *bin, const uint64_t *bits, const DsbSlotArena &ar, unsigned int *work_counter, DsbReadOut *rout,
+        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg, uint32_t item_base, uint32_t slot_base, unsigned long long *work_cnt, DsbSeed *seed_blob, const DsbSeedInfo *sinfo, const uint64_t *pk, uint32_t group_mode)
+{
+	const int lane = threadIdx.x;
+	const uint32_t slot_id = slot_base + blockIdx.x;            /* arena slot (and debug row) of this wave */
+	uint8_t *slot = ar.base + (size_t)slot_id * ar.stride;
+	/* The index descriptor is read on every rank query: keep it in LDS.  (A pointer to the kernel-argument segment
+	   would turn each x->field into a vector load from host-coherent memory.) */
+	__shared__ DsbDevIndex sx;
+	__shared__ uint4 lds_ring[DSB_RING];
+	__shared__ __attribute__((aligned(16))) uint32_t lds_wtab[DSB_WTAB_SLOTS];
+	__shared__ uint32_t lds_red[2];
+	__shared__ unsigned int s_word;
+	__shared__ uint32_t lds_cnt[4];
+	__shared__ dsb_g64::DpBatch lds_dpb;
+	if (lane < 4) lds_cnt[lane] = 0;
+	if (lane == 0) sx = x;
+	__syncthreads();
+	__shared__ dsb_g64::WCtx s_w;                  /* the context of the read: wave-uniform, in LDS (dsb_classify_dev.h) */
+	dsb_g64::WCtxL &w = *(dsb_g64::WCtxL *)&s_w;
+	w.ring = lds_ring; w.dpb = (dsb_g64::DpBatchL *)&lds_dpb; w.red = lds_red; w.k.c = (dsb_g64::lds_u32 *)lds_cnt; w.k.uni = 1;
+	w.x = (dsb_g64::DsbXP)&sx; w.dbg = dbg ? dbg + 4 * slot_id : nullptr;
+	for (int i = 0; i < 14; i++) w.tacc[i] = 0;
+	for (int i = 0; i < 10; i++) w.tx[i] = 0;
+	w.seeds = (DsbSeed *)(slot + ar.off_seeds);
+	w.anc = (DsbAnchor *)(slot + ar.off_anc); w.anc_tmp = (DsbAnchor *)(slot + ar.off_anc_tmp);
+	w.hit = (DsbChain *)(slot + ar.off_hit); w.hit_tmp = (DsbChain *)(slot + ar.off_hit_tmp);
+	w.sms = (DsbSms *)(slot + ar.off_sms);
+	w.sc = (DsbScHash *)(slot + ar.off_sc); w.wtab = lds_wtab;
+	w.mem_slow = (DsbMem *)(slot + ar.off_mem);
+	w.spset = (uint64_t *)(slot + ar.off_spset);
+	w.score_v = (int *)(slot + ar.off_scorev);
+	w.sortkey = (uint64_t *)(slot + ar.off_sortkey); w.sortidx = (uint32_t *)(slot + ar.off_sortidx);
+	w.win_mid = slot + ar.off_win; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
+	w.lane_anc = (DsbAnchor *)(slot + ar.off_lane_anc); w.lane_spset = (uint64_t *)(slot + ar.off_lane_sp);
+	w.top_idx = (uint32_t *)(slot + ar.off_top); w.round_info = (uint32_t *)(slot + ar.off_round);
+	w.anc_cap = ar.anc_cap; w.anc_cap_main = ar.anc_cap; w.hit_cap = ar.hit_cap; w.step_limit = x.step_limit; w.heavy_limit = x.heavy_limit; w.sp_gen = 0; w.mw = nullptr; w.n_waves = 1;
+	/* visited-row sets are generation-tagged: clear them once per launch */
+	for (uint32_t i = lane; i < 64u * DSB_SPHASH; i += 64) w.lane_spset[i] = 0;
+	for (uint32_t i = lane; i < DSB_SPHASH; i += 64) w.spset[i] = 0;
+	__syncthreads();
+	const unsigned int n_items = n_ptr ? *n_ptr : n_fixed;
+	if (w.dbg && lane == 0) w.dbg[0] = 300;
+	/* group_mode (short reads with seed lists from k_seed_scan): a work item is 64 reads -- the anchor stage of one read per
+	   lane (fast_classify_lane), then the reads one after the other on the whole wavefront from those anchors; a read
+	   whose anchors outgrew its lane scratch is done afterwards the usual way (pass 1) */
+	/* The first group_mode reads of the launch (the heaviest by the order) still go one by one: 64 of them in a row on one
+	   wavefront would outlast the rest of the launch.  Groups are 64 consecutive positions of the order (similar reads
+	   keep the lanes of the anchor stage together). */
+	for (;;) {
+		unsigned int n_grp = 1u;
+		if (group_mode && seed_blob) n_grp = __hip_atomic_load(work_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= group_mode ? 64u : 1u;
+		n_grp = (unsigned int)__builtin_amdgcn_readfirstlane((int)n_grp);
+		if (lane == 0) s_word = atomicAdd(work_counter, n_grp);
+		__syncthreads();
+		unsigned int k = s_word + item_base;
+		__syncthreads();
+		if (k >= n_items) {   /* every group reaches this: the grid always drains */
+			if (lane < 4 && lds_cnt[lane]) atomicAdd(work_cnt + lane, (unsigned long long)lds_cnt[lane]);
+			if (w.dbg && lane == 0) { w.dbg[0] = 999; for (int i = 0; i < 14; i++) dbg[4 * 65536 + 14 * slot_id + i] += (uint32_t)(w.tacc[i] / 100); for (int i = 0; i < 10; i++) dbg[8 * 65536 + 10 * slot_id + i] += (uint32_t)(i < 6 ? w.tx[i] / 100 : w.tx[i]); }
+			break;
+		}
+		uint32_t g_nanc = 0, g_ovf = 0;
+		if (n_grp > 1) {
+			const bool valid = k + lane < n_items;
+			const unsigned int rl = valid ? (list ? list[k + lane] : k + lane) : 0u;
+			const DsbReadDesc dl = rd[rl];
+			uint64_t tg = w.dbg ? wall_clock64() : 0;
+			dsb_g64::fast_classify_lane(w, valid, bin + dl.bin_off + DSB_QPAD_L, dl.len, seed_blob + dl.seed_off, sinfo + rl, &g_nanc, &g_ovf);
+			if (w.dbg) w.tacc[1] += wall_clock64() - tg;
+		}
+		for (unsigned int pass = 0; pass < (n_grp > 1 ? 2u : 1u); pass++)
+		for (unsigned int gl = 0; gl < n_grp; gl++) {
+			const unsigned int pos = k + gl;
+			if (pos >= n_items) break;
+			bool have_anc = false;
+			if (n_grp > 1) {
+				const uint32_t ovf_l = dsb_g64::dsb_shfl(g_ovf, (int)gl);
+				if ((ovf_l != 0) != (pass == 1)) continue;
+				have_anc = !ovf_l;
+			}
+		unsigned int r = list ? list[pos] : pos;
+		DsbReadDesc d = rd[r];
+		uint64_t t_start = wall_clock64();
+		uint64_t tacc0[14]; if (w.dbg) for (int i = 0; i < 14; i++) tacc0[i] = w.tacc[i];
+		if (w.dbg && lane == 0) { w.dbg[2] = r; w.dbg[0] = 100; }
+		w.bin = bin + d.bin_off + DSB_QPAD_L; w.L = d.len; w.status = 0; w.max_read_l = d.hist_max;
+		w.pre_seeds = seed_blob ? seed_blob + d.seed_off : nullptr; w.pre_info = sinfo + r;
+		w.pk[0] = pk + d.pk_off; w.pk[1] = w.pk[0] + ((d.len + 31) / 32 + 1);
+		if (have_anc) {   /* the anchors lane gl made for this read */
+			const uint32_t na = dsb_g64::dsb_shfl(g_nanc, (int)gl);
+			const DsbAnchor *src = w.lane_anc + (size_t)gl * DSB_LANE_ANC_CAP;
+			for (uint32_t i = lane; i < na; i += 64) w.anc[i] = src[i];
+			w.n_anc = na;
+			dsb_g64::wave_sync();
+		}
+		uint32_t fast = dsb_g64::classify_read<false>(w, bits + d.bit_off, bits + d.bit_off + d.n_words, have_anc);
+		if (w.boosted) __builtin_amdgcn_s_setprio(0);
+		/* publish the hits of this read (none if it is handed over to k_classify_heavy) */
+		if (w.status & DSB_ST_HEAVY) w.n_hit = 0;
+		if (lane == 0) s_word = w.n_hit ? atomicAdd(hout_counter, w.n_hit) : 0u;
+		__syncthreads();
+		unsigned int first = s_word;
+		__syncthreads();
+		uint32_t n_out = w.n_hit;
+		if (first + n_out > hout_cap) { w.status |= DSB_ST_OUT_OVF; n_out = 0; }
+		for (uint32_t i = lane; i < n_out; i += 64) {
+			DsbChain h = w.hit[i]; DsbHitOut o;
+			o.ref_ID = h.ref_ID; o.t_st = h.t_st; o.t_ed = h.t_ed; o.q_st = h.q_st; o.q_ed = h.q_ed; o.sum_score = h.sum_score; o.indel = h.indel;
+			o.direction = h.direction; o.primary = h.primary; o.pri_index = h.pri_index; o.pad = 0;
+			hout[first + i] = o;
+		}
+		if (w.dbg && lane == 0) { w.dbg[0] = 200; if (r < 65536u) for (int i = 0; i < 14; i++) dbg[16 * 65536 + 14 * r + i] = (uint32_t)((w.tacc[i] - tacc0[i]) / 100); }
+		if (lane == 0) { DsbReadOut ro; ro.first = first; ro.n = n_out; ro.status = w.status | (w.status ? (w.stage << 8) : 0);
+			ro.fast = fast | ((uint32_t)((wall_clock64() - t_start) / 100) << 1); ro.n_anc = w.n_anc; ro.pad = 0; rout[r] = ro; }
+		}
+	}
 }
 
-DSB_DEFINE_CLASSIFY(k_classify, dsb_g64, 64)
-// the same kernel under a second name for the early launch of the heaviest reads, so that profiles list the two apart
-DSB_DEFINE_CLASSIFY(k_classify_early, dsb_g64, 64)
+
+#define DSB_CLASSIFY_ARGS DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr, const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, \
+        unsigned int *work_counter, DsbReadOut *rout, DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg, uint32_t item_base, uint32_t slot_base, unsigned long long *work_cnt, \
+        DsbSeed *seed_blob, const DsbSeedInfo *sinfo, const uint64_t *pk, uint32_t group_mode
+#define DSB_CLASSIFY_PASS x, rd, n_fixed, n_ptr, list, bin, bits, ar, work_counter, rout, hout, hout_counter, hout_cap, dbg, item_base, slot_base, work_cnt, seed_blob, sinfo, pk, group_mode
+__global__ void __launch_bounds__(64, DSB_WAVES_PER_EU) k_classify(DSB_CLASSIFY_ARGS) { classify_kernel_body(DSB_CLASSIFY_PASS); }
+// the same under a second name for the early launch of the heaviest reads, so that profiles list the two apart
+__global__ void __launch_bounds__(64, DSB_WAVES_PER_EU) k_classify_early(DSB_CLASSIFY_ARGS) { classify_kernel_body(DSB_CLASSIFY_PASS); }
 // ... and a third one for the second run of reads whose match-node arena overflowed (usually an empty launch)
-DSB_DEFINE_CLASSIFY(k_classify_second, dsb_g64, 64)
+__global__ void __launch_bounds__(64, DSB_WAVES_PER_EU) k_classify_second(DSB_CLASSIFY_ARGS) { classify_kernel_body(DSB_CLASSIFY_PASS); }
+
 
 
 // Several wavefronts per read, for the handful of reads whose sparse DP is the batch's tail (tandem repeats: tens of
@@ -754,12 +786,46 @@ struct InSlot {
 	size_t n_reads = 0; uint64_t n_words_total = 0, total_bases = 0, total_windows = 0, seed_entries = 0; uint32_t max_len = 0, min_len = 0;
 	uint32_t *d_scan_order = nullptr; size_t cap_scan_order = 0;   // reads longest first (ragged batches only), for k_seed_scan
 	bool ragged = false;
+	uint64_t upload_bytes = 0;     // what the sequences of this batch took over PCIe
+	bool packed = false;           // d_ascii holds 2-bit packed sequences (dsb_batch_upload's gather), not text
 };
 
 // pinned staging of dsb_batch_upload: one per gather thread, two chunks each (one is filled while the other is on its way)
 struct UpStage { char *buf[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; bool used[2] = {false, false}; hipStream_t st = nullptr; };
 
+// Diagnostic and tuning switches of the environment, read ONCE per context (dsb_ctx_create; dsb_ctx_reload_env for tests that
+// change them on a living context): nothing on the per-batch path calls getenv.  -1 / 0 = not set.
+struct DsbKnobs {
+	bool upload_text = false;          // DSB_UPLOAD_TEXT: dsb_batch_upload gathers the sequences as text (round 3's form) instead of packing them
+	bool debug = false, upload_trace = false, no_turn = false, turn_whole_run = false, no_group = false, heavy_first_set = false;
+	long hout_cap = 0, sms_cap = 0, anc_cap_rt = 0, upload_chunk_kb = 0, step_limit_rt = 0, group_head = -1;
+	int upload_threads = 0, seed_scan = -1, heavy_mw = -1, heavy_first = 0;
+	bool heavy_preds_set = false; uint32_t heavy_preds = 0;
+	std::string order_file;
+};
+static bool g_upload_trace = false;           // (the buffer helpers below have no context at hand: DSB_UPLOAD_TRACE of the last knobs_read)
+static void knobs_read(DsbKnobs &k)
+{
+	auto num = [](const char *name, long dflt) { const char *e = getenv(name); return e ? atol(e) : dflt; };
+	k = DsbKnobs();
+	k.debug = getenv("DSB_DEBUG") != nullptr; k.upload_trace = getenv("DSB_UPLOAD_TRACE") != nullptr;
+	k.upload_text = getenv("DSB_UPLOAD_TEXT") != nullptr;
+	k.no_turn = getenv("DSB_NO_TURN") != nullptr; k.turn_whole_run = getenv("DSB_TURN_WHOLE_RUN") != nullptr; k.no_group = getenv("DSB_NO_GROUP") != nullptr;
+	k.hout_cap = num("DSB_HOUT_CAP", 0); if (getenv("DSB_HOUT_CAP") && k.hout_cap <= 0) k.hout_cap = 1;
+	k.sms_cap = num("DSB_SMS_CAP", 0); if (getenv("DSB_SMS_CAP") && k.sms_cap < 64) k.sms_cap = 64;
+	k.anc_cap_rt = num("DSB_ANC_CAP_RT", 0); if (getenv("DSB_ANC_CAP_RT")) { if (k.anc_cap_rt < 64) k.anc_cap_rt = 64; if (k.anc_cap_rt > DSB_ANC_CAP) k.anc_cap_rt = DSB_ANC_CAP; }
+	k.upload_chunk_kb = num("DSB_UPLOAD_CHUNK_KB", 0); k.upload_threads = (int)num("DSB_UPLOAD_THREADS", 0);
+	k.step_limit_rt = num("DSB_STEP_LIMIT_RT", 0); k.group_head = num("DSB_GROUP_HEAD", -1);
+	k.seed_scan = getenv("DSB_SEED_SCAN") ? (num("DSB_SEED_SCAN", 0) != 0 ? 1 : 0) : -1;
+	k.heavy_mw = getenv("DSB_HEAVY_MW") ? (int)num("DSB_HEAVY_MW", 0) : -1;
+	k.heavy_first_set = getenv("DSB_HEAVY_FIRST") != nullptr; k.heavy_first = (int)num("DSB_HEAVY_FIRST", 0);
+	if (const char *e = getenv("DSB_HEAVY_PREDS")) { k.heavy_preds_set = true; k.heavy_preds = (uint32_t)strtoul(e, nullptr, 10); }
+	if (const char *e = getenv("DSB_ORDER_FILE")) k.order_file = e;
+	g_upload_trace = k.upload_trace;
+}
+
 struct dsb_ctx {
+	DsbKnobs knobs;
 	dsb_index *idx = nullptr; int device = 0; hipStream_t stream = nullptr;
 	DsbStaged *staged = nullptr; DsbDevIndex dx;
 	std::vector<InSlot> in; int cur = 0;          // input slots (dsb_ctx_select_slot); upload / run / fetch work on slot `cur`
@@ -809,7 +875,15 @@ template <class T> static int grow(T **p, size_t *cap, size_t need);
 struct SeqView { const char *p; uint32_t len; };
 static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *ext_text = nullptr, size_t ext_len = 0, const uint64_t *ext_off = nullptr);
 static int upload_stages(dsb_ctx *c, int T);
-static int upload_threads(void);
+static int upload_threads(const dsb_ctx *c);
+
+// reads the DSB_* switches of the environment again (they are read once, when the context is made): for tests and experiments that
+// change them on a living context.  The debug buffers (DSB_DEBUG) exist only if the variable was set when the context was made.
+extern "C" void dsb_ctx_reload_env(dsb_ctx *c)
+{
+	if (!c) return;
+	knobs_read(c->knobs);                                      // (the pinned upload chunks keep the size they were made with)
+}
 
 extern "C" void dsb_ctx_destroy(dsb_ctx *c)
 {
@@ -846,6 +920,7 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device_id));
 	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) { fprintf(stderr, "[desamba_amd] device %d is %s, kernels are built for gfx950 only\n", device_id, prop.gcnArchName); return DSB_ENODEV; }
 	dsb_ctx *c = new dsb_ctx();
+	knobs_read(c->knobs);
 	c->idx = idx; c->device = device_id;
 	if (opts) c->opts = *opts;
 	else { c->opts.L_min_matching = 170; c->opts.min_score = 64; c->opts.max_sec_N = 5; }
@@ -864,7 +939,7 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 		c->dx.filter_min_length = c->opts.L_min_matching; c->dx.filter_min_score = c->opts.min_score; c->dx.filter_min_score_LV3 = c->opts.min_score + 10;
 		if (hipMalloc((void **)&c->d_counters, 256) != hipSuccess) rc = DSB_ENOMEM;
 	}
-	if (rc == DSB_OK && getenv("DSB_DEBUG")) {
+	if (rc == DSB_OK && c->knobs.debug) {
 		CK(hipHostMalloc((void **)&c->dbg_host, 32 * 65536 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
 		if (rc == DSB_OK) { memset(c->dbg_host, 0, 32 * 65536 * sizeof(uint32_t)); CK(hipHostGetDevicePointer((void **)&c->dbg_dev, c->dbg_host, 0)); }
 	}
@@ -891,7 +966,7 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 		std::vector<char> seq(2048); uint64_t z = 88172645463325252ULL;
 		for (char &ch : seq) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; ch = "ACGT"[z & 3]; }
 		SeqView v[4]; for (int i = 0; i < 4; i++) { v[i].p = seq.data() + 100 * i; v[i].len = 1500; }
-		rc = upload_stages(c, upload_threads());
+		rc = upload_stages(c, upload_threads(c));
 		if (rc == DSB_OK) rc = upload_views(c, v, 4);
 		if (rc == DSB_OK) rc = dsb_batch_run(c);
 		c->hist_max = 0; c->in[c->cur].n_reads = 0; memset(&c->timing, 0, sizeof c->timing);
@@ -989,7 +1064,7 @@ template <class T> static int grow(T **p, size_t *cap, size_t need)
 	if (need <= *cap) return 0;
 	// (an allocation on the per-batch path: hipFree / hipMalloc wait for the device and were seen to stall a sibling context's
 	// batch for seconds -- the hints of dsb_ctx_create exist to keep this from happening; DSB_UPLOAD_TRACE shows each one)
-	const bool tr = getenv("DSB_UPLOAD_TRACE") != nullptr; struct timespec t0, t1; if (tr) clock_gettime(CLOCK_MONOTONIC, &t0);
+	const bool tr = g_upload_trace; struct timespec t0, t1; if (tr) clock_gettime(CLOCK_MONOTONIC, &t0);
 	const size_t old = *cap;
 	if (*p) hipFree(*p);
 	size_t n = need + need / 8 + 1024;
@@ -1044,7 +1119,7 @@ static int size_arena(DsbSlotArena &a, int *cur_slots, uint32_t max_len, int wan
 	const bool oversized = a.base && a.max_len > 4 * (uint64_t)max_len + 65536 && a.stride * ((size_t)*cur_slots + have_extra) > ((size_t)4 << 30);
 	if (fits && !oversized && (*cur_slots >= want_slots || a.max_len > max_len)) return 0;   // (fewer slots than wanted are kept if they were a budget decision for longer reads)
 	if (check_only) return 1;                      // would have to be built: the caller comes again with the memory budget
-	if (getenv("DSB_UPLOAD_TRACE")) fprintf(stderr, "[upload] an arena is (re)built: has max_len %u, %d + %d slots, sms_cap %u; wanted max_len %u, %d + %d slots, sms_cap %u%s\n", a.base ? a.max_len : 0u, *cur_slots, have_extra, a.base ? a.sms_cap : 0u, max_len, want_slots, extra_slots, sms_cap, oversized ? " (oversized)" : "");
+	if (g_upload_trace) fprintf(stderr, "[upload] an arena is (re)built: has max_len %u, %d + %d slots, sms_cap %u; wanted max_len %u, %d + %d slots, sms_cap %u%s\n", a.base ? a.max_len : 0u, *cur_slots, have_extra, a.base ? a.sms_cap : 0u, max_len, want_slots, extra_slots, sms_cap, oversized ? " (oversized)" : "");
 	if (a.base && !oversized && a.max_len > max_len) max_len = a.max_len;
 	if (a.base) { hipFree(a.base); a.base = nullptr; budget += a.stride * ((size_t)*cur_slots + have_extra); }
 	DsbSlotArena n = a;
@@ -1075,8 +1150,8 @@ static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_b
 	if ((rc = grow(&c->d_bits, &c->cap_bits, (size_t)bit_words + 8))) return rc;
 	if ((rc = grow(&c->d_rout, &c->cap_rout, n + 1))) return rc;
 	size_t want_hout = 16 * n + 4096;
-	if (const char *e = getenv("DSB_HOUT_CAP")) want_hout = (size_t)atol(e) > 0 ? (size_t)atol(e) : 1;   // diagnostics: a small hit buffer forces the regrow path
-	if (c->cap_hout < want_hout || getenv("DSB_HOUT_CAP")) {
+	if (c->knobs.hout_cap) want_hout = (size_t)c->knobs.hout_cap;   // diagnostics (DSB_HOUT_CAP): a small hit buffer forces the regrow path
+	if (c->cap_hout < want_hout || c->knobs.hout_cap) {
 		if (c->cap_hout != want_hout) { if (c->d_hout) hipFree(c->d_hout); c->d_hout = nullptr; c->cap_hout = 0; if (hipMalloc((void **)&c->d_hout, want_hout * sizeof(DsbHitOut)) != hipSuccess) return DSB_ENOMEM; c->cap_hout = want_hout; }
 	}
 	if ((rc = grow(&c->d_score, &c->cap_score, n + 1))) return rc;
@@ -1093,16 +1168,16 @@ static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_b
 	// ... and an arena that has to grow for a longer read grows by a quarter more than needed (the next longer read is coming)
 	if (c->arena.base && max_len > c->arena.max_len) { const uint64_t g = (uint64_t)max_len + max_len / 4; max_len = g > 0xfffffff0ull ? 0xfffffff0u : (uint32_t)g; }
 	uint32_t cap1 = dsb_sms_cap_for(max_len);
-	const bool cap_forced = getenv("DSB_SMS_CAP") != NULL;                      // diagnostics: a small arena forces second runs
-	if (cap_forced) { cap1 = (uint32_t)atol(getenv("DSB_SMS_CAP")); if (cap1 < 64) cap1 = 64; }
+	const bool cap_forced = c->knobs.sms_cap != 0;                              // diagnostics (DSB_SMS_CAP): a small arena forces second runs
+	if (cap_forced) cap1 = (uint32_t)c->knobs.sms_cap;
 	uint64_t cap2 = (uint64_t)cap1 * DSB_RETRY_GROW; if (cap2 > DSB_RETRY_MAX_NODES) cap2 = cap1 > DSB_RETRY_MAX_NODES ? cap1 : DSB_RETRY_MAX_NODES;
 	uint32_t anc1 = DSB_ANC_CAP;
-	if (const char *e = getenv("DSB_ANC_CAP_RT")) { anc1 = (uint32_t)atol(e); if (anc1 < 64) anc1 = 64; if (anc1 > DSB_ANC_CAP) anc1 = DSB_ANC_CAP; }   // diagnostics
+	if (c->knobs.anc_cap_rt) anc1 = (uint32_t)c->knobs.anc_cap_rt;   // diagnostics (DSB_ANC_CAP_RT)
 	// memory budget: what the device has free now, minus a reserve for the other buffers of this and a sibling context.  Asked for
 	// only when an arena has to be (re)built: the query goes to the driver and was seen to wait seconds behind a running kernel.
-	const bool exact = cap_forced || getenv("DSB_ANC_CAP_RT");
+	const bool exact = cap_forced || c->knobs.anc_cap_rt;
 	// the early launch of the heaviest reads (dsb_batch_run) exists for batches of >= 4096 reads: only those pay for its slots
-	int want_extra = (n >= 4096 || getenv("DSB_HEAVY_FIRST")) ? DSB_HEAVY_SLOTS : 0;
+	int want_extra = (n >= 4096 || c->knobs.heavy_first_set) ? DSB_HEAVY_SLOTS : 0;
 	if (want_extra < c->n_extra) want_extra = c->n_extra;
 	for (int pass = 0; pass < 2; pass++) {
 		size_t budget_big = 0, budget_main = 0;
@@ -1130,13 +1205,13 @@ static int ensure_buffers(dsb_ctx *c, size_t n, uint32_t max_len, uint64_t bin_b
 #include <time.h>
 static size_t upload_chunk(dsb_ctx *c)
 {
-	if (!c->up_chunk) { const char *e = getenv("DSB_UPLOAD_CHUNK_KB"); c->up_chunk = e && atol(e) > 0 ? (size_t)atol(e) << 10 : (size_t)8 << 20; }
+	if (!c->up_chunk) c->up_chunk = c->knobs.upload_chunk_kb > 0 ? (size_t)c->knobs.upload_chunk_kb << 10 : (size_t)8 << 20;
 	return c->up_chunk;
 }
-static int upload_threads(void)
+static int upload_threads(const dsb_ctx *c)
 {
 	int T = dsb_host_cpus() / 2; if (T > 16) T = 16;
-	if (const char *e = getenv("DSB_UPLOAD_THREADS")) T = atoi(e);
+	if (c->knobs.upload_threads) T = c->knobs.upload_threads;
 	return T < 1 ? 1 : T;
 }
 // the pinned chunks, events and stream of T gather threads (made once; dsb_ctx_create makes them ahead of the first batch when it has the hints)
@@ -1151,17 +1226,43 @@ static int upload_stages(dsb_ctx *c, int T)
 	}
 	return DSB_OK;
 }
+// 2-bit codes of two text bytes at a time (CLY_Bit, src/cly.c:17-35: anything that is not A / G / T is C): [b0 | b1 << 8] -> code(b0) << 2 | code(b1)
+static const uint8_t *pack_lut(void)
+{
+	static uint8_t *lut = nullptr; static std::once_flag once;
+	std::call_once(once, [] {
+		uint8_t one[256];
+		for (int ch = 0; ch < 256; ch++) one[ch] = (ch == 'A' || ch == 'a') ? 0 : (ch == 'G' || ch == 'g') ? 2 : (ch == 'T' || ch == 't') ? 3 : 1;
+		uint8_t *t = (uint8_t *)malloc(65536);
+		for (int v = 0; v < 65536; v++) t[v] = (uint8_t)(one[v & 255] << 2 | one[v >> 8]);
+		lut = t;
+	});
+	return lut;
+}
+// bases [b0, b0 + 4 nb) of a read of len bases (text at src) -> nb packed bytes; bases beyond the read pack as A
+static void pack_bases(uint8_t *dst, const char *src, uint64_t b0, uint64_t nb, uint32_t len)
+{
+	const uint8_t *lut = pack_lut(); const uint8_t *p = (const uint8_t *)src + b0;
+	uint64_t full = b0 + 4 * nb <= len ? nb : (len > b0 ? (len - b0) / 4 : 0);
+	for (uint64_t k = 0; k < full; k++, p += 4) { uint16_t a, b; memcpy(&a, p, 2); memcpy(&b, p + 2, 2); dst[k] = (uint8_t)(lut[a] << 4 | lut[b]); }
+	for (uint64_t k = full; k < nb; k++) {
+		uint32_t v = 0;
+		for (int j = 0; j < 4; j++) { const uint64_t bi = b0 + 4 * k + j; const uint8_t ch = bi < len ? (uint8_t)src[bi] : (uint8_t)'A'; v = v << 2 | (uint32_t)(lut[ch] >> 2); }
+		dst[k] = (uint8_t)v;
+	}
+}
 static int upload_gather(dsb_ctx *c, InSlot &s, const SeqView *reads, size_t n, uint64_t total)
 {
 	if (!total) return DSB_OK;
+	const bool packed = s.packed;                  // seq_off and total are then bytes of packed sequence: a read takes (len + 3) / 4
 	const size_t CB = upload_chunk(c), n_chunks = (size_t)((total + CB - 1) / CB);
-	int T = upload_threads();
+	int T = upload_threads(c);
 	if ((size_t)T > n_chunks) T = (int)n_chunks;
 	if (T < 1) T = 1;
 	if (int rc = upload_stages(c, T)) return rc;
 	std::atomic<size_t> next(0); std::atomic<int> err(0);
 	const DsbReadDesc *rd = s.h_rd.data();
-	const bool trace = getenv("DSB_UPLOAD_TRACE") != nullptr;
+	const bool trace = c->knobs.upload_trace;
 	std::vector<double> t_wait(T, 0.0), t_copy(T, 0.0), t_sub(T, 0.0);
 	auto clk = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
 	const double t_begin = clk();
@@ -1176,11 +1277,14 @@ static int upload_gather(dsb_ctx *c, InSlot &s, const SeqView *reads, size_t n, 
 			const double w1 = trace ? clk() : 0;
 			const uint64_t lo = (uint64_t)ch * CB, hi = lo + CB < total ? lo + CB : total;
 			size_t a = 0, b = n;                               // first read that ends beyond lo
-			while (a < b) { const size_t m = (a + b) / 2; if (rd[m].seq_off + rd[m].len > lo) b = m; else a = m + 1; }
+			auto ext = [&](size_t m) { return packed ? ((uint64_t)rd[m].len + 3) / 4 : (uint64_t)rd[m].len; };      // bytes of read m in the blob
+			while (a < b) { const size_t m = (a + b) / 2; if (rd[m].seq_off + ext(m) > lo) b = m; else a = m + 1; }
 			char *dst = u.buf[par];
 			for (size_t i = a; i < n && rd[i].seq_off < hi; i++) {
-				const uint64_t p = rd[i].seq_off > lo ? rd[i].seq_off : lo, q = rd[i].seq_off + rd[i].len < hi ? rd[i].seq_off + rd[i].len : hi;
-				if (q > p) memcpy(dst + (p - lo), reads[i].p + (p - rd[i].seq_off), (size_t)(q - p));
+				const uint64_t p = rd[i].seq_off > lo ? rd[i].seq_off : lo, q = rd[i].seq_off + ext(i) < hi ? rd[i].seq_off + ext(i) : hi;
+				if (q <= p) continue;
+				if (packed) pack_bases((uint8_t *)dst + (p - lo), reads[i].p, 4 * (p - rd[i].seq_off), q - p, rd[i].len);
+				else memcpy(dst + (p - lo), reads[i].p + (p - rd[i].seq_off), (size_t)(q - p));
 			}
 			const double w2 = trace ? clk() : 0;
 			if (hipMemcpyAsync(s.d_ascii + lo, dst, (size_t)(hi - lo), hipMemcpyHostToDevice, u.st) != hipSuccess || hipEventRecord(u.ev[par], u.st) != hipSuccess) { err = 1; break; }
@@ -1198,7 +1302,7 @@ static int upload_gather(dsb_ctx *c, InSlot &s, const SeqView *reads, size_t n, 
 	for (std::thread &x : th) x.join();
 	if (trace) {
 		double a = 0, b = 0, d = 0; for (int t = 0; t < T; t++) { a += t_wait[t]; b += t_copy[t]; d += t_sub[t]; }
-		fprintf(stderr, "[upload] %.2f GB in %zu chunks on %d threads: %.3f s wall = %.1f GB/s; per thread: gather %.3f s, waiting for a chunk's transfer %.3f s, submitting %.3f s\n", total / 1e9, n_chunks, T,
+		fprintf(stderr, "[upload] %.2f GB%s in %zu chunks on %d threads: %.3f s wall = %.1f GB/s; per thread: gather %.3f s, waiting for a chunk's transfer %.3f s, submitting %.3f s\n", total / 1e9, packed ? " (2 bits per base: bases / 4)" : " of text", n_chunks, T,
 		        clk() - t_begin, total / 1e9 / (clk() - t_begin), b / T, a / T, d / T);
 	}
 	if (err.load()) { fprintf(stderr, "[desamba_amd] HIP error %s in upload_gather\n", hipGetErrorString(hipGetLastError())); return DSB_ENODEV; }
@@ -1213,10 +1317,14 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 	InSlot &s = c->in[c->cur];
 	const int k = c->dx.ek_len;
 	s.h_rd.resize(n);
-	uint64_t seq_off = 0, bin_off = 0, pk_off = 0, bit_off = 0, windows = 0, seed_off = 0; uint32_t max_len = 64, min_len = 0xffffffffu; int hist = c->hist_max;
+	uint64_t seq_off = 0, bin_off = 0, pk_off = 0, bit_off = 0, windows = 0, seed_off = 0, blob_off = 0; uint32_t max_len = 64, min_len = 0xffffffffu; int hist = c->hist_max;
+	// sequences gathered from the caller's buffers travel as 2 bits per base (packed by the gather threads): a quarter of the pinned
+	// writes and of the transfer; a caller's whole text blob (dsb_batch_upload_text) travels as it is
+	s.packed = !ext_text && !c->knobs.upload_text;
 	for (size_t i = 0; i < n; i++) {
 		DsbReadDesc &d = s.h_rd[i];
-		d.len = reads[i].len; d.seq_off = ext_text ? ext_off[i] : seq_off; d.bin_off = bin_off; d.pk_off = pk_off; d.bit_off = bit_off;
+		d.len = reads[i].len; d.seq_off = ext_text ? ext_off[i] : (s.packed ? blob_off : seq_off); d.bin_off = bin_off; d.pk_off = pk_off; d.bit_off = bit_off;
+		blob_off += ((uint64_t)d.len + 3) / 4;
 		d.n_win = d.len >= 40 ? d.len - k + 1 : 0; d.n_words = (d.n_win + 63) / 64;
 		d.hist_max = hist; if ((int)d.len > hist) hist = d.len;
 		d.seed_off = seed_off; seed_off += ((uint64_t)d.len >> 1) + 64;
@@ -1229,12 +1337,13 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 	c->hist_max = hist;
 	s.n_reads = n; s.n_words_total = bit_off; s.total_bases = seq_off; s.total_windows = windows; s.max_len = max_len; s.seed_entries = seed_off;
 	s.min_len = n ? min_len : 0; s.ragged = n && (uint64_t)max_len > (uint64_t)min_len + (min_len >> 3) + 64;
+	s.upload_bytes = ext_text ? ext_len : (s.packed ? blob_off : seq_off);
 	int rc;
-	const bool utrace = getenv("DSB_UPLOAD_TRACE") != nullptr;
+	const bool utrace = c->knobs.upload_trace;
 	auto uclk = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
 	const double u0 = utrace ? uclk() : 0;
 	if ((rc = grow(&s.d_rd, &s.cap_rd, n + 1))) return rc;
-	if ((rc = grow(&s.d_ascii, &s.cap_ascii, (ext_text ? ext_len : (size_t)seq_off) + 64))) return rc;
+	if ((rc = grow(&s.d_ascii, &s.cap_ascii, (ext_text ? ext_len : (size_t)(s.packed ? blob_off : seq_off)) + 64))) return rc;
 	if ((rc = ensure_buffers(c, n, max_len, bin_off, pk_off, bit_off, seed_off))) return rc;
 	if (utrace) fprintf(stderr, "[upload] %zu reads, longest %u, %.2f Gbases: descriptors %.3f s on the host, device buffers checked / grown in %.3f s%s\n", n, max_len, seq_off / 1e9, 0.0, uclk() - u0, s.ragged ? " (ragged: reads sorted by length for the seed scan)" : "");
 	if (n) {
@@ -1250,7 +1359,7 @@ static int upload_views(dsb_ctx *c, const SeqView *reads, size_t n, const char *
 		if (ext_text) HIPCHK(hipMemcpyAsync(s.d_ascii, ext_text, ext_len, hipMemcpyHostToDevice, c->stream));
 		else {
 			// sequences: gathered out of the caller's buffers (caller owns read memory) through pinned chunks
-			if ((rc = upload_gather(c, s, reads, n, seq_off))) return rc;
+			if ((rc = upload_gather(c, s, reads, n, s.packed ? blob_off : seq_off))) return rc;
 		}
 	}
 	HIPCHK(hipStreamSynchronize(c->stream));               // the caller's buffers are free again when this returns
@@ -1314,7 +1423,7 @@ static void launch_classify(K kern, dsb_ctx *c, hipStream_t st, unsigned grid, c
 {
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, st, dx, (const DsbReadDesc *)s.d_rd, n_fixed, n_ptr, list, c->d_bin, (const uint64_t *)c->d_bits, ar, work_counter,
 	                   c->d_rout, c->d_hout, c->d_counters + 1, (uint32_t)c->cap_hout, dbg, item_base, slot_base, (unsigned long long *)(c->d_counters + 16 + 8 * cnt_set),
-	                   pre_seeds ? c->d_seeds : nullptr, (const DsbSeedInfo *)c->d_sinfo, (const uint64_t *)c->d_pk, (uint32_t)((pre_seeds && s.max_len <= DSB_GROUP_MAX_LEN && !getenv("DSB_NO_GROUP")) ? (getenv("DSB_GROUP_HEAD") ? (unsigned)atoi(getenv("DSB_GROUP_HEAD")) : 8u * grid) : 0u));
+	                   pre_seeds ? c->d_seeds : nullptr, (const DsbSeedInfo *)c->d_sinfo, (const uint64_t *)c->d_pk, (uint32_t)((pre_seeds && s.max_len <= DSB_GROUP_MAX_LEN && !c->knobs.no_group) ? (c->knobs.group_head >= 0 ? (unsigned)c->knobs.group_head : 8u * grid) : 0u));
 }
 
 static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn);
@@ -1324,7 +1433,7 @@ extern "C" int dsb_batch_run(dsb_ctx *c)
 	// Contexts that share a device take turns with their kernels: two batches side by side run 1.25x as long as one after
 	// the other (two persistent launches halve each other's wave slots and both end in their tails), while the uploads and
 	// fetches of the waiting context still overlap the running one's kernels -- which is what the second context is for.
-	if (c->staged && !getenv("DSB_NO_TURN")) { std::unique_lock<std::mutex> g(c->staged->run_mu); return batch_run_locked(c, &g); }
+	if (c->staged && !c->knobs.no_turn) { std::unique_lock<std::mutex> g(c->staged->run_mu); return batch_run_locked(c, &g); }
 	return batch_run_locked(c, nullptr);
 }
 static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn)
@@ -1333,19 +1442,21 @@ static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn)
 	InSlot &s = c->in[c->cur];
 	size_t n = s.n_reads;
 	memset(&c->timing, 0, sizeof c->timing);
+	c->timing.upload_bytes = s.upload_bytes;
 	if (n == 0) return DSB_OK;
 	HIPCHK(hipMemsetAsync(c->d_counters, 0, 256, c->stream));
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
-	hipLaunchKernelGGL(k_encode_bytes, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, s.d_ascii, c->d_bin);
+	if (s.packed) hipLaunchKernelGGL(k_encode_bytes_pk, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, (const uint8_t *)s.d_ascii, c->d_bin);
+	else hipLaunchKernelGGL(k_encode_bytes, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, s.d_ascii, c->d_bin);
 	hipLaunchKernelGGL(k_encode_pack, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, c->d_bin, c->d_pk);
 	HIPCHK(hipEventRecord(c->ev[1], c->stream));
-	const bool dbg = getenv("DSB_DEBUG") != NULL && c->dbg_dev;
+	const bool dbg = c->knobs.debug && c->dbg_dev;
 	if (dbg) { HIPCHK(hipStreamSynchronize(c->stream)); fprintf(stderr, "[dsb] encode done\n"); }
 	// the LPT order needs only the packed reads.  (Run beside the seed probe its scoring kernel takes 90 ms instead
 	// of 12: both stream the packed reads.)
 	hipLaunchKernelGGL(k_repeat_score, dim3((unsigned)n), dim3(256), 0, c->stream, s.d_rd, c->d_pk, c->d_score);
 	hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, c->stream, c->d_score, (uint32_t)n, c->d_order);
-	if (const char *of = getenv("DSB_ORDER_FILE")) {
+	if (const char *of = c->knobs.order_file.empty() ? nullptr : c->knobs.order_file.c_str()) {
 		// experiments: a processing order from outside (n x u32, a permutation of the reads) -- e.g. the measured wave times of an
 		// earlier run of the same batch, to see what a perfect longest-first order is worth.  Changes no result.
 		std::vector<uint32_t> ord(n); FILE *f = fopen(of, "rb");
@@ -1359,8 +1470,7 @@ static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn)
 	// k_classify launch on the second stream right away, beside the main seed probe, instead of after it.
 	unsigned n_heavy = 0;
 	if (!dbg && s.n_words_total && !c->seed_only) {
-		const char *hv = getenv("DSB_HEAVY_FIRST");
-		n_heavy = hv ? (unsigned)atoi(hv) : (n >= 4096 ? (unsigned)(n / 64) : 0u);
+		n_heavy = c->knobs.heavy_first_set ? (unsigned)c->knobs.heavy_first : (n >= 4096 ? (unsigned)(n / 64) : 0u);
 		if (n_heavy > (unsigned)c->n_extra) n_heavy = (unsigned)c->n_extra;
 		if (n_heavy > n / 2) n_heavy = (unsigned)(n / 2);
 	}
@@ -1370,16 +1480,16 @@ static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn)
 	// bits otherwise (a strand is a serial chain of ~7000 round trips: a small batch would wait for it).  DSB_SEED_SCAN=0/1
 	// forces one or the other.  The early launch of the heaviest reads always takes the hit-bit path.
 	bool use_scan = n >= 2048;
-	if (const char *e = getenv("DSB_SEED_SCAN")) use_scan = atoi(e) != 0;
+	if (c->knobs.seed_scan >= 0) use_scan = c->knobs.seed_scan != 0;
 	c->bits_valid = !use_scan; c->seeds_valid = use_scan;
 	uint32_t step_limit = DSB_STEP_LIMIT;
-	if (const char *e = getenv("DSB_STEP_LIMIT_RT")) { long v = atol(e); if (v > 0) step_limit = (uint32_t)v; }   // diagnostics: a small budget forces second runs
+	if (c->knobs.step_limit_rt > 0) step_limit = (uint32_t)c->knobs.step_limit_rt;   // diagnostics: a small budget forces second runs
 	DsbDevIndex dx1 = c->dx; dx1.sms_cap = c->arena.sms_cap; dx1.step_limit = step_limit;
 	// a read whose sparse DP scans more predecessors than this on one wavefront is given up there and run again by a
 	// workgroup of 8 wavefronts (k_classify_heavy) after the main launch; DSB_HEAVY_PREDS=0 switches that off
 	dx1.heavy_limit = DSB_HEAVY_PREDS;
 	if (dbg) dx1.heavy_limit = 0;                                 // (stage dumps describe whole reads, unless the limit is asked for)
-	if (const char *e = getenv("DSB_HEAVY_PREDS")) dx1.heavy_limit = (uint32_t)strtoul(e, nullptr, 10);
+	if (c->knobs.heavy_preds_set) dx1.heavy_limit = c->knobs.heavy_preds;
 	if (n_heavy) {
 		// their probes first, alone on the device (about a millisecond), then their classify launch on the second stream
 		hipLaunchKernelGGL(k_seed_probe_reads, dim3(n_heavy * DSB_HPROBE_SPLIT), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const uint32_t *)c->d_order, c->d_pk, c->d_bits, c->d_summ, c->summ_shift);
@@ -1388,7 +1498,7 @@ static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn)
 		// the very heaviest of them (DSB_HEAVY_MW; by default 16, more once the batches of this ctx have ended in their tails,
 		// see the end of this function) get eight wavefronts each (k_classify_heavy) on a third stream
 		unsigned n_mw = c->mw_reads;
-		if (const char *e = getenv("DSB_HEAVY_MW")) n_mw = (unsigned)atoi(e);
+		if (c->knobs.heavy_mw >= 0) n_mw = (unsigned)c->knobs.heavy_mw;
 		if (n_mw > n_heavy) n_mw = n_heavy;
 		c->timing.n_heavy_mw = n_mw;
 		if (n_mw) {
@@ -1470,7 +1580,7 @@ static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn)
 	// The device's turn ends with the main launch: what may still follow it -- the early launch's last reads (tandem repeats: a
 	// handful of wavefronts), the pass over the reads given up as heavy, the second run -- leaves most of the device idle, and the
 	// other context's next batch starts with its HBM-bound seed lookup.  (DSB_TURN_WHOLE_RUN=1: the turn lasts to the end, as before.)
-	if (turn && !getenv("DSB_TURN_WHOLE_RUN")) { HIPCHK(hipEventSynchronize(c->ev_cls_wait)); turn->unlock(); }
+	if (turn && !c->knobs.turn_whole_run) { HIPCHK(hipEventSynchronize(c->ev_cls_wait)); turn->unlock(); }
 	HIPCHK(hipEventSynchronize(c->ev[3]));
 	{
 		// The hit buffer holds 16 n + 4096 records (the reference's lists are unbounded).  The device counts every
@@ -1686,6 +1796,8 @@ extern "C" int dsb_shard_plan(const uint32_t *lengths, size_t n, int world, uint
 
 struct dsb_multi {
 	dsb_index *idx = nullptr; std::vector<dsb_ctx *> ctx; uint32_t hist = 0;
+	uint32_t chunk_reads_env = 0;                 // DSB_SHARD_CHUNK_READS, read when the contexts are made (tests: many small chunks)
+	std::vector<uint32_t> last_calls;             // dsb_classify_batch calls each context made in the last dsb_multi_classify_batch
 	std::vector<dsb_read_result> reads; std::vector<dsb_hit> hits;
 };
 
@@ -1701,6 +1813,7 @@ extern "C" int dsb_ctx_create_multi(dsb_index *idx, const int *device_ids, int n
 {
 	if (!idx || !device_ids || n_dev < 1 || !out) return DSB_EINVAL;
 	dsb_multi *m = new dsb_multi(); m->idx = idx;
+	if (const char *cr = getenv("DSB_SHARD_CHUNK_READS")) m->chunk_reads_env = (uint32_t)atol(cr);
 	for (int i = 0; i < n_dev; i++) {
 		dsb_ctx *c = nullptr; int rc = dsb_ctx_create(idx, device_ids[i], opts, &c);
 		if (rc) { dsb_multi_destroy(m); return rc; }
@@ -1712,31 +1825,49 @@ extern "C" int dsb_ctx_create_multi(dsb_index *idx, const int *device_ids, int n
 extern "C" int dsb_multi_n(const dsb_multi *m) { return m ? (int)m->ctx.size() : 0; }
 extern "C" dsb_ctx *dsb_multi_ctx(dsb_multi *m, int i) { return (m && i >= 0 && (size_t)i < m->ctx.size()) ? m->ctx[i] : nullptr; }
 extern "C" void dsb_multi_reset_history(dsb_multi *m) { if (m) m->hist = 0; }
+// dsb_classify_batch calls context i made in the last dsb_multi_classify_batch (how the batch was cut)
+extern "C" uint32_t dsb_multi_last_calls(const dsb_multi *m, int i) { return (m && i >= 0 && (size_t)i < m->last_calls.size()) ? m->last_calls[(size_t)i] : 0; }
 
-// the kt_for seam (src/cly_mt.c:389) over several devices: the batch is cut by dsb_shard_plan, every context takes its
-// chunks in turn on a host thread of its own, results come back in input order
+// the kt_for seam (src/cly_mt.c:389) over several devices: the batch is cut into contiguous chunks (dsb_shard_plan: hist_max_before in
+// the chunk header), the contexts take the chunks from a counter -- whichever is free takes the next (kt_for's work stealing,
+// src/lib/kthread.c:61-86) -- on a host thread each; results come back in input order.
+// A dsb_classify_batch call lasts as long as its heaviest read and fills the device from ~64 k long reads on, so a chunk is n / W reads,
+// not less than 32768, bounded by what the contexts were told to expect (dsb_opts.max_batch_reads / max_batch_bases) and by 4 Gbases
+// (the device buffers of a chunk: ~5 bytes per base).  DSB_SHARD_CHUNK_READS (read by dsb_ctx_create_multi) forces small chunks.
 extern "C" int dsb_multi_classify_batch(dsb_multi *m, const dsb_read *reads, size_t n, dsb_result *out)
 {
 	if (!m || (!reads && n) || !out) return DSB_EINVAL;
 	const int W = (int)m->ctx.size();
 	std::vector<uint32_t> len(n);
 	for (size_t i = 0; i < n; i++) len[i] = reads[i].len;
-	const char *cr = getenv("DSB_SHARD_CHUNK_READS"); const uint32_t chunk_reads = cr ? (uint32_t)atol(cr) : 0;
+	uint32_t chunk_reads = m->chunk_reads_env; uint64_t chunk_bases = 4000000000ULL;
+	if (!chunk_reads) {
+		uint64_t want = (n + (size_t)W - 1) / (size_t)W; if (want < 32768) want = 32768;
+		const dsb_opts &o = m->ctx[0]->opts;
+		if (o.max_batch_reads && want > o.max_batch_reads) want = o.max_batch_reads;
+		if (o.max_batch_bases) chunk_bases = o.max_batch_bases;
+		chunk_reads = want > 0xffffffffULL ? 0xffffffffu : (uint32_t)want;
+	}
 	size_t nc = 0;
-	dsb_shard_plan(len.data(), n, W, 0, chunk_reads, nullptr, 0, &nc);
+	dsb_shard_plan(len.data(), n, W, chunk_bases, chunk_reads, nullptr, 0, &nc);
 	std::vector<dsb_chunk> plan(nc ? nc : 1);
-	dsb_shard_plan(len.data(), n, W, 0, chunk_reads, plan.data(), nc, &nc);
+	dsb_shard_plan(len.data(), n, W, chunk_bases, chunk_reads, plan.data(), nc, &nc);
 	m->reads.assign(n, dsb_read_result());
 	std::vector<std::vector<dsb_hit>> chunk_hits(nc);
 	std::vector<int> rcs(W, DSB_OK);
 	const uint32_t hist0 = m->hist;
+	std::atomic<size_t> next_chunk(0);
+	m->last_calls.assign((size_t)W, 0);
 	auto worker = [&](int w) {
 		dsb_ctx *c = m->ctx[w];
-		for (size_t k = (size_t)w; k < nc; k += (size_t)W) {
+		for (;;) {
+			const size_t k = next_chunk.fetch_add(1);
+			if (k >= nc) break;
 			const dsb_chunk &ch = plan[k];
 			dsb_ctx_set_history(c, ch.hist_max_before > hist0 ? ch.hist_max_before : hist0);
 			dsb_result r;
 			int rc = dsb_classify_batch(c, reads + ch.start, (size_t)(ch.end - ch.start), &r);
+			m->last_calls[(size_t)w]++;
 			if (rc && rc != DSB_ECAP) { rcs[w] = rc; return; }
 			if (rc == DSB_ECAP) rcs[w] = DSB_ECAP;
 			std::vector<dsb_hit> &H = chunk_hits[k];

@@ -98,6 +98,7 @@ typedef struct {
 	uint64_t main_occ, main_mem, main_sa, main_ref_bases;   /* the same for the main k_classify launch alone (what classify_ms times) */
 	uint32_t n_heavy_mw;   /* reads of the early launch that ran on several wavefronts each (k_classify_heavy) */
 	uint32_t n_requeue;    /* reads given up by their wavefront as heavy (quadratic sparse DP) and run again by a workgroup of wavefronts */
+	uint64_t upload_bytes; /* bytes the sequences of the batch took over PCIe: bases / 4 from dsb_batch_upload (packed by the gather threads), the text from dsb_batch_upload_text */
 } dsb_timing;
 
 /* load_idx (src/idx.c:1103-1160, src/bwt.c:68-104): read <dir>/deSAMBA.* into host memory */
@@ -139,6 +140,9 @@ void dsb_ctx_destroy(dsb_ctx *ctx);
  * are allocated once, before the loop over the input files (src/cly_mt.c:538-556) -- so a drop-in caller calls this only
  * where a new `deSAMBA classify` process would start */
 void dsb_ctx_reset_history(dsb_ctx *ctx);
+/* The DSB_* diagnostic switches of the environment are read once, by dsb_ctx_create; this reads them again (tests and experiments
+ * that change them on a living context).  No counterpart in the reference. */
+void dsb_ctx_reload_env(dsb_ctx *ctx);
 /* set it explicitly: the longest read of the run before the next batch (for callers that deal batches to several
  * contexts and therefore carry the prefix maximum themselves) */
 void dsb_ctx_set_history(dsb_ctx *ctx, uint32_t max_len_before);
@@ -159,6 +163,9 @@ void dsb_multi_destroy(dsb_multi *m);
 int  dsb_multi_n(const dsb_multi *m);
 dsb_ctx *dsb_multi_ctx(dsb_multi *m, int i);          /* for callers that drive the contexts themselves (the CLI) */
 void dsb_multi_reset_history(dsb_multi *m);
+/* how the last dsb_multi_classify_batch was cut: the dsb_classify_batch calls context i made (a batch is cut into n / n_ctx reads per
+ * call, not less than 32768, bounded by dsb_opts.max_batch_reads / max_batch_bases: a call fills the device from ~64 k long reads on) */
+uint32_t dsb_multi_last_calls(const dsb_multi *m, int i);
 /* the kt_for seam over all contexts: the batch is cut by dsb_shard_plan, results in input order, valid until the next call */
 int  dsb_multi_classify_batch(dsb_multi *m, const dsb_read *reads, size_t n, dsb_result *out);
 /* the sharding rule: contiguous chunks of the input order (a chunk ends after chunk_bases bases or chunk_reads reads;

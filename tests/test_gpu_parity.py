@@ -19,9 +19,18 @@ def gpu(demo):
     ctx.close(); idx.close()
 
 
+@pytest.fixture(autouse=True)
+def _switches_of_the_shared_ctx(request):
+    """the DSB_* switches are read once per ctx: after a test that set some (monkeypatch has put the environment back by now) the
+    shared ctx reads them again, so that the next test starts from the defaults"""
+    yield
+    if "gpu" in request.fixturenames:
+        request.getfixturevalue("gpu")[2].reload_env()
+
+
 def classify_all(D, ctx, recs, chunk=None):
     """-> (list of hit-key lists, SAM bytes); history is reset like a new input file"""
-    ctx.reset_history()
+    ctx.reset_history(); ctx.reload_env()          # (the DSB_* switches a test sets are read once per ctx: read them again)
     out, sam = [], []
     chunk = chunk or len(recs) or 1
     for s in range(0, max(len(recs), 1), chunk):
@@ -119,7 +128,7 @@ def test_stage_parity_seed_lookup(gpu, demo, oracle):
     D, idx, ctx = gpu
     recs = D.read_fastq(demo["fastq"], 64) + D.read_fastq(os.path.join(GOLDEN, "synth", "ngs150.fq"), 64)
     reads = D.make_reads(recs)
-    ctx.reset_history(); ctx.classify(reads)
+    ctx.reset_history(); ctx.reload_env(); ctx.classify(reads)
     hist = 0
     for i, (nm, seq, q) in enumerate(recs):
         oracle.classify(seq, hist); hist = max(hist, len(seq))
@@ -312,6 +321,45 @@ def test_cli_two_logical_shards_on_one_device(gpu, tmp_path, monkeypatch):
     assert out2.read_bytes() == out.read_bytes()
 
 
+def test_multi_api_cuts_a_batch_into_device_filling_calls(demo, tmp_path):
+    """dsb_multi_classify_batch on 131072 x 5 kbp reads over two contexts of device 0: the batch is cut into n / W reads per call
+    (64 k here), not into 64-Mbase crumbs -- at most two dsb_classify_batch calls per context, the same hits as one context on the whole
+    batch, and a rate within 10 % of it (round 3's 64-Mbase chunks ran ~13 k such reads per call)"""
+    import subprocess, time
+    import desamba_amd as D
+    fq = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else str(tmp_path), "dsb_multi_test.fq")
+    subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "gen_fastq.py"), demo["index"], fq, "131072", "5000", "0.15", "77", "ont", "8"], check=True, stdout=subprocess.DEVNULL)
+    idx = D.Index(demo["index"]); ctx = None; m = None
+    try:
+        lines = open(fq, "rb").read().split(b"\n"); os.remove(fq)          # (four-line records: the general parser takes minutes on 1.3 GB)
+        recs = [(lines[i][1:], lines[i + 1], None) for i in range(0, len(lines) - 3, 4)]
+        del lines
+        assert len(recs) == 131072
+        reads = D.make_reads(recs)
+        ctx = D.Ctx(idx, 0, max_read_len=5064, max_batch_reads=131072, max_batch_bases=131072 * 5100)
+        ctx.classify(reads)                                  # (buffers, arenas: grown once)
+        t0 = time.perf_counter(); res1 = ctx.classify(reads); t_single = time.perf_counter() - t0
+        one = [[res1.hits[res1.reads[i].first + k].key() for k in range(res1.reads[i].n)] for i in range(0, len(recs), 37)]
+        ctx.close(); ctx = None
+        m = D.Multi(idx, [0, 0])
+        m.classify(reads); m.reset_history()
+        t0 = time.perf_counter(); res2 = m.classify(reads); t_multi = time.perf_counter() - t0
+        calls = m.last_calls()
+        assert sum(calls) == 2 and max(calls) <= 2, calls
+        two = [[res2.hits[res2.reads[i].first + k].key() for k in range(res2.reads[i].n)] for i in range(0, len(recs), 37)]
+        assert two == one
+        print("131072 x 5 kbp: one context %.3f s, dsb_multi_classify_batch over two contexts of one device %.3f s, calls per context %r" % (t_single, t_multi, calls))
+        # measured: 0.25-0.29 s against 0.24 s -- each half ends in the tail of its own heaviest reads (tandem repeats of the demo index), which
+        # only partly hides behind the other half's main launch; round 3's 64-Mbase chunks (10 calls of 13 k reads) took 2x
+        assert t_multi <= 1.5 * t_single
+    finally:
+        if ctx:
+            ctx.close()
+        if m:
+            m.close()
+        idx.close()
+
+
 def test_multi_api_shards_a_batch(gpu, monkeypatch):
     """dsb_ctx_create_multi + dsb_multi_classify_batch: one batch cut by dsb_shard_plan into chunks of 50 reads over two
     contexts (device 0 listed twice): same hits as the single context, in input order, history carried per chunk"""
@@ -443,7 +491,7 @@ def test_seed_scan_kernel_stage_parity(gpu, demo, oracle, monkeypatch):
     recs = D.read_fastq(demo["fastq"], 300) + D.read_fastq(os.path.join(GOLDEN, "synth", "ngs150.fq"), 64) + [(b"short", b"ACGT" * 9, None), (b"polyA", b"A" * 300, None)] + \
         D.read_fastq(os.path.join(GOLDEN, "synth", "ont20k.fq"), 4)
     reads = D.make_reads(recs)
-    ctx.reset_history(); ctx.classify(reads)
+    ctx.reset_history(); ctx.reload_env(); ctx.classify(reads)
     t = ctx.timing()
     assert t.seed_scan == 1 and 0 < t.windows < 1.2 * t.bases and t.probes_t1 < t.windows
     hist = 0
@@ -508,7 +556,7 @@ def test_seed_lookup_on_synthetic_multi_gib_tables(demo, tmp_path, monkeypatch):
         got = {}
         for mode in ("0", "1"):
             monkeypatch.setenv("DSB_SEED_SCAN", mode)
-            ctx.reset_history(); ctx.upload(reads); ctx.run()
+            ctx.reset_history(); ctx.reload_env(); ctx.upload(reads); ctx.run()
             t = ctx.timing()
             assert t.seed_scan == int(mode) and t.classify_ms == 0
             got[mode] = [(ctx.seeds(i, 1), ctx.seeds(i, 0)) for i in range(len(recs))]
