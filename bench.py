@@ -701,7 +701,7 @@ def main():
     # ---- BASELINE configs[2]: 1 M synthetic 150 bp reads (1 % error) on the HEADLINE index, one resident batch
     if rank == 0 and not a.no_short_reads:
         out["config3_short_reads"] = resident_batch(D, L, idx, index_dir, local, 1 << 20, 150, 0.01, 4242, 0, gen_threads * world,
-                                                    "1048576 synthetic 150 bp reads, 1 % error, the headline index (%s), one batch resident in HBM" % ("viral-RefSeq-sized synthetic strain collection" if a.headline == "strain" else "demo"))
+                                                    "1048576 synthetic 150 bp reads, 1 %% error, the headline index (%s), one batch resident in HBM" % ("viral-RefSeq-sized synthetic strain collection" if a.headline == "strain" else "demo"))
     m.close(); idx.close()
     # ---- BASELINE configs[4] proxy: a >= 1-Gbp index built here, PacBio-mixed reads, one resident batch + a parity sample against the reference
     if rank == 0 and not a.no_proxy:

@@ -189,7 +189,10 @@ DV void lctx_done(WCtxL &w, const LCtx &l) { w.n_anc = l.n_anc; w.status = l.sta
 // Serial sections: stretches of the per-read logic with no lane-level parallelism run on lane 0 alone, so that
 // their loads and stores are one-address memory instructions instead of 64 copies of the same address going
 // through the CU's address pipeline; serial_end() broadcasts the scalars such a section may change.
-#define DSB_SERIAL(w) if (DSB_LANE == 0)
+// (A serial section begins with a wave_sync(), like it ends with one: what all lanes stored before it -- the same values, redundantly
+// -- is then in place before lane 0 changes it, by the wavefront memory model and not just by the order of the instructions.)
+DV bool dsb_serial_lane() { wave_sync(); return DSB_LANE == 0; }
+#define DSB_SERIAL(w) if (dsb_serial_lane())
 DV void serial_end(WCtxL &) { wave_sync(); }      // (the context is in LDS: what lane 0 wrote is what every lane reads)
 
 // ---- hashes (src/lib/utils.c:1067-1091) ---------------------------------------------------
@@ -1347,7 +1350,12 @@ DN void chain_top_select(WCtxL &w)
 // resolve_tree (src/cly.c:326-349)
 DN void resolve_tree(WCtxL &w)
 {
+	// (what follows has lane 0 alone change the context and the anchors that all lanes have just written with the same values --
+	// slow_classify, the islands walked again at commit --: a wave_sync() before and after the reset keeps that in order by the
+	// wavefront memory model, not just by the order of the instructions; the 64-lane emulation of tests/emu checks such places)
+	wave_sync();
 	w.n_hit = 0;
+	wave_sync();
 	const bool lds_dp = w.n_anc >= 50 && w.n_anc <= DSB_CHAINDP_LDS && w.wtab;
 	if (w.n_anc >= 50) chain_sort_M3(w);
 	const bool wave_dp = w.n_anc >= 50 && w.wtab != nullptr;
@@ -1445,6 +1453,7 @@ template <class P8>
 DN void wtab_build(lds_u32 *tab, int lane, P8 q_str, uint32_t q_bg, uint32_t n_q)
 {
 	const uint32_t slots = wtab_size(n_q);
+	wave_sync();                // (see wtab_build_pk)
 	for (uint32_t i = lane; i < slots; i += DSB_WAVE) tab[i] = DSB_WTAB_EMPTY;
 	wave_sync();
 	// four positions per lane per round: the loads of a round are issued before its first insert (the read bytes come
@@ -1484,6 +1493,7 @@ DN void wtab_build(lds_u32 *tab, int lane, P8 q_str, uint32_t q_bg, uint32_t n_q
 DN void wtab_build_pk(lds_u32 *tab, int lane, const uint64_t *P, uint32_t n_words, uint32_t q_bg, uint32_t n_q)
 {
 	const uint32_t slots = wtab_size(n_q);
+	wave_sync();                // (the table's memory changes tenants: whoever still reads the previous one -- sdp_match_inv's pair count -- has read it)
 	{	// (the table is 16-byte aligned)
 		const uint32_t s4 = slots & ~3u;
 		for (uint32_t i = 4 * lane; i < s4; i += 4 * DSB_WAVE) lds_fill4(tab + i, DSB_WTAB_EMPTY);

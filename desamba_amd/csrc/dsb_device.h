@@ -93,6 +93,7 @@ static inline uint32_t dsb_sms_cap_for(uint32_t max_len) { uint32_t c = 2 * max_
 #define DSB_MEMSLOW_CAP (8 * 800 + 1 + 16)
 #define DSB_SPSET_CAP 500
 #define DSB_REFWIN 2176
+#define DSB_REFWIN_FRONT 64    /* bytes in front of the first window: the backward exact-match test loads the 8 bytes that end at a window's 4th base */
 
 // status bits
 #define DSB_ST_ANC_OVF 1

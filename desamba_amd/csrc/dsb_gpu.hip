@@ -471,7 +471,7 @@ __device__ __forceinline__ void classify_kernel_body(const DsbDevIndex &x, const
 	w.spset = (uint64_t *)(slot + ar.off_spset);
 	w.score_v = (int *)(slot + ar.off_scorev);
 	w.sortkey = (uint64_t *)(slot + ar.off_sortkey); w.sortidx = (uint32_t *)(slot + ar.off_sortidx);
-	w.win_mid = slot + ar.off_win; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
+	w.win_mid = slot + ar.off_win + DSB_REFWIN_FRONT; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
 	w.lane_anc = (DsbAnchor *)(slot + ar.off_lane_anc); w.lane_spset = (uint64_t *)(slot + ar.off_lane_sp);
 	w.top_idx = (uint32_t *)(slot + ar.off_top); w.round_info = (uint32_t *)(slot + ar.off_round);
 	w.anc_cap = ar.anc_cap; w.anc_cap_main = ar.anc_cap; w.hit_cap = ar.hit_cap; w.step_limit = x.step_limit; w.heavy_limit = x.heavy_limit; w.sp_gen = 0; w.mw = nullptr; w.n_waves = 1;
@@ -613,7 +613,7 @@ __global__ void __launch_bounds__(64 * MWW, DSB_WAVES_PER_EU) k_classify_heavy(D
 		w.spset = (uint64_t *)(slot + ar.off_spset);
 		w.score_v = (int *)(slot + ar.off_scorev);
 		w.sortkey = (uint64_t *)(slot + ar.off_sortkey); w.sortidx = (uint32_t *)(slot + ar.off_sortidx);
-		w.win_mid = slot + ar.off_win; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
+		w.win_mid = slot + ar.off_win + DSB_REFWIN_FRONT; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
 		w.lane_anc = (DsbAnchor *)(slot + ar.off_lane_anc); w.lane_spset = (uint64_t *)(slot + ar.off_lane_sp);
 		w.top_idx = (uint32_t *)(slot + ar.off_top); w.round_info = (uint32_t *)(slot + ar.off_round);
 		w.anc_cap = ar.anc_cap; w.anc_cap_main = ar.anc_cap; w.hit_cap = ar.hit_cap; w.step_limit = x.step_limit; w.heavy_limit = 0; w.sp_gen = 0;
@@ -1099,7 +1099,7 @@ static size_t arena_layout(DsbSlotArena &a, uint32_t max_len, int group, uint32_
 	a.off_scorev = o;  o += al256((size_t)1024 * sizeof(int));
 	a.off_sortkey = o; o += al256((size_t)2 * anc_cap * sizeof(uint64_t));
 	a.off_sortidx = o; o += al256((size_t)2 * anc_cap * sizeof(uint32_t));
-	a.off_win = o;     o += al256((size_t)3 * DSB_REFWIN);
+	a.off_win = o;     o += al256((size_t)3 * DSB_REFWIN + DSB_REFWIN_FRONT);
 	a.off_lane_anc = o; o += al256((size_t)group * DSB_LANE_ANC_CAP * sizeof(DsbAnchor));
 	a.off_lane_sp = o;  o += al256((size_t)group * DSB_SPHASH * 8);
 	a.off_top = o;      o += al256(((size_t)(max_len >> 1) + 64) * 4);

@@ -35,12 +35,27 @@
 #define DSB_SCAN_DONE 4u
 #define DSB_SCAN_NONE 0xffffffffu
 #define DSB_SCAN_W 8           /* windows a lane asks for per round */
+#ifndef DSB_SCAN_SPEC_AFTER_SEED
+#define DSB_SCAN_SPEC_AFTER_SEED 4u
+#endif
+#ifndef DSB_SCAN_BACK_FWD
+#define DSB_SCAN_BACK_FWD 2      /* forward windows asked for together with the two behind a hit (<= DSB_SCAN_W - 2) */
+#endif
+#ifndef DSB_SCAN_FWD_N
+#define DSB_SCAN_FWD_N 4         /* windows per round while a run of hits is followed (<= DSB_SCAN_W) */
+// (Round 3 asked for 6 and 8: on the demo index, whose tables are 1 % full, a run of hits is a true seed and goes on; on a viral-RefSeq-
+// sized index (20 % full, a window in 25 a false positive) most runs end after a window or two, and every window asked for behind the
+// first miss is a probe the reference's scan never makes: 1.52 x the reference's table-0 probes there, 1.31 x with 2 and 4 -- and the
+// kernel, which runs at the random-gather ceiling of the memory system, is 9.5 % faster: 104.0 -> 94.1 ms per 65536 x 50 kbp; the demo
+// index is unchanged.  tools note: /tmp-free CPU measurement through tests/emu (emu_scan_seeds) against the oracle's P0.)
+#endif
 
 struct DsbScan {
 	uint32_t n;                 // windows of the strand
 	uint32_t i;                 // stride position (mirrored coordinates for the reverse strand)
 	uint32_t mode;
 	uint32_t off, len, j;       // the seed being extended; next forward window
+	uint32_t spec;              // stride points asked for per round: DSB_SCAN_W, fewer right behind a seed (see dsb_scan_want)
 	// get_seed_vector_M2's marking of the best seed per 100-window bin (src/cly.c:1200-1234), run on each seed as it is made
 	uint32_t ns, total, max_index, max_length, index_end, cur_top;
 };
@@ -48,7 +63,7 @@ struct DsbScan {
 DSB_SCAN_FN void dsb_scan_init(DsbScan &s, uint32_t n)
 {
 	s.n = n; s.i = 2; s.mode = n > 2 ? DSB_SCAN_STRIDE : DSB_SCAN_DONE;
-	s.off = s.len = s.j = 0;
+	s.off = s.len = s.j = 0; s.spec = DSB_SCAN_W;
 	s.ns = 0; s.total = 0; s.max_index = 0; s.max_length = 0; s.index_end = 100; s.cur_top = 0;
 }
 
@@ -60,17 +75,19 @@ DSB_SCAN_FN void dsb_scan_want(const DsbScan &s, uint32_t (&want)[DSB_SCAN_W])
 #pragma unroll
 	for (int t = 0; t < DSB_SCAN_W; t++) want[t] = DSB_SCAN_NONE;
 	if (s.mode == DSB_SCAN_STRIDE) {
-		// the next eight stride points: 93 % of them miss, so little of the look-ahead is wasted
+		// the next stride points: eight while they miss (on the demo index 93 % do, little of the look-ahead is wasted); only
+		// DSB_SCAN_SPEC_AFTER_SEED right behind a seed -- seeds come in clusters (the matching stretch of the read: on an index whose
+		// tables are 20 % full a stride point in nine hits), and every point behind the first hit of a round is a probe the reference's scan never makes
 #pragma unroll
-		for (int t = 0; t < DSB_SCAN_W; t++) { const uint32_t p = s.i + 3u * (uint32_t)t; if (p < s.n) want[t] = p; }
+		for (int t = 0; t < DSB_SCAN_W; t++) { const uint32_t p = s.i + 3u * (uint32_t)t; if ((uint32_t)t < s.spec && p < s.n) want[t] = p; }
 	} else if (s.mode == DSB_SCAN_BACK) {
 		// around a hit at i: two back (i >= 2 at every hit), and the run forward
 		want[0] = s.i - 1; want[1] = s.i - 2;
 #pragma unroll
-		for (int t = 2; t < DSB_SCAN_W; t++) { const uint32_t p = s.i + (uint32_t)(t - 1); if (p < s.n) want[t] = p; }
+		for (int t = 2; t < 2 + DSB_SCAN_BACK_FWD; t++) { const uint32_t p = s.i + (uint32_t)(t - 1); if (p < s.n) want[t] = p; }
 	} else if (s.mode == DSB_SCAN_FWD) {
 #pragma unroll
-		for (int t = 0; t < DSB_SCAN_W; t++) { const uint32_t p = s.j + (uint32_t)t; if (p < s.n) want[t] = p; }
+		for (int t = 0; t < DSB_SCAN_FWD_N; t++) { const uint32_t p = s.j + (uint32_t)t; if (p < s.n) want[t] = p; }
 	}
 }
 
@@ -91,17 +108,17 @@ DSB_SCAN_FN void dsb_scan_emit(DsbScan &s, bool rc, Store &store, Mark &mark)
 		s.index_end += 100; s.total += s.max_length; s.max_index = s.ns; s.max_length = l;
 	}
 	s.ns++;
-	s.i = s.off + l + 3; s.mode = s.i < s.n ? DSB_SCAN_STRIDE : DSB_SCAN_DONE;
+	s.i = s.off + l + 3; s.mode = s.i < s.n ? DSB_SCAN_STRIDE : DSB_SCAN_DONE; s.spec = DSB_SCAN_SPEC_AFTER_SEED;
 }
 
 // the run of hits in bits[from ..] (bit t = window want[t]): extends the seed, at most to 61 windows (src/cly.c:1100);
 // returns true if the run reached the last slot and may go on
-DSB_SCAN_FN bool dsb_scan_run(DsbScan &s, uint32_t bits, int from)
+DSB_SCAN_FN bool dsb_scan_run(DsbScan &s, uint32_t bits, int from, int slots)
 {
-	const uint32_t run = (uint32_t)__builtin_ctz(~(bits >> from) | (1u << (DSB_SCAN_W - from)));   // consecutive set bits, <= W - from
+	const uint32_t run = (uint32_t)__builtin_ctz(~(bits >> from) | (1u << slots));   // consecutive set bits among the `slots` windows asked for
 	const uint32_t room = 61u - s.len, take = run < room ? run : room;
 	s.len += take; s.j += take;
-	return take == (uint32_t)(DSB_SCAN_W - from) && s.len < 61 && s.j < s.n;
+	return take == (uint32_t)slots && s.len < 61 && s.j < s.n;
 }
 
 // bits: bit t = window want[t] hit (0 for unused slots)
@@ -110,13 +127,13 @@ DSB_SCAN_FN void dsb_scan_consume(DsbScan &s, uint32_t bits, bool rc, Store &sto
 {
 	if (s.mode == DSB_SCAN_STRIDE) {
 		if (bits) { s.i += 3u * (uint32_t)__builtin_ctz(bits); s.mode = DSB_SCAN_BACK; }
-		else { s.i += 3u * DSB_SCAN_W; if (s.i >= s.n) s.mode = DSB_SCAN_DONE; }
+		else { s.i += 3u * s.spec; s.spec = DSB_SCAN_W; if (s.i >= s.n) s.mode = DSB_SCAN_DONE; }
 	} else if (s.mode == DSB_SCAN_BACK) {
 		const uint32_t back = (bits & 1u) ? ((bits & 2u) ? 2u : 1u) : 0u;
 		s.off = s.i - back; s.len = 1 + back; s.j = s.i + 1;
-		if (dsb_scan_run(s, bits, 2)) s.mode = DSB_SCAN_FWD; else dsb_scan_emit(s, rc, store, mark);
+		if (dsb_scan_run(s, bits, 2, DSB_SCAN_BACK_FWD)) s.mode = DSB_SCAN_FWD; else dsb_scan_emit(s, rc, store, mark);
 	} else if (s.mode == DSB_SCAN_FWD) {
-		if (!dsb_scan_run(s, bits, 0)) dsb_scan_emit(s, rc, store, mark);
+		if (!dsb_scan_run(s, bits, 0, DSB_SCAN_FWD_N)) dsb_scan_emit(s, rc, store, mark);
 	}
 }
 

@@ -2,13 +2,13 @@
 // (dsb_classify_dev.h) compiles unchanged for the host (-DDSB_HOST_EMU).  Included in place of dsb_wave.h, inside namespace DSB_NS.
 //
 //   DSB_EMU_LANES == 1 (default)  one lane: every cross-lane operation is the identity.  Fast; checks the per-read logic.
-//   DSB_EMU_LANES == 64           64 lanes as cooperative fibers (tests/emu/emu_fiber.cpp).  A lane runs until it reaches a
-//       cross-lane operation (wave_sync, ballot, shuffle, scan, maximum), then the next lane runs; when all 64 have arrived the
-//       operation's result is formed and the lanes go on.  Between two such points the lanes do NOT run in lockstep: lane 0 is
-//       a whole stretch ahead of lane 63 (or behind it: DSB_EMU_ORDER=rev) -- a weaker model than the hardware's, so a store
-//       that another lane reads without a wave_sync() in between shows as a wrong result here even where lockstep hides it on
-//       the GPU.  The emulation aborts when the lanes of a wave arrive at different operations (a cross-lane operation in
-//       divergent control flow) or when some lanes finish while others wait.  ASan / UBSan see every lane's indexing.
+//   DSB_EMU_LANES == 64           64 lanes as fibers on a bulk-synchronous machine with a race detector (tests/emu/emu_simt.cpp; the
+//       device code is then compiled with -fsanitize=thread for its instrumentation hooks, which that file implements).  A lane runs
+//       from one cross-lane operation (wave_sync, ballot, shuffle, scan, maximum) to the next alone, on the memory of the stretch's
+//       start; the lanes' stores are put in place together when all 64 have arrived.  Code written to the wavefront memory model
+//       (lanes exchange data only across a wave_sync) gives the GPU's results; stores of different values to one place, reads of what
+//       another lane changes in the same stretch, accesses outside the registered arrays and cross-lane operations in divergent control
+//       flow are reported.
 #ifndef DSB_EMU_LANES
 #define DSB_EMU_LANES 1
 #endif
@@ -38,11 +38,13 @@ template <class T> static inline T dsb_shfl(T v, int) { return v; }
 DV uint32_t dsb_shfl_var(uint32_t v, int) { return v; }
 DV uint32_t dsb_shfl_up1(uint32_t v) { return v; }
 #else
-// emu_fiber.cpp: the lane that is running, and the exchange all cross-lane operations are made of -- every lane hands in a
+// emu_simt.cpp: the lane that is running, and the exchange all cross-lane operations are made of -- every lane hands in a
 // value and gets the 64 values of the wave back (`site` names the call: all lanes must be at the same one)
 extern "C" int dsb_emu_cur_lane;
 extern "C" const uint64_t *dsb_emu_exchange(uint64_t v, int site);
 extern "C" void dsb_emu_run(void (*fn)(void *), void *arg);
+extern "C" void dsb_emu_regions_clear(void);
+extern "C" void dsb_emu_region(const void *p, size_t n, const char *name);
 #define DSB_LANE dsb_emu_cur_lane
 DV void wave_sync() { dsb_emu_exchange(0, 1); }
 DV void block_sync() { dsb_emu_exchange(0, 2); }      // (one wavefront per workgroup in the emulation)
@@ -65,10 +67,19 @@ DV void dsb_setprio3() {}
 #define DSB_RFL(v) (v)
 #define DSB_RFL64(v) (v)
 
-// LDS atomics: fibers are switched only at cross-lane operations, so a read-modify-write is atomic as it stands
+#if DSB_EMU_LANES == 1
 DV uint32_t lds_add(lds_u32 *p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 DV void lds_or(lds_u32 *p, uint32_t v) { *p |= v; }
 DV uint32_t lds_cas(lds_u32 *p, uint32_t expect, uint32_t desired) { const uint32_t o = *p; if (o == expect) *p = desired; return o; }
+#else
+// LDS atomics act on memory at once, in lane order, outside the undo log of the stretch (emu_simt.cpp)
+extern "C" uint32_t dsb_emu_atomic_add(uint32_t *p, uint32_t v);
+extern "C" void dsb_emu_atomic_or(uint32_t *p, uint32_t v);
+extern "C" uint32_t dsb_emu_atomic_cas(uint32_t *p, uint32_t expect, uint32_t desired);
+DV uint32_t lds_add(lds_u32 *p, uint32_t v) { return dsb_emu_atomic_add(p, v); }
+DV void lds_or(lds_u32 *p, uint32_t v) { dsb_emu_atomic_or(p, v); }
+DV uint32_t lds_cas(lds_u32 *p, uint32_t expect, uint32_t desired) { return dsb_emu_atomic_cas(p, expect, desired); }
+#endif
 DV void lds_fill4(lds_u32 *p, uint32_t v) { p[0] = p[1] = p[2] = p[3] = v; }
 DV uint4 ring_ld(const uint4 *ring, uint32_t i) { return ring[i]; }
 DV void ring_st(uint4 *ring, uint32_t i, uint4 v) { ring[i] = v; }

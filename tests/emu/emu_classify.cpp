@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE: runs the DEVICE code of desamba_amd (dsb_classify_dev.h, dsb_probe.h) on the
 // host (-DDSB_HOST_EMU) -- as a 1-lane wave (libdsbemu.so: fast, the per-read logic) or as 64 lanes on cooperative
-// fibers (-DDSB_EMU_LANES=64 + emu_fiber.cpp, libdsbemu64.so: every cross-lane operation, every lane's indexing) -- so
+// fibers with a race detector (-DDSB_EMU_LANES=64 -fsanitize=thread + emu_simt.cpp, libdsbemu64.so: every cross-lane operation, every lane's indexing) -- so
 // it can be checked against the oracle with `pytest -m "not gpu"`, gdb and sanitizers.  Not linked into libdesamba_amd.so.
 #include <stdio.h>
 #include <stdlib.h>
@@ -13,7 +13,10 @@
 #include "dsb_host.h"
 using namespace dsb_g64;
 
+struct EmuRegion { const void *p; size_t n; const char *name; };
 struct EmuCtx {
+	std::vector<EmuRegion> regions;       // the arrays a lane may touch (64-lane emulation: emu_simt.cpp checks every access against them)
+	dsb_index *idx = nullptr;
 	DsbDevIndex dx; std::vector<uint8_t> arena; uint32_t max_len; WCtx w; size_t sms_off;
 	std::vector<uint8_t> bin; std::vector<uint64_t> pk, bits;
 	std::vector<DsbSeed> seedsF, seedsR;
@@ -26,7 +29,7 @@ static size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 extern "C" void *emu_new(dsb_index *idx, int min_len, int min_score)
 {
 	const DsbHostIndex *h = dsb_index_host(idx);
-	EmuCtx *e = new EmuCtx();
+	EmuCtx *e = new EmuCtx(); e->idx = idx;
 	DsbDevIndex &dx = e->dx; memset(&dx, 0, sizeof dx);
 	dx.ek0 = h->ek0; dx.ek1 = h->ek1; dx.ek_mask = h->ek_mask; dx.ek_len = h->ek_len; dx.single_base_max = h->single_base_max;
 	dx.fm = h->fm; dx.fm_sb = h->fm_sb; dx.bwt_len = h->bwt_len; memcpy(dx.rank, h->rank, sizeof dx.rank); dx.dollar_pos = h->dollar_pos; dx.dollar_row = h->dollar_row;
@@ -43,8 +46,8 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	if (L <= e->max_len) return;
 	e->max_len = L + L / 4 + 1024;
 	e->dx.sms_cap = getenv("DSB_EMU_SMS_CAP") ? (uint32_t)atol(getenv("DSB_EMU_SMS_CAP")) : dsb_sms_cap_for(e->max_len);
-	size_t o = 0, off[20]; int k = 0;
-	auto add = [&](size_t n) { off[k++] = o; o += al(n); };
+	size_t o = 0, off[20], len[20]; int k = 0;
+	auto add = [&](size_t n) { len[k] = n; off[k++] = o; o += al(n); };
 	add(((size_t)(e->max_len >> 1) + 64) * sizeof(DsbSeed));            // 0 seeds
 	add((size_t)DSB_ANC_CAP * sizeof(DsbAnchor)); add((size_t)DSB_ANC_CAP * sizeof(DsbAnchor));  // 1,2
 	add((size_t)DSB_HIT_CAP * sizeof(DsbChain)); add((size_t)DSB_HIT_CAP * sizeof(DsbChain));    // 3,4
@@ -54,19 +57,25 @@ static void setup_arena(EmuCtx *e, uint32_t L)
 	add((size_t)DSB_MEMSLOW_CAP * sizeof(DsbMem));                       // 8
 	add((size_t)DSB_SPHASH * 8); add(1024 * sizeof(int));                // 9,10
 	add((size_t)2 * DSB_ANC_CAP * 8); add((size_t)2 * DSB_ANC_CAP * 4);  // 11,12
-	add(3 * DSB_REFWIN);                                                 // 13
+	add(3 * DSB_REFWIN + DSB_REFWIN_FRONT);                                                 // 13
 	add((size_t)DSB_WAVE * DSB_LANE_ANC_CAP * sizeof(DsbAnchor)); add((size_t)DSB_WAVE * DSB_SPHASH * 8); add(((size_t)(e->max_len >> 1) + 64) * 4);   // 14,15,16 (per-lane scratch)
 	add(((size_t)(e->max_len >> 1) + 64) * 4);                           // 17 island records of fast_classify
 	e->arena.assign(o + 256, 0xCD);
 	memset(e->arena.data() + off[9], 0, DSB_SPHASH * 8); memset(e->arena.data() + off[15], 0, (size_t)DSB_WAVE * DSB_SPHASH * 8); e->w.sp_gen = 0;
 	uint8_t *s = e->arena.data(); WCtx &w = e->w;
+	{
+		static const char *nm[18] = {"seeds", "anchors", "anchors (copy)", "chains", "chains (copy)", "match nodes", "(unused)", "chain-end hash", "slow-path MEMs", "visited rows", "score_v",
+		                            "sort keys", "sort indices", "reference windows", "lane anchors", "lane visited rows", "top islands", "island records"};
+		e->regions.clear();
+		for (int i = 0; i < k && i < 18; i++) e->regions.push_back(EmuRegion{s + off[i], len[i], nm[i]});
+	}
 	w.x = &e->dx; w.dbg = nullptr;
 	w.seeds = (DsbSeed *)(s + off[0]); w.anc = (DsbAnchor *)(s + off[1]); w.anc_tmp = (DsbAnchor *)(s + off[2]);
 	w.hit = (DsbChain *)(s + off[3]); w.hit_tmp = (DsbChain *)(s + off[4]); w.sms = (DsbSms *)(s + off[5]);
 	alignas(16) static uint32_t emu_wtab[DSB_WTAB_SLOTS]; w.wtab = emu_wtab;
 	w.sc = (DsbScHash *)(s + off[7]); w.mem_slow = (DsbMem *)(s + off[8]); w.spset = (uint64_t *)(s + off[9]); w.score_v = (int *)(s + off[10]);
 	w.sortkey = (uint64_t *)(s + off[11]); w.sortidx = (uint32_t *)(s + off[12]);
-	w.win_mid = s + off[13]; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
+	w.win_mid = s + off[13] + DSB_REFWIN_FRONT; w.win_right = w.win_mid + DSB_REFWIN; w.win_left = w.win_right + DSB_REFWIN;
 	static uint4 emu_ring[DSB_RING]; w.ring = emu_ring; static DpBatch emu_dpb; w.dpb = &emu_dpb;
 	static uint32_t emu_red[4]; w.red = emu_red; w.round_info = (uint32_t *)(s + off[17]);
 	w.lane_anc = (DsbAnchor *)(s + off[14]); w.lane_spset = (uint64_t *)(s + off[15]); w.top_idx = (uint32_t *)(s + off[16]); w.anc_cap = DSB_ANC_CAP;
@@ -112,6 +121,20 @@ extern "C" int emu_classify(void *p, const char *seq, uint32_t L, int hist_max, 
 	w.pre_seeds = nullptr; w.pre_info = nullptr; w.pk[0] = getenv("DSB_EMU_NO_GAP_LANE") ? nullptr : e->pk.data(); w.pk[1] = w.pk[0] ? w.pk[0] + nw : nullptr;
 #if DSB_EMU_LANES == 64
 	struct Job { WCtx *w; const uint64_t *bF, *bR; } job = {&w, e->bits.data(), e->bits.data() + n_words};
+	{	// every array a lane may touch, by name
+		const DsbHostIndex *h = dsb_index_host(e->idx);
+		dsb_emu_regions_clear();
+		for (const EmuRegion &r : e->regions) dsb_emu_region(r.p, r.n, r.name);
+		dsb_emu_region(&job, sizeof job, "job"); dsb_emu_region(e, sizeof *e, "context (WCtx, index descriptor, counters)");
+		dsb_emu_region(w.wtab, 4 * DSB_WTAB_SLOTS, "LDS window table"); dsb_emu_region(w.ring, sizeof(uint4) * DSB_RING, "LDS ring"); dsb_emu_region(w.dpb, sizeof(DpBatch), "LDS DP batch"); dsb_emu_region(w.red, 16, "LDS red");
+		dsb_emu_region(e->bin.data(), e->bin.size(), "byte strands"); dsb_emu_region(e->pk.data(), 8 * e->pk.size(), "packed strands"); dsb_emu_region(e->bits.data(), 8 * e->bits.size(), "hit bits");
+		dsb_emu_region(h->ek0, h->ek_size, "filter table 0"); dsb_emu_region(h->ek1, h->ek_size, "filter table 1"); dsb_emu_region(h->fm, h->n_fm * sizeof(DsbFmBlock), "rank lines");
+		if (h->fm_sb) dsb_emu_region(h->fm_sb, h->n_fm_sb * 40, "rank superblocks");
+		if (h->hash_c) dsb_emu_region(h->hash_c, (size_t)h->n_hash_c * sizeof(DsbHiLine), "13-mer table (compressed)"); else dsb_emu_region(h->hash_index, (((size_t)1 << 26) + 1) * 8, "13-mer table");
+		dsb_emu_region(h->sa, h->sa_size * 8, "SA samples"); dsb_emu_region(h->uni, (h->n_uni + 1) * 8, "unitigs"); dsb_emu_region(h->refpos, (h->n_refpos + 1) * 8, "reference positions");
+		dsb_emu_region(h->refbin, h->n_refbin + 4096, "reference text"); dsb_emu_region(h->refinfo, h->n_ref * sizeof(DsbRefInfo), "reference info");
+		dsb_emu_region(h->Q_MEM, 2000 * sizeof(int), "Q_MEM"); dsb_emu_region(&h->Q_LV[0][0], 400 * sizeof(int), "Q_LV");
+	}
 	dsb_emu_run([](void *a) { Job *j = (Job *)a; classify_read<false>(*j->w, j->bF, j->bR); }, &job);
 #else
 	classify_read<false>(w, e->bits.data(), e->bits.data() + n_words);
@@ -136,6 +159,29 @@ extern "C" int emu_seeds(void *p, int strand, DsbSeed *out, int max_out, uint32_
 	if (total) *total = sd->total_score;
 	return (int)sd->l_seed_v;
 }
+
+#if DSB_EMU_LANES == 64
+// the detector on four tiny kernels: 0 clean (a sync between the exchange), 1 conflicting stores, 2 a read of what the neighbour
+// writes in the same stretch, 3 a store behind the registered array; -> number of findings, their text in out
+extern "C" int dsb_emu_findings(char *out, size_t cap);
+extern "C" int emu_selftest(int what, char *out, size_t cap)
+{
+	static uint32_t shared[128];
+	struct J { uint32_t *s; int what; } j = {shared, what};
+	dsb_emu_regions_clear(); dsb_emu_region(shared, 64 * 4, "selftest array (64 words)"); dsb_emu_region(&j, sizeof j, "job");
+	memset(shared, 0, sizeof shared);
+	dsb_emu_findings(nullptr, 0);
+	dsb_emu_run([](void *a) {
+		J *j = (J *)a; const int lane = DSB_LANE;
+		if (j->what == 0) { j->s[lane] = (uint32_t)lane; wave_sync(); j->s[63 - lane] += 1; }
+		if (j->what == 1) j->s[0] = (uint32_t)lane;
+		if (j->what == 2) { j->s[lane] = 7; j->s[lane] += j->s[(lane + 1) & 63]; }
+		if (j->what == 3) j->s[lane + 64] = 1;
+	}, &j);
+	if (what == 0) for (int i = 0; i < 64; i++) if (shared[i] != (uint32_t)i + 1) return -1;
+	return dsb_emu_findings(out, cap);
+}
+#endif
 
 #ifdef EMU_MAIN
 int main(int argc, char **argv)

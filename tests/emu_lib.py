@@ -28,6 +28,8 @@ class Emu:
         L.emu_sms_peak.argtypes = [C.c_void_p]; L.emu_sms_peak.restype = C.c_uint32
         L.emu_seeds.argtypes = [C.c_void_p, C.c_int, C.POINTER(EmuSeed), C.c_int, C.POINTER(C.c_uint32)]
         L.emu_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        if hasattr(L, "dsb_emu_findings"):
+            L.dsb_emu_findings.argtypes = [C.c_char_p, C.c_size_t]; L.dsb_emu_findings.restype = C.c_int
         L.emu_scan_seeds.argtypes = [C.c_void_p, C.c_int, C.POINTER(EmuSeed), C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         self.L = L
         self.idx = C.c_void_p()
@@ -46,6 +48,14 @@ class Emu:
             raise RuntimeError("device-code status %#x" % (-n))
         hits = [self.buf[i].key() for i in range(min(n, 512))]
         return (hits, bF, bR) if want_bits else hits
+
+    def findings(self):
+        """64-lane emulation (tests/emu/emu_simt.cpp): what the race detector found since the last call -> list of text lines"""
+        if not hasattr(self.L, "dsb_emu_findings"):
+            return []
+        buf = C.create_string_buffer(1 << 16)
+        self.L.dsb_emu_findings(buf, len(buf))
+        return [l for l in buf.value.decode().split("\n") if l]
 
     def n_anc(self):
         return int(self.L.emu_n_anc(self.e))
