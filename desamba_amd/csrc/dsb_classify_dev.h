@@ -2399,6 +2399,9 @@ DV int sdp_best_pred_b(WCtxL &w, DpBatchL &b, const DsbSms &cs, int32_t cur, con
 //    stopping at the first predecessor p that meets the cut takes the maximum over the predecessors newer than p; in ascending order
 //    that is "forget what you have when a predecessor meets the cut" -- which also discards the old predecessors, all of them older.
 // Same maxima as the reference's loop, everything in registers.  MODE 1 = right, 2 = left (sdp_judge).
+#ifndef DSB_BLK_CHUNKS
+#define DSB_BLK_CHUNKS 1
+#endif
 template <int MODE>
 DN int sdp_block_scores(WCtxL &w, const uint32_t n0_, const uint32_t m_, const DsbSms cs)
 {
@@ -2425,8 +2428,13 @@ DN int sdp_block_scores(WCtxL &w, const uint32_t n0_, const uint32_t m_, const D
 	const int NS = (int)((psc) + nl - (uint32_t)(ai_ >> 3) - (uint32_t)ov_);                                                  \
 	const bool OK = !sk_ & !BRK & (ai_ <= 200);
 	// old predecessors, newest first: the first chunk of 64 one node per lane ...
+	TX0(w, t_old);
 	int32_t hi = (int32_t)n0 - 1;
-	if (hi >= 0) {
+	bool all_done = false;
+	// (DSB_BLK_CHUNKS chunks of 64 this way.  One is enough: measured on the headline workload, the blocks that do not end within 64
+	// predecessors -- one window in ten -- do not end within 192 or 384 either: they are the windows of tandem repeats, hundreds of
+	// nodes at one reference position whose scan the reference also runs to the start of the list; 1 / 3 / 6 chunks: 351 / 353 / 353 ms)
+	for (int ch = 0; ch < DSB_BLK_CHUNKS && hi >= 0 && !all_done; ch++) {
 		const int32_t pi = hi - lane;
 		DsbSms o; o.t_pos = o.q_pos = o.len = o.score = 0;
 		if (pi >= 0) o = sms[pi];
@@ -2440,7 +2448,7 @@ DN int sdp_block_scores(WCtxL &w, const uint32_t n0_, const uint32_t m_, const D
 				best = (!done & ok & (ns > best)) ? ns : best;
 				done |= brk;
 				preds += DSB_WAVE;                                 // (what the hand-over limit prices is the wavefront's time: a round costs the same however many lanes hold a node)
-				if (dsb_ballot64(!done) == 0) break;
+				if (dsb_ballot64(!done) == 0) { all_done = true; break; }
 			}
 		} else {
 			for (int k = 0; k < cnt; k++) {
@@ -2448,7 +2456,7 @@ DN int sdp_block_scores(WCtxL &w, const uint32_t n0_, const uint32_t m_, const D
 				bool skip, brk; int ns; sdp_judge<MODE>(cs, ps, lim_q, lim_t, skip, brk, ns);
 				if (!done) { if (brk) done = true; else if (!skip && ns > best) best = ns; }
 				preds += DSB_WAVE;
-				if (dsb_ballot64(!done) == 0) break;
+				if (dsb_ballot64(!done) == 0) { all_done = true; break; }
 			}
 		}
 		hi -= DSB_WAVE;
@@ -2456,7 +2464,9 @@ DN int sdp_block_scores(WCtxL &w, const uint32_t n0_, const uint32_t m_, const D
 	// ... and for the nodes that have not met their distance cut there (repeats: more than 64 nodes within 600 bases), the rest of the
 	// list with the lanes over the predecessors, eight nodes at a time (sdp_batch_old)
 	uint64_t left = dsb_ballot64(!done);
+	TX0(w, t_deep);
 	if (hi >= 0 && left) {
+		TXC(w, 7);
 		DpBatchL &b = *w.dpb;
 		while (left) {
 			int id[DSB_DPB]; uint32_t K = 0;
@@ -2470,6 +2480,9 @@ DN int sdp_block_scores(WCtxL &w, const uint32_t n0_, const uint32_t m_, const D
 			wave_sync();
 		}
 	}
+	TX1(w, 9, t_deep);
+	TX1(w, 2, t_old);
+	TX0(w, t_in);
 	// predecessors inside the block, in ascending order
 	if (m > 1) {
 		const uint32_t cA = MODE == 2 ? cs.q_pos : cs.q_pos + cs.len + 8, cB = MODE == 2 ? cs.t_pos : cs.t_pos + cs.len + 8, cC = MODE == 2 ? cs.t_pos : cs.t_pos + 600;
@@ -2492,6 +2505,8 @@ DN int sdp_block_scores(WCtxL &w, const uint32_t n0_, const uint32_t m_, const D
 		}
 	}
 #undef DSB_BLK_PLAIN
+	TX1(w, 6, t_in);
+	if (w.dbg) w.tx[8] += preds / DSB_WAVE;
 	w.dp_preds += preds + m * DSB_WAVE;
 	DSB_HEAVY_CHECK(w);
 	return best;
@@ -2848,7 +2863,6 @@ DN int sdp_right_M2_mw(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, Dsb
 			max_search_ref = MINV(600u, max_search_ref);
 			get_ref_wave(x->refbin, x->ref_bases, DSB_LANE, ref, c_t_offset + t_offset_global, max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50);
 			wave_sync();
-			TXC(w, 7);
 			int search_q_ed = (int)best_q + 1000;
 			search_q_ed = MINV((uint32_t)search_q_ed, l_read);
 			int search_q_st = MAXV((uint32_t)(search_q_ed - 2000), ch_q_st - 8);
@@ -2941,7 +2955,6 @@ DN int sdp_left_M2_mw(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbC
 			int search_q_st = (int)best_q - 1000;
 			search_q_st = MAXV(search_q_st, 0);
 			int search_q_ed = MINV((uint32_t)(search_q_st + 2000), ch_q_st - 1);
-			TXC(w, 9);
 			TX0(w, t_lm);
 			sdp_match(w, search_q_st, search_q_ed, q_str, ref + 50, max_search_ref, key_len, tbl, c_t_offset - max_search_ref, false);
 			TX1(w, 3, t_lm);
@@ -3056,7 +3069,6 @@ DN int sdp_right_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbCha
 			max_search_ref = MINV(600u, max_search_ref);
 			get_ref_wave(x->refbin, x->ref_bases, DSB_LANE, ref, c_t_offset + t_offset_global, max_search_ref + 50); cnt_add(Cnt{w.k.c, 1u}, 3, max_search_ref + 50);
 			wave_sync();
-			TXC(w, 7);
 			int search_q_ed = (int)e.best_q + 1000;
 			search_q_ed = MINV((uint32_t)search_q_ed, l_read);
 			int search_q_st = MAXV((uint32_t)(search_q_ed - 2000), ch_q_st - 8);
@@ -3137,7 +3149,6 @@ DN int sdp_left_M2(WCtxL &w, const uint8_t *q_str, int tbl, int key_len, DsbChai
 			int search_q_st = (int)e.best_q - 1000;
 			search_q_st = MAXV(search_q_st, 0);
 			int search_q_ed = MINV((uint32_t)(search_q_st + 2000), ch_q_st - 1);
-			TXC(w, 9);
 			TX0(w, t_lm);
 			sdp_match(w, search_q_st, search_q_ed, q_str, ref + 50, max_search_ref, key_len, tbl, c_t_offset - max_search_ref, false);
 			TX1(w, 3, t_lm);

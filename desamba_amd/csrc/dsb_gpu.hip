@@ -1608,8 +1608,8 @@ static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn)
 		for (unsigned sI = 0; sI < sl; sI++) { for (int i = 0; i < 10; i++) { tot[i] += c->dbg_host[4 * 65536 + 14 * sI + i]; all += c->dbg_host[4 * 65536 + 14 * sI + i]; } for (int i = 0; i < 4; i++) sub[i] += c->dbg_host[4 * 65536 + 14 * sI + 10 + i]; }
 		fprintf(stderr, "[dsb] inside sdp_right (ms, -DDSB_TIMERS builds): sdp_match %.1f  dp %.1f  combine %.1f | fast_classify commit phase %.1f\n", sub[0] / 1e3, sub[1] / 1e3, sub[2] / 1e3, sub[3] / 1e3);
 		{ double tx[10] = {0}; for (unsigned sI = 0; sI < sl; sI++) for (int i = 0; i < 10; i++) tx[i] += c->dbg_host[8 * 65536 + 10 * sI + i];
-		  fprintf(stderr, "[dsb] fine (ms, -DDSB_TIMERS builds): table build %.1f  probe %.1f  dp old pass %.1f  sdp_match in sdp_left %.1f  dp in sdp_left %.1f  gap-per-lane phase of sdp_middle %.1f | counts: dp batches %.0f  windows(right) %.0f  nodes(right) %.0f  windows(left) %.0f\n",
-		          tx[0] / 1e3, tx[1] / 1e3, tx[2] / 1e3, tx[3] / 1e3, tx[4] / 1e3, tx[5] / 1e3, tx[6], tx[7], tx[8], tx[9]); }
+		  fprintf(stderr, "[dsb] fine (ms, -DDSB_TIMERS builds): table build %.1f  probe %.1f  block DP: old predecessors %.1f, inside the block %.1f  sdp_match in sdp_left %.1f  dp in sdp_left %.1f  gap-per-lane phase of sdp_middle %.1f | of the old predecessors: beyond the first 64 (sdp_batch_old) %.1f in %.0f blocks; rounds over the first 64: %.0f\n",
+		          tx[0] / 1e3, tx[1] / 1e3, tx[2] / 1e3, tx[6] / 100.0 / 1e3, tx[3] / 1e3, tx[4] / 1e3, tx[5] / 1e3, tx[9] / 100.0 / 1e3, tx[7], tx[8]); }
 		{	// stage split of the slowest read of the batch (as it ran, i.e. under load)
 			size_t worst = 0; uint64_t wsum = 0;
 			for (size_t r = 0; r < n && r < 65536; r++) { uint64_t sm = 0; for (int i = 0; i < 10; i++) sm += c->dbg_host[16 * 65536 + 14 * r + i]; if (sm > wsum) { wsum = sm; worst = r; } }

@@ -248,3 +248,21 @@ def test_gpu_gbp_scale_index_against_the_reference(tmp_path):
     a = open(tmp_path / "gpu.sam", "rb").read(); b = open(tmp_path / "ref.sam", "rb").read()
     assert a.count(b"\n") > 2048 and a == b
     shutil.rmtree(out)
+
+
+@pytest.mark.gpu
+def test_gpu_headline_index_reads_decided_by_the_read_buffer_pad(tmp_path):
+    """tests/golden/synth/u1_flagpair.*: the two reads of the headline batch whose printed secondaries differ between the stock reference
+    and its UB-pinned build (one pad byte shifts every score of the read by 1, the reference's parity tie-break then prints another
+    five of a dozen tied hits: u1_flagpair.txt).  On the headline index, built here, this repo prints the UB-pinned lines."""
+    import desamba_amd as D
+    fa = str(tmp_path / "syn.fa"); out = str(tmp_path / "idx")
+    subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "synth_ref.py"), fa, "320", "11", "3", "60", "12"], check=True, stderr=subprocess.DEVNULL)
+    D.build_index(fa, out)
+    os.remove(fa)
+    g = os.path.join(ROOT, "tests", "golden", "synth", "u1_flagpair")
+    sam = str(tmp_path / "o.sam")
+    subprocess.run([os.path.join(ROOT, "desamba_amd", "bin", "deSAMBA"), "classify", out, g + ".fq", "-o", sam], check=True, stderr=subprocess.DEVNULL)
+    got = open(sam, "rb").read()
+    assert got == open(g + ".ubfree.sam", "rb").read()
+    assert got != open(g + ".stock_t1.sam", "rb").read()
