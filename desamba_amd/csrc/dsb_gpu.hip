@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256) k_seed_probe_reads(DsbDevIndex x, const D
 // wavefront finish together on ragged batches.
 __global__ void __launch_bounds__(256) k_seed_scan(DsbDevIndex x, const DsbReadDesc *__restrict__ rd, const uint32_t *__restrict__ order, uint32_t n_reads,
                                                    const uint64_t *__restrict__ pk, DsbSeed *__restrict__ seeds, DsbSeedInfo *__restrict__ sinfo,
-                                                   const uint8_t *__restrict__ summ, int summ_shift, unsigned long long *counters)
+                                                   const uint8_t *__restrict__ summ, int summ_shift, unsigned long long *counters, DsbScanLook look)
 {
 	const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
 	const bool active = g < 2ull * n_reads;
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256) k_seed_scan(DsbDevIndex x, const DsbReadD
 	auto mark = [&](uint32_t idx) { if (idx < cap) sv[idx].top = 1; };
 	const int k = x.ek_len, sbm = x.single_base_max;
 	const uint64_t kmask = k >= 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
-	DsbScan s; dsb_scan_init(s, active ? d.n_win : 0u);
+	DsbScan s; dsb_scan_init(s, active ? d.n_win : 0u, look);
 	uint32_t p0 = 0, p1 = 0;
 	uint64_t K0 = 0, K1 = 0, K2 = 0; uint32_t wbase = 0xfffffff0u;          // packed words wbase .. wbase + 2 of the strand (none yet)
 	for (;;) {
@@ -1515,7 +1515,8 @@ static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn)
 	}
 	if (use_scan) {
 		hipLaunchKernelGGL(k_seed_scan, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const uint32_t *)(s.ragged ? s.d_scan_order : nullptr),
-		                   (uint32_t)n, (const uint64_t *)c->d_pk, c->d_seeds, c->d_sinfo, (const uint8_t *)c->d_summ, c->summ_shift, (unsigned long long *)(c->d_counters + 40));
+		                   (uint32_t)n, (const uint64_t *)c->d_pk, c->d_seeds, c->d_sinfo, (const uint8_t *)c->d_summ, c->summ_shift, (unsigned long long *)(c->d_counters + 40),
+		                   dsb_scan_look_for((c->dx.ek_mask + 1) / 8));
 	} else if (s.n_words_total) {
 		uint64_t waves = (s.n_words_total + DSB_PROBE_UN - 1) / DSB_PROBE_UN; unsigned blocks = (unsigned)((waves + 3) / 4);
 		if (blocks > 256u * 32u) blocks = 256u * 32u;       // >= 8 blocks of 4 waves per CU, grid-stride beyond

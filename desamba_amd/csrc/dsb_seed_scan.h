@@ -35,20 +35,23 @@
 #define DSB_SCAN_DONE 4u
 #define DSB_SCAN_NONE 0xffffffffu
 #define DSB_SCAN_W 8           /* windows a lane asks for per round */
-#ifndef DSB_SCAN_SPEC_AFTER_SEED
-#define DSB_SCAN_SPEC_AFTER_SEED 4u
-#endif
-#ifndef DSB_SCAN_BACK_FWD
-#define DSB_SCAN_BACK_FWD 2      /* forward windows asked for together with the two behind a hit (<= DSB_SCAN_W - 2) */
-#endif
-#ifndef DSB_SCAN_FWD_N
-#define DSB_SCAN_FWD_N 4         /* windows per round while a run of hits is followed (<= DSB_SCAN_W) */
-// (Round 3 asked for 6 and 8: on the demo index, whose tables are 1 % full, a run of hits is a true seed and goes on; on a viral-RefSeq-
-// sized index (20 % full, a window in 25 a false positive) most runs end after a window or two, and every window asked for behind the
-// first miss is a probe the reference's scan never makes: 1.52 x the reference's table-0 probes there, 1.31 x with 2 and 4 -- and the
-// kernel, which runs at the random-gather ceiling of the memory system, is 9.5 % faster: 104.0 -> 94.1 ms per 65536 x 50 kbp; the demo
-// index is unchanged.  tools note: /tmp-free CPU measurement through tests/emu (emu_scan_seeds) against the oracle's P0.)
-#endif
+// How far a lane looks ahead: stride points right behind a seed, forward windows asked for together with the two behind a hit
+// (<= DSB_SCAN_W - 2), windows per round while a run of hits is followed (<= DSB_SCAN_W).  Every window asked for behind the first miss
+// is a probe the reference's scan never makes -- and every window not asked for is a round trip more on the lane's serial chain.
+// Which side wins depends on where the tables live (measured, 65536 x 50 kbp, A/B on one box):
+//   * tables that sit in the Infinity Cache (<= 256 MiB each; a viral-RefSeq-sized index: 2 x 128 MiB, 20 % full, a window in 25 a false
+//     positive, so most runs end after a window or two): the kernel runs at the request rate of the memory system, a probe not made is
+//     time not spent -- (4, 2, 4): 1.31 x the reference's table-0 probes instead of 1.52 x with round 3's (8, 6, 8), 104.0 -> 94.1 ms;
+//     the demo index (1 % full: a hit is a true seed and goes on) is unchanged, 52.1 / 52.6 ms;
+//   * multi-GiB tables in HBM (2 x 2 GiB synthetic, 20 % full): the same 80 ms either way -- there the lanes' round trips are the limit
+//     (131072 strands, a round trip of 2-3 us), so the longer look-ahead stays: it keeps the kernel at 0.96 of the random-gather ceiling.
+struct DsbScanLook { uint8_t after_seed, back_fwd, fwd_n, pad; };
+static inline DsbScanLook dsb_scan_look_for(uint64_t table_bytes)
+{
+	DsbScanLook k; k.pad = 0;
+	if (table_bytes <= (256ull << 20)) { k.after_seed = 4; k.back_fwd = 2; k.fwd_n = 4; } else { k.after_seed = 8; k.back_fwd = 6; k.fwd_n = 8; }
+	return k;
+}
 
 struct DsbScan {
 	uint32_t n;                 // windows of the strand
@@ -56,12 +59,14 @@ struct DsbScan {
 	uint32_t mode;
 	uint32_t off, len, j;       // the seed being extended; next forward window
 	uint32_t spec;              // stride points asked for per round: DSB_SCAN_W, fewer right behind a seed (see dsb_scan_want)
+	DsbScanLook look;
 	// get_seed_vector_M2's marking of the best seed per 100-window bin (src/cly.c:1200-1234), run on each seed as it is made
 	uint32_t ns, total, max_index, max_length, index_end, cur_top;
 };
 
-DSB_SCAN_FN void dsb_scan_init(DsbScan &s, uint32_t n)
+DSB_SCAN_FN void dsb_scan_init(DsbScan &s, uint32_t n, DsbScanLook look)
 {
+	s.look = look;
 	s.n = n; s.i = 2; s.mode = n > 2 ? DSB_SCAN_STRIDE : DSB_SCAN_DONE;
 	s.off = s.len = s.j = 0; s.spec = DSB_SCAN_W;
 	s.ns = 0; s.total = 0; s.max_index = 0; s.max_length = 0; s.index_end = 100; s.cur_top = 0;
@@ -76,7 +81,7 @@ DSB_SCAN_FN void dsb_scan_want(const DsbScan &s, uint32_t (&want)[DSB_SCAN_W])
 	for (int t = 0; t < DSB_SCAN_W; t++) want[t] = DSB_SCAN_NONE;
 	if (s.mode == DSB_SCAN_STRIDE) {
 		// the next stride points: eight while they miss (on the demo index 93 % do, little of the look-ahead is wasted); only
-		// DSB_SCAN_SPEC_AFTER_SEED right behind a seed -- seeds come in clusters (the matching stretch of the read: on an index whose
+		// look.after_seed right behind a seed -- seeds come in clusters (the matching stretch of the read: on an index whose
 		// tables are 20 % full a stride point in nine hits), and every point behind the first hit of a round is a probe the reference's scan never makes
 #pragma unroll
 		for (int t = 0; t < DSB_SCAN_W; t++) { const uint32_t p = s.i + 3u * (uint32_t)t; if ((uint32_t)t < s.spec && p < s.n) want[t] = p; }
@@ -84,10 +89,10 @@ DSB_SCAN_FN void dsb_scan_want(const DsbScan &s, uint32_t (&want)[DSB_SCAN_W])
 		// around a hit at i: two back (i >= 2 at every hit), and the run forward
 		want[0] = s.i - 1; want[1] = s.i - 2;
 #pragma unroll
-		for (int t = 2; t < 2 + DSB_SCAN_BACK_FWD; t++) { const uint32_t p = s.i + (uint32_t)(t - 1); if (p < s.n) want[t] = p; }
+		for (int t = 2; t < DSB_SCAN_W; t++) { const uint32_t p = s.i + (uint32_t)(t - 1); if (t < 2 + (int)s.look.back_fwd && p < s.n) want[t] = p; }
 	} else if (s.mode == DSB_SCAN_FWD) {
 #pragma unroll
-		for (int t = 0; t < DSB_SCAN_FWD_N; t++) { const uint32_t p = s.j + (uint32_t)t; if (p < s.n) want[t] = p; }
+		for (int t = 0; t < DSB_SCAN_W; t++) { const uint32_t p = s.j + (uint32_t)t; if (t < (int)s.look.fwd_n && p < s.n) want[t] = p; }
 	}
 }
 
@@ -108,7 +113,7 @@ DSB_SCAN_FN void dsb_scan_emit(DsbScan &s, bool rc, Store &store, Mark &mark)
 		s.index_end += 100; s.total += s.max_length; s.max_index = s.ns; s.max_length = l;
 	}
 	s.ns++;
-	s.i = s.off + l + 3; s.mode = s.i < s.n ? DSB_SCAN_STRIDE : DSB_SCAN_DONE; s.spec = DSB_SCAN_SPEC_AFTER_SEED;
+	s.i = s.off + l + 3; s.mode = s.i < s.n ? DSB_SCAN_STRIDE : DSB_SCAN_DONE; s.spec = s.look.after_seed;
 }
 
 // the run of hits in bits[from ..] (bit t = window want[t]): extends the seed, at most to 61 windows (src/cly.c:1100);
@@ -131,9 +136,9 @@ DSB_SCAN_FN void dsb_scan_consume(DsbScan &s, uint32_t bits, bool rc, Store &sto
 	} else if (s.mode == DSB_SCAN_BACK) {
 		const uint32_t back = (bits & 1u) ? ((bits & 2u) ? 2u : 1u) : 0u;
 		s.off = s.i - back; s.len = 1 + back; s.j = s.i + 1;
-		if (dsb_scan_run(s, bits, 2, DSB_SCAN_BACK_FWD)) s.mode = DSB_SCAN_FWD; else dsb_scan_emit(s, rc, store, mark);
+		if (dsb_scan_run(s, bits, 2, (int)s.look.back_fwd)) s.mode = DSB_SCAN_FWD; else dsb_scan_emit(s, rc, store, mark);
 	} else if (s.mode == DSB_SCAN_FWD) {
-		if (!dsb_scan_run(s, bits, 0, DSB_SCAN_FWD_N)) dsb_scan_emit(s, rc, store, mark);
+		if (!dsb_scan_run(s, bits, 0, (int)s.look.fwd_n)) dsb_scan_emit(s, rc, store, mark);
 	}
 }
 

@@ -224,7 +224,7 @@ extern "C" int emu_scan_seeds(void *p, int strand, DsbSeed *out, int max_out, ui
 	std::vector<DsbSeed> sv;
 	auto store = [&](uint32_t idx, uint32_t off, uint32_t len) { if (sv.size() <= idx) sv.resize(idx + 1); sv[idx].offset = off; sv[idx].len = (uint16_t)len; sv[idx].top = 0; };
 	auto mark = [&](uint32_t idx) { sv[idx].top = 1; };
-	DsbScan s; dsb_scan_init(s, n);
+	DsbScan s; dsb_scan_init(s, n, dsb_scan_look_for((dx.ek_mask + 1) / 8));
 	uint32_t np = 0, nall = 0;
 	while (s.mode != DSB_SCAN_DONE) {
 		uint32_t want[DSB_SCAN_W]; dsb_scan_want(s, want); uint32_t bits = 0;
