@@ -973,7 +973,8 @@ static int index_main(int argc, char **argv)
 		fprintf(stderr, "  Usage:     deSAMBA  index  <Options> [SortedKmer] <Reference> <IndexDir>\n  Basic:     \n");
 		fprintf(stderr, "    [SortedKmer]  FILE   sorted kmers file \"kmer.srt\" generated by \"kmersort\"; without it the 31-mers are taken from the reference\n");
 		fprintf(stderr, "    <Reference>   FILE   one fasta REF file, multiple files need to be combined\n");
-		fprintf(stderr, "    <IndexDir>    FOLDER the directory to store deSAMBA index\n  Options:\n    -g INT        GPU device id [0]\n    -h            help\n\n");
+		fprintf(stderr, "    <IndexDir>    FOLDER the directory to store deSAMBA index\n  Options:\n    -g INT        GPU device id [0]\n    -h            help\n");
+		fprintf(stderr, "  Environment:\n    DSB_BUILD_BUDGET=<bytes>[k|m|g]  device memory the build may hold (default: in one piece if ~64 bytes per base fit, else 85 %% of the free memory)\n\n");
 		return 0;
 	}
 	const char *srt = optind + 3 <= argc ? argv[optind++] : NULL;
@@ -985,6 +986,9 @@ static int index_main(int argc, char **argv)
 	        (unsigned long)st.n_kmer, (unsigned long)st.n_unitig, (unsigned long)st.n_rows);
 	fprintf(stderr, "index built in %.2fs (read %.2f, k-mers %.2f, graph %.2f, unitigs %.2f, BWT rows %.2f, tables %.2f, write %.2f)\n", st.total_s, st.parse_s,
 	        st.sort_s, st.graph_s, st.walk_s, st.rows_s, st.tables_s, st.write_s);
+	if (st.budget_bytes)
+		fprintf(stderr, "built in ranges of k-mer prefixes within %.2f GiB of device memory (held at most %.2f GiB): %u passes for the k-mers, %u for the unitig numbers, %u for the BWT rows, %u for the filter tables\n",
+		        st.budget_bytes / 1073741824.0, st.peak_device_bytes / 1073741824.0, st.ranges_kmers, st.ranges_unitig_numbers, st.ranges_rows, st.ranges_exist);
 	return 0;
 }
 

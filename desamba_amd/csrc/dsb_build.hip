@@ -3,14 +3,17 @@
 // Every stage is one launch of k_for over k-mers / text chunks / unitigs / BWT rows (atomics only where several
 // iterations mark the same k-mer); the three sorts (all 31-mers of the text, the 30 suffixes per unitig, the
 // unitig -> position pairs) are rocPRIM LSD radix sorts, which are stable -- the order of equal keys is part of the
-// file format (see the header of dsb_build_impl.h); prefix sums are a two-level scan below.  The whole working set of a
-// build lives in HBM at once (about 60 bytes per reference base: 23 GB for a 380-Mbp reference).
+// file format (see the header of dsb_build_impl.h); prefix sums are a two-level scan below.  dsb_build_run keeps the whole
+// working set of a build in HBM at once (about 60 bytes per reference base: 23 GB for a 380-Mbp reference); when that does
+// not fit the device -- or DSB_BUILD_BUDGET says so -- dsb_build_run_parts (dsb_build_parts.h) builds the same files in
+// passes over ranges of 13-mer prefixes.
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <chrono>
 #include "desamba_amd.h"
 #include "dsb_build_host.h"
+#include "dsb_build_parts.h"
 
 #define HIPB(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "desamba_amd: %s: %s\n", #x, hipGetErrorString(e_)); failed = true; } } while (0)
 
@@ -63,15 +66,23 @@ struct HipBE {
 	bool failed = false;
 	hipStream_t st = 0;
 	int n_cu = 256;
-	std::vector<void *> live;                          // what a failed build leaves behind is freed with the backend
-	~HipBE() { for (void *p : live) (void)hipFree(p); }
-	template <class T> T *alloc(size_t n) { void *p = nullptr; HIPB(hipMalloc(&p, (n ? n : 1) * sizeof(T))); if (p) live.push_back(p); return (T *)p; }
+	std::vector<std::pair<void *, size_t>> live;      // what a failed build leaves behind is freed with the backend
+	size_t live_b = 0, peak_b = 0;                     // bytes held now / at most (what a budget is checked against)
+	~HipBE() { for (auto &p : live) (void)hipFree(p.first); }
+	template <class T> T *alloc(size_t n)
+	{
+		void *p = nullptr; const size_t b = (n ? n : 1) * sizeof(T);
+		HIPB(hipMalloc(&p, b));
+		if (p) { live.push_back({p, b}); live_b += b; if (live_b > peak_b) peak_b = live_b; }
+		return (T *)p;
+	}
 	void free(void *p)
 	{
 		if (!p) return;
-		for (size_t i = live.size(); i-- > 0;) if (live[i] == p) { live[i] = live.back(); live.pop_back(); break; }
+		for (size_t i = live.size(); i-- > 0;) if (live[i].first == p) { live_b -= live[i].second; live[i] = live.back(); live.pop_back(); break; }
 		(void)hipFree(p);
 	}
+	size_t peak_bytes() const { return peak_b; }
 	void zero(void *p, size_t bytes) { HIPB(hipMemsetAsync(p, 0, bytes, st)); }
 	void fill_ff(void *p, size_t bytes) { HIPB(hipMemsetAsync(p, 0xff, bytes, st)); }
 	void to_dev(void *d, const void *s, size_t bytes) { HIPB(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, st)); HIPB(hipStreamSynchronize(st)); }
@@ -86,9 +97,9 @@ struct HipBE {
 	void sort_keys(uint64_t *k, uint64_t n, int bits)
 	{
 		if (n < 2 || failed) return;
-		uint64_t *o = alloc<uint64_t>(n); size_t tb = 0; void *tmp = nullptr;
+		uint64_t *o = alloc<uint64_t>(n); size_t tb = 0;
 		HIPB(rocprim::radix_sort_keys(nullptr, tb, k, o, n, 0, bits, st));
-		HIPB(hipMalloc(&tmp, tb ? tb : 1));
+		void *tmp = alloc<uint8_t>(tb);
 		HIPB(rocprim::radix_sort_keys(tmp, tb, k, o, n, 0, bits, st));
 		HIPB(hipMemcpyAsync(k, o, n * 8, hipMemcpyDeviceToDevice, st)); HIPB(hipStreamSynchronize(st));
 		free(tmp); free(o);
@@ -96,9 +107,9 @@ struct HipBE {
 	template <class K, class V> void sort_pairs(K *k, V *v, uint64_t n, int bits)
 	{
 		if (n < 2 || failed) return;
-		K *ko = alloc<K>(n); V *vo = alloc<V>(n); size_t tb = 0; void *tmp = nullptr;
+		K *ko = alloc<K>(n); V *vo = alloc<V>(n); size_t tb = 0;
 		HIPB(rocprim::radix_sort_pairs(nullptr, tb, k, ko, v, vo, n, 0, bits, st));
-		HIPB(hipMalloc(&tmp, tb ? tb : 1));
+		void *tmp = alloc<uint8_t>(tb);
 		HIPB(rocprim::radix_sort_pairs(tmp, tb, k, ko, v, vo, n, 0, bits, st));
 		HIPB(hipMemcpyAsync(k, ko, n * sizeof(K), hipMemcpyDeviceToDevice, st)); HIPB(hipMemcpyAsync(v, vo, n * sizeof(V), hipMemcpyDeviceToDevice, st));
 		HIPB(hipStreamSynchronize(st));
@@ -141,8 +152,24 @@ extern "C" int dsb_index_build(const char *kmer_srt, const char *fasta, const ch
 	const double t_parse = wall() - t0;
 	if (const char *e = getenv("DSB_FORCE_EK_LEVEL")) in.force_ek_level = atoi(e);
 	HipBE be; be.n_cu = prop.multiProcessorCount;
-	const int rc = dsb_build_run(be, in, out);
+	// DSB_BUILD_BUDGET=<bytes>[k|m|g]: the device memory the build may hold; DSB_BUILD_PARTS=<n> (tests on small references): n ranges of
+	// prefixes per stage whatever the budget.  Without either: in one piece when ~64 bytes per base fit the free device memory, in ranges
+	// within 85 % of it when they do not.
+	uint64_t budget = 0; DsbPartsInfo pi;
+	if (const char *e = getenv("DSB_BUILD_BUDGET")) {
+		char *end = nullptr; double v = strtod(e, &end);
+		if (end && (*end == 'k' || *end == 'K')) v *= 1024.0; else if (end && (*end == 'm' || *end == 'M')) v *= 1048576.0; else if (end && (*end == 'g' || *end == 'G')) v *= 1073741824.0;
+		if (v >= 1.0) budget = (uint64_t)v;
+	}
+	if (const char *e = getenv("DSB_BUILD_PARTS")) pi.force_parts = (uint32_t)atoi(e);
+	size_t mem_free = 0, mem_total = 0;
+	if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return DSB_ENODEV;
+	const uint64_t in_one_piece = 64 * (uint64_t)in.code.size() + (3ULL << 30);
+	const bool parts = budget || pi.force_parts || in_one_piece > mem_free;
+	if (parts && !budget) budget = (uint64_t)(0.85 * (double)mem_free);
+	const int rc = parts ? dsb_build_run_parts(be, in, out, budget, &pi) : dsb_build_run(be, in, out);
 	if (be.failed) return DSB_ENODEV;
+	if (rc == -5) { fprintf(stderr, "desamba_amd: a budget of %llu bytes of device memory does not hold what an index of %llu bases keeps resident\n", (unsigned long long)budget, (unsigned long long)in.code.size()); return DSB_ENOMEM; }
 	if (rc) return rc;
 	t0 = wall();
 	if (dsb_build_write(in, out, out_dir)) return DSB_EIO;
@@ -150,6 +177,8 @@ extern "C" int dsb_index_build(const char *kmer_srt, const char *fasta, const ch
 		stats->n_bases = in.code.size(); stats->n_refs = in.refs.size(); stats->n_kmer = out.n_kmer; stats->n_unitig = out.n_uni; stats->n_rows = out.n_rows;
 		stats->parse_s = t_parse; stats->sort_s = out.t_sort; stats->graph_s = out.t_graph; stats->walk_s = out.t_walk; stats->rows_s = out.t_rows;
 		stats->tables_s = out.t_tables; stats->write_s = wall() - t0; stats->total_s = wall() - t_all;
+		stats->budget_bytes = parts ? budget : 0; stats->peak_device_bytes = be.peak_bytes();
+		stats->ranges_kmers = pi.parts_kmers; stats->ranges_unitig_numbers = pi.parts_uid; stats->ranges_rows = pi.parts_rows; stats->ranges_exist = pi.parts_exist;
 	}
 	return DSB_OK;
 }

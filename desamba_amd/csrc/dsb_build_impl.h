@@ -145,6 +145,46 @@ DSB_BFN void b_sa_sample(const uint32_t *ulen, uint64_t n_uni, uint32_t u, uint3
 	else { const uint32_t v = u ? u - 1 : (uint32_t)(n_uni - 1); out[0] = v; out[1] = ulen[v]; }
 }
 
+// hash_index / unv / ref_p from what the device stages leave on the host (shared by dsb_build_run and dsb_build_run_parts)
+static inline void dsb_build_finish_host(const DsbBuildIn &in, DsbBuildOut &out, const std::vector<uint64_t> &hs, const std::vector<uint32_t> &hc,
+                                         const std::vector<uint32_t> &h_ulen, const std::vector<uint32_t> &h_ru_u, const std::vector<uint64_t> &h_ru_g)
+{
+	const uint64_t n_uni = out.n_uni, n_ru = h_ru_u.size();
+	// the 13-mer table, compressed as the reference does (src/idx.c:943-961): the first row of a prefix that occurs, the end of the
+	// last one that does for a prefix that does not
+	out.hash_index.resize(DSB_PRE_N);
+	{
+		uint64_t prev = 0;
+		for (uint64_t k = 0; k + 1 < DSB_PRE_N; k++) {
+			if (hc[k]) { out.hash_index[k] = hs[k]; prev = hs[k] + hc[k]; } else out.hash_index[k] = prev;
+		}
+		out.hash_index[DSB_PRE_N - 1] = prev;
+	}
+	// unitig table: interval of each unitig in the position list, filled the way set_ref_lists does (src/idx.c:683-709) --
+	// unitigs shorter than 35 bases have no positions and keep whatever the previous listed unitig left in their slot
+	out.unv.assign(2 * (n_uni + 1), 0);
+	{
+		uint32_t old = 0xffffffffu;
+		for (uint64_t r = 0; r < n_ru; r++) {
+			const uint32_t c = h_ru_u[r];
+			if (c != old) { if (out.unv[2 * c] == 0) out.unv[2 * c] = (uint32_t)r; out.unv[2 * (c + 1)] = (uint32_t)(r + 1); old = c; }
+			else out.unv[2 * (c + 1)]++;
+		}
+		for (uint64_t u = 0; u < n_uni; u++) out.unv[2 * u + 1] = h_ulen[u];
+		out.unv[2 * n_uni] = (uint32_t)n_ru; out.unv[2 * n_uni + 1] = 0;
+	}
+	out.ref_p.resize(n_ru);
+	{
+		std::vector<uint64_t> starts(in.refs.size());
+		for (size_t i = 0; i < in.refs.size(); i++) starts[i] = in.refs[i].seq_offset;
+		for (uint64_t r = 0; r < n_ru; r++) {
+			const uint64_t g = h_ru_g[r];
+			size_t id = std::upper_bound(starts.begin(), starts.end(), g) - starts.begin() - 1;     // last sequence that starts at or before g (empty ones share a start)
+			out.ref_p[r] = (g & 0xffffffffffULL) | ((uint64_t)(id & 0x7fffffu) << 40) | (1ULL << 63);    // FORWARD = 1 (src/lib/utils.h:66)
+		}
+	}
+}
+
 template <class B>
 int dsb_build_run(B &be, const DsbBuildIn &in, DsbBuildOut &out)
 {
@@ -440,39 +480,7 @@ int dsb_build_run(B &be, const DsbBuildIn &in, DsbBuildOut &out)
 	                (void *)uoff, (void *)ustr, (void *)ru_u, (void *)ru_g, (void *)spk, (void *)spi, (void *)bw, (void *)sa, (void *)hstart, (void *)hcnt,
 	                (void *)bh, (void *)bs, (void *)blocks, (void *)ek0, (void *)ek1, (void *)refb}) be.free(p);
 
-	// the 13-mer table, compressed as the reference does (src/idx.c:943-961): the first row of a prefix that occurs, the end of the
-	// last one that does for a prefix that does not
-	out.hash_index.resize(DSB_PRE_N);
-	{
-		uint64_t prev = 0;
-		for (uint64_t k = 0; k + 1 < DSB_PRE_N; k++) {
-			if (hc[k]) { out.hash_index[k] = hs[k]; prev = hs[k] + hc[k]; } else out.hash_index[k] = prev;
-		}
-		out.hash_index[DSB_PRE_N - 1] = prev;
-	}
-	// unitig table: interval of each unitig in the position list, filled the way set_ref_lists does (src/idx.c:683-709) --
-	// unitigs shorter than 35 bases have no positions and keep whatever the previous listed unitig left in their slot
-	out.unv.assign(2 * (n_uni + 1), 0);
-	{
-		uint32_t old = 0xffffffffu;
-		for (uint64_t r = 0; r < n_ru; r++) {
-			const uint32_t c = h_ru_u[r];
-			if (c != old) { if (out.unv[2 * c] == 0) out.unv[2 * c] = (uint32_t)r; out.unv[2 * (c + 1)] = (uint32_t)(r + 1); old = c; }
-			else out.unv[2 * (c + 1)]++;
-		}
-		for (uint64_t u = 0; u < n_uni; u++) out.unv[2 * u + 1] = h_ulen[u];
-		out.unv[2 * n_uni] = (uint32_t)n_ru; out.unv[2 * n_uni + 1] = 0;
-	}
-	out.ref_p.resize(n_ru);
-	{
-		std::vector<uint64_t> starts(in.refs.size());
-		for (size_t i = 0; i < in.refs.size(); i++) starts[i] = in.refs[i].seq_offset;
-		for (uint64_t r = 0; r < n_ru; r++) {
-			const uint64_t g = h_ru_g[r];
-			size_t id = std::upper_bound(starts.begin(), starts.end(), g) - starts.begin() - 1;     // last sequence that starts at or before g (empty ones share a start)
-			out.ref_p[r] = (g & 0xffffffffffULL) | ((uint64_t)(id & 0x7fffffu) << 40) | (1ULL << 63);    // FORWARD = 1 (src/lib/utils.h:66)
-		}
-	}
+	dsb_build_finish_host(in, out, hs, hc, h_ulen, h_ru_u, h_ru_g);
 	out.t_tables = be.now() - t0;
 	return 0;
 }

@@ -109,12 +109,19 @@ typedef struct {
  * fasta: plain or gzip FASTA read with the reference's reader rules; out_dir is created; the ten deSAMBA.* files
  * written are byte-identical to the reference's (.ref_i: the reference leaves the padding behind each name
  * uninitialised; zeros here).  Limits: < 2^32 / 30 unitigs (the file format holds unitig numbers in 32 bits); k-mer ranks and BWT rows
- * are 64-bit (an index of > 2^32 BWT rows is built and classified on: tests/tools/huge_index.sh); the working set (~60 bytes per
- * reference base) must fit the device.  DSB_EINVAL: reference shorter than 31 bases, a k-mer of the text missing from kmer_srt or a
+ * are 64-bit (an index of > 2^32 BWT rows is built and classified on: tests/tools/huge_index.sh).  The build runs in one piece when
+ * its working set (~60 bytes per reference base) fits the free device memory, and otherwise -- or when the environment says
+ * DSB_BUILD_BUDGET=<bytes>[k|m|g] -- in passes over ranges of 13-mer prefixes (dsb_build_parts.h; the reference's bucket-by-bucket
+ * construction, src/idx_sort.c:298-401, src/idx.c:884-1026): the device then holds the text (1 byte per base), ~12 bytes per unitig
+ * occurrence and unitig, and one range; host memory holds the k-mer list (8 bytes per k-mer) and the files.  Same files either way.
+ * DSB_ENOMEM: the budget does not hold what stays resident.  DSB_EINVAL: reference shorter than 31 bases, a k-mer of the text missing from kmer_srt or a
  * k-mer of kmer_srt missing from the text, or a unitig cycle the reference's builder does not handle either. */
 typedef struct {
 	uint64_t n_bases, n_refs, n_kmer, n_unitig, n_rows;
 	double parse_s, sort_s, graph_s, walk_s, rows_s, tables_s, write_s, total_s;
+	uint64_t budget_bytes;        /* 0: built in one piece; else the device memory the passes were planned for */
+	uint64_t peak_device_bytes;   /* the most the build held at once (every allocation of the build is counted) */
+	uint32_t ranges_kmers, ranges_unitig_numbers, ranges_rows, ranges_exist;   /* passes of the k-mer / unitig-number / BWT-row / filter-table stages */
 } dsb_build_stats;
 int  dsb_index_build(const char *kmer_srt, const char *fasta, const char *out_dir, int device, dsb_build_stats *stats);
 

@@ -11,8 +11,7 @@ EXTS = [".acg", ".bwt", ".exk0", ".exk1", ".exki", ".ref_b", ".ref_i", ".ref_p",
 _emu = None
 
 
-def emu_build(fasta, out_dir, kmer_srt=None):
-    """run the builder stages on the host; returns (n_kmer, n_unitig, n_rows, n_refs)"""
+def _load_emu():
     global _emu
     if _emu is None:
         p = os.path.join(ROOT, "tests", "emu", "libdsbemu_build.so")
@@ -20,11 +19,28 @@ def emu_build(fasta, out_dir, kmer_srt=None):
             raise RuntimeError("%s missing -- run __graft_entry__.build()" % p)
         _emu = C.CDLL(p)
         _emu.dsb_emu_index_build.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64)]
+        _emu.dsb_emu_index_build_parts.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+
+
+def emu_build(fasta, out_dir, kmer_srt=None):
+    """run the builder stages on the host; returns (n_kmer, n_unitig, n_rows, n_refs)"""
+    _load_emu()
     st = (C.c_uint64 * 4)()
     rc = _emu.dsb_emu_index_build(kmer_srt.encode() if kmer_srt else None, fasta.encode(), out_dir.encode(), st)
     if rc:
         raise RuntimeError("dsb_emu_index_build(%s) = %d" % (fasta, rc))
     return tuple(st)
+
+
+def emu_build_parts(fasta, out_dir, kmer_srt=None, budget=1 << 40, parts=0):
+    """the same through dsb_build_run_parts (dsb_build_parts.h): `parts` ranges of prefixes per stage, or as many as `budget` bytes ask
+    for; returns a dict with the counts, the peak bytes the backend held and the number of ranges of each stage"""
+    _load_emu()
+    st = (C.c_uint64 * 10)()
+    rc = _emu.dsb_emu_index_build_parts(kmer_srt.encode() if kmer_srt else None, fasta.encode(), out_dir.encode(), budget, parts, st)
+    if rc:
+        raise RuntimeError("dsb_emu_index_build_parts(%s) = %d" % (fasta, rc))
+    return dict(zip(("n_kmer", "n_unitig", "n_rows", "n_refs", "peak", "parts_kmers", "parts_uid", "parts_rows", "start_windows", "parts_exist"), st))
 
 
 def n_rows_of(d):

@@ -4,11 +4,15 @@
 #define DSB_HOST_EMU 1
 #include <chrono>
 #include <numeric>
+#include <map>
 #include "dsb_build_host.h"
+#include "dsb_build_parts.h"
 
 struct HostBE {
-	template <class T> T *alloc(size_t n) { return (T *)malloc((n ? n : 1) * sizeof(T)); }
-	void free(void *p) { ::free(p); }
+	std::map<void *, size_t> live; size_t live_b = 0, peak_b = 0;          // what dsb_build_run_parts' budget is checked against
+	template <class T> T *alloc(size_t n) { const size_t b = (n ? n : 1) * sizeof(T); void *p = malloc(b); live[p] = b; live_b += b; if (live_b > peak_b) peak_b = live_b; return (T *)p; }
+	void free(void *p) { auto it = live.find(p); if (it != live.end()) { live_b -= it->second; live.erase(it); } ::free(p); }
+	size_t peak_bytes() const { return peak_b; }
 	void zero(void *p, size_t bytes) { memset(p, 0, bytes); }
 	void fill_ff(void *p, size_t bytes) { memset(p, 0xff, bytes); }
 	void to_dev(void *d, const void *s, size_t bytes) { memcpy(d, s, bytes); }
@@ -39,5 +43,24 @@ extern "C" int dsb_emu_index_build(const char *kmer_srt, const char *fasta, cons
 	const int rc = dsb_build_run(be, in, out);
 	if (rc) return rc;
 	if (stats) { stats[0] = out.n_kmer; stats[1] = out.n_uni; stats[2] = out.n_rows; stats[3] = in.refs.size(); }
+	return dsb_build_write(in, out, out_dir);
+}
+
+// the same index through dsb_build_run_parts: `parts` ranges of prefixes per stage (0: as many as `budget` bytes ask for);
+// stats[4..]: peak bytes held, ranges of the k-mer / unitig-number / row stages, start windows
+extern "C" int dsb_emu_index_build_parts(const char *kmer_srt, const char *fasta, const char *out_dir, uint64_t budget, uint32_t parts, uint64_t *stats)
+{
+	DsbBuildIn in; DsbBuildOut out;
+	if (dsb_build_read_fasta(fasta, in)) return -1;
+	if (kmer_srt && *kmer_srt && dsb_build_read_kmers(kmer_srt, in)) return -1;
+	HostBE be;
+	if (const char *e = getenv("DSB_FORCE_EK_LEVEL")) in.force_ek_level = atoi(e);
+	DsbPartsInfo pi; pi.force_parts = parts;
+	const int rc = dsb_build_run_parts(be, in, out, budget, &pi);
+	if (rc) return rc;
+	if (stats) {
+		stats[0] = out.n_kmer; stats[1] = out.n_uni; stats[2] = out.n_rows; stats[3] = in.refs.size();
+		stats[4] = pi.peak; stats[5] = pi.parts_kmers; stats[6] = pi.parts_uid; stats[7] = pi.parts_rows; stats[8] = pi.n_start_windows; stats[9] = pi.parts_exist;
+	}
 	return dsb_build_write(in, out, out_dir);
 }

@@ -99,6 +99,50 @@ def test_emulated_stages_rebuild_the_demo_index(tmp_path):
     assert got == DEMO_MD5
 
 
+# ---- the builder in ranges of k-mer prefixes (dsb_build_parts.h): what a build beyond the device's memory runs ---------------------
+
+@pytest.mark.parametrize("name,parts", [("graph1", 3), ("graph2", 5), ("graph3", 7), ("reader", 2)])
+def test_build_in_ranges_writes_the_reference_files(name, parts, tmp_path):
+    """dsb_build_run_parts on the host: the k-mer, unitig-number and BWT-row stages each in `parts` ranges of 13-mer prefixes (the
+    golden references have unitigs that start in one range and end in another, k-mers whose neighbours lie in other ranges, padded
+    suffixes that sort between the k-mers of another range): every file's digest as the reference's builder wrote it"""
+    out = str(tmp_path / "idx")
+    st = build_lib.emu_build_parts(os.path.join(GOLD, name + ".fa.gz"), out, parts=parts)
+    assert st["parts_kmers"] >= parts and st["parts_rows"] >= parts and st["parts_uid"] >= min(parts, 3)
+    assert st["n_rows"] == json.load(open(os.path.join(GOLD, name + ".md5.json")))["n_rows"]
+    check_case(name, out)
+
+
+def test_build_in_ranges_with_a_supplied_kmer_list(tmp_path):
+    """`index kmer.srt ref.fa dir` in ranges: the list is cut at the prefixes, a k-mer of the text that the list lacks is an error"""
+    text = gzip.open(os.path.join(GOLD, "graph1.fa.gz")).read()
+    recs = build_lib.reader_view(text)
+    srt = str(tmp_path / "kmer.srt")
+    build_lib.write_kmer_srt_from_text(recs, srt)
+    out = str(tmp_path / "idx")
+    build_lib.emu_build_parts(os.path.join(GOLD, "graph1.fa.gz"), out, kmer_srt=srt, parts=4)
+    check_case("graph1", out)
+    build_lib.write_kmer_srt_from_text(recs[1:], srt)
+    with pytest.raises(RuntimeError):
+        build_lib.emu_build_parts(os.path.join(GOLD, "graph1.fa.gz"), str(tmp_path / "idx2"), kmer_srt=srt, parts=4)
+
+
+def test_build_in_ranges_under_a_budget_rebuilds_the_demo_index(tmp_path):
+    """the demo reference (11.5 Mbp, 11 M 31-mers) under a budget of 400 MB -- a fifth of what the one-piece build holds on the host
+    backend (whose fixed tables of 2^26 entries alone are 1.3 GB): the ranges are planned from the budget, the backend counts every
+    allocation, the nine md5s of SURVEY.md 8c come out"""
+    out = str(tmp_path / "idx")
+    budget = 400 << 20
+    st = build_lib.emu_build_parts(demo_fasta(tmp_path), out, budget=budget)
+    assert st["n_kmer"] == 10982489 and st["n_refs"] == 463
+    assert st["peak"] <= budget, st
+    assert st["parts_kmers"] >= 2 and st["parts_rows"] >= 2, st
+    got = {e: md5_file(os.path.join(out, "deSAMBA" + e)) for e in DEMO_MD5}
+    assert got == DEMO_MD5
+    with pytest.raises(RuntimeError):                       # a budget that does not hold the text + slack: an error code, nothing built
+        build_lib.emu_build_parts(demo_fasta(tmp_path), str(tmp_path / "idx2"), budget=40 << 20)
+
+
 # ---------------------------------------------------------------- GPU: through the C ABI and the CLI
 
 @pytest.mark.gpu
@@ -161,6 +205,45 @@ def test_cli_index_with_and_without_a_kmer_list(tmp_path):
     subprocess.run([cli, "index", srt, fa, str(tmp_path / "b")], check=True, stderr=subprocess.DEVNULL)
     check_case("graph2", str(tmp_path / "b"))
     assert subprocess.run([cli, "index", str(tmp_path / "nope.fa"), str(tmp_path / "c")], stderr=subprocess.DEVNULL).returncode == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_gpu_build_in_ranges_writes_the_reference_files(name, tmp_path, monkeypatch):
+    """dsb_index_build with DSB_BUILD_PARTS=3: the three per-range stages of dsb_build_parts.h as HIP kernels (atomic appends, rocPRIM
+    sorts of one range at a time, text passes with the start list): the reference's files"""
+    import desamba_amd as D
+    monkeypatch.setenv("DSB_BUILD_PARTS", "3")
+    out = str(tmp_path / "idx")
+    st = D.build_index(os.path.join(GOLD, name + ".fa.gz"), out)
+    assert st.ranges_kmers >= 3 and st.ranges_rows >= 3 and st.budget_bytes > 0
+    check_case(name, out)
+
+
+@pytest.mark.gpu
+def test_gpu_build_beyond_the_budget_gives_the_same_files(tmp_path, monkeypatch):
+    """a 380-Mbp collection (tandem repeats, strains, mobile elements: 4e8 BWT rows) built in one piece and under
+    DSB_BUILD_BUDGET = an eighth of what the one-piece build held: the same ten files byte for byte, and the device never held more
+    than the budget (every allocation of the build is counted)"""
+    import shutil
+    import desamba_amd as D
+    if shutil.disk_usage(str(tmp_path)).free < (8 << 30):
+        pytest.skip("needs 8 GiB of disk")
+    fa = str(tmp_path / "syn.fa"); a = str(tmp_path / "a"); b = str(tmp_path / "b")
+    subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "synth_ref.py"), fa, "380", "1"], check=True, stderr=subprocess.DEVNULL)
+    s1 = D.build_index(fa, a)
+    assert s1.budget_bytes == 0 and s1.peak_device_bytes > 50 * s1.n_bases
+    budget = s1.peak_device_bytes // 8
+    monkeypatch.setenv("DSB_BUILD_BUDGET", str(budget))
+    s2 = D.build_index(fa, b)
+    monkeypatch.delenv("DSB_BUILD_BUDGET")
+    print("380 Mbp: one piece %.1f s holding %.2f GiB; budget %.2f GiB: %.1f s holding %.2f GiB in %d / %d / %d / %d passes (k-mers / unitig numbers / rows / filter tables)" %
+          (s1.total_s, s1.peak_device_bytes / 2**30, budget / 2**30, s2.total_s, s2.peak_device_bytes / 2**30, s2.ranges_kmers, s2.ranges_unitig_numbers, s2.ranges_rows, s2.ranges_exist))
+    assert s2.budget_bytes == budget and s2.peak_device_bytes <= budget and s2.ranges_kmers >= 4
+    assert (s2.n_kmer, s2.n_unitig, s2.n_rows) == (s1.n_kmer, s1.n_unitig, s1.n_rows)
+    for e in build_lib.EXTS:
+        assert md5_file(os.path.join(a, "deSAMBA" + e)) == md5_file(os.path.join(b, "deSAMBA" + e)), e
+    shutil.rmtree(a); shutil.rmtree(b)
 
 
 # ---- every filter k the reference knows (src/idx.c:966-982): forced table levels on one small reference -----------------------------
