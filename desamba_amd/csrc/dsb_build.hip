@@ -73,7 +73,7 @@ struct HipBE {
 	{
 		void *p = nullptr; const size_t b = (n ? n : 1) * sizeof(T);
 		HIPB(hipMalloc(&p, b));
-		if (p) { live.push_back({p, b}); live_b += b; if (live_b > peak_b) peak_b = live_b; }
+		if (p) { live.push_back({p, b}); live_b += b; if (live_b > peak_b) peak_b = live_b; if (live_b > mark_b) mark_b = live_b; }
 		return (T *)p;
 	}
 	void free(void *p)
@@ -83,6 +83,8 @@ struct HipBE {
 		(void)hipFree(p);
 	}
 	size_t peak_bytes() const { return peak_b; }
+	size_t mark_b = 0;
+	size_t peak_mark() { const size_t r = mark_b > live_b ? mark_b : live_b; mark_b = live_b; return r; }   // the most held since the last mark
 	void zero(void *p, size_t bytes) { HIPB(hipMemsetAsync(p, 0, bytes, st)); }
 	void fill_ff(void *p, size_t bytes) { HIPB(hipMemsetAsync(p, 0xff, bytes, st)); }
 	void to_dev(void *d, const void *s, size_t bytes) { HIPB(hipMemcpyAsync(d, s, bytes, hipMemcpyHostToDevice, st)); HIPB(hipStreamSynchronize(st)); }
@@ -97,21 +99,27 @@ struct HipBE {
 	void sort_keys(uint64_t *k, uint64_t n, int bits)
 	{
 		if (n < 2 || failed) return;
+		// the sort's second buffer through rocprim::double_buffer: the two buffers take turns pass by pass (the plain form keeps the
+		// input intact and allocates a third buffer of n keys in its temporary storage)
 		uint64_t *o = alloc<uint64_t>(n); size_t tb = 0;
-		HIPB(rocprim::radix_sort_keys(nullptr, tb, k, o, n, 0, bits, st));
+		rocprim::double_buffer<uint64_t> db(k, o);
+		HIPB(rocprim::radix_sort_keys(nullptr, tb, db, n, 0, bits, st));
 		void *tmp = alloc<uint8_t>(tb);
-		HIPB(rocprim::radix_sort_keys(tmp, tb, k, o, n, 0, bits, st));
-		HIPB(hipMemcpyAsync(k, o, n * 8, hipMemcpyDeviceToDevice, st)); HIPB(hipStreamSynchronize(st));
+		HIPB(rocprim::radix_sort_keys(tmp, tb, db, n, 0, bits, st));
+		if (db.current() != k) HIPB(hipMemcpyAsync(k, o, n * 8, hipMemcpyDeviceToDevice, st));
+		HIPB(hipStreamSynchronize(st));
 		free(tmp); free(o);
 	}
 	template <class K, class V> void sort_pairs(K *k, V *v, uint64_t n, int bits)
 	{
 		if (n < 2 || failed) return;
 		K *ko = alloc<K>(n); V *vo = alloc<V>(n); size_t tb = 0;
-		HIPB(rocprim::radix_sort_pairs(nullptr, tb, k, ko, v, vo, n, 0, bits, st));
+		rocprim::double_buffer<K> dk(k, ko); rocprim::double_buffer<V> dv(v, vo);
+		HIPB(rocprim::radix_sort_pairs(nullptr, tb, dk, dv, n, 0, bits, st));
 		void *tmp = alloc<uint8_t>(tb);
-		HIPB(rocprim::radix_sort_pairs(tmp, tb, k, ko, v, vo, n, 0, bits, st));
-		HIPB(hipMemcpyAsync(k, ko, n * sizeof(K), hipMemcpyDeviceToDevice, st)); HIPB(hipMemcpyAsync(v, vo, n * sizeof(V), hipMemcpyDeviceToDevice, st));
+		HIPB(rocprim::radix_sort_pairs(tmp, tb, dk, dv, n, 0, bits, st));
+		if (dk.current() != k) HIPB(hipMemcpyAsync(k, ko, n * sizeof(K), hipMemcpyDeviceToDevice, st));
+		if (dv.current() != v) HIPB(hipMemcpyAsync(v, vo, n * sizeof(V), hipMemcpyDeviceToDevice, st));
 		HIPB(hipStreamSynchronize(st));
 		free(tmp); free(ko); free(vo);
 	}
@@ -171,6 +179,10 @@ extern "C" int dsb_index_build(const char *kmer_srt, const char *fasta, const ch
 	if (be.failed) return DSB_ENODEV;
 	if (rc == -5) { fprintf(stderr, "desamba_amd: a budget of %llu bytes of device memory does not hold what an index of %llu bases keeps resident\n", (unsigned long long)budget, (unsigned long long)in.code.size()); return DSB_ENOMEM; }
 	if (rc) return rc;
+	if (parts && getenv("DSB_BUILD_TRACE"))
+		fprintf(stderr, "[dsb_index_build] budget %.3f GiB; held at most (GiB): prefix histogram %.3f, k-mers %.3f (%u ranges), unitig numbers %.3f (%u), unitig walk %.3f, positions %.3f (%u), rows %.3f (%u), blocks %.3f (%u), tables + text %.3f (%u)\n",
+		        budget / 1073741824.0, pi.stage_peak[0] / 1073741824.0, pi.stage_peak[1] / 1073741824.0, pi.parts_kmers, pi.stage_peak[2] / 1073741824.0, pi.parts_uid, pi.stage_peak[3] / 1073741824.0,
+		        pi.stage_peak[4] / 1073741824.0, pi.parts_refpos, pi.stage_peak[5] / 1073741824.0, pi.parts_rows, pi.stage_peak[6] / 1073741824.0, pi.parts_blocks, pi.stage_peak[7] / 1073741824.0, pi.parts_exist);
 	t0 = wall();
 	if (dsb_build_write(in, out, out_dir)) return DSB_EIO;
 	if (stats) {

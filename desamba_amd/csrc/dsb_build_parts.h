@@ -43,6 +43,7 @@ struct DsbPartsInfo {
 	uint32_t force_parts = 0;      // tests on small references: this many ranges per stage whatever the budget (DSB_BUILD_PARTS)
 	uint32_t parts_kmers = 0, parts_uid = 0, parts_rows = 0, parts_refpos = 0, parts_exist = 0, parts_blocks = 0;
 	uint64_t n_start_windows = 0, max_part_windows = 0;
+	uint64_t stage_peak[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // bytes held at most in: prefix histogram, k-mers, unitig numbers, unitig walk, positions, rows, blocks, tables + text
 };
 
 DSB_BFN uint64_t b_fetch_add64(uint64_t *p, uint64_t v)
@@ -148,6 +149,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 		be.to_host(hwin.data(), hist, P * 4);
 		be.free(hist);
 	}
+	pi.stage_peak[0] = be.peak_mark();
 	uint64_t n_win = 0;
 	for (uint64_t p = 0; p < P; p++) n_win += hwin[p];
 	if (n_win == 0) return -4;
@@ -265,6 +267,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 	if (n == 0) return -4;
 	out.n_kmer = n;
 	out.t_sort = be.now() - t0; t0 = be.now();
+	pi.stage_peak[1] = be.peak_mark();
 
 	// ---- 2b. unitig starts and ends, window by window; the start windows in text order
 	uint32_t *wcnt = be.template alloc<uint32_t>(n_chunk);
@@ -324,6 +327,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 	if (n_uni == 0 || n_uni * 30 >= 0xfffffff0ULL) return -4;
 	out.n_uni = n_uni;
 	out.t_graph = be.now() - t0; t0 = be.now();
+	pi.stage_peak[2] = be.peak_mark();
 
 	// ---- 3. unitig lengths and last k-mers: a walk over the text with the start list (every occurrence of a unitig says the same)
 	uint32_t *ulen = be.template alloc<uint32_t>(n_uni + 1);
@@ -345,6 +349,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 	if (n_rows != n + 31 * n_uni) return -4;                             // (every k-mer lies in exactly one unitig)
 	out.n_rows = n_rows;
 	out.t_walk = be.now() - t0; t0 = be.now();
+	pi.stage_peak[3] = be.peak_mark();
 	const uint64_t resident = N + 1 + n_chunk * 8 + n_sw * 12 + n_uni * 12;
 	pi.resident = resident;
 	if (budget <= resident + slack) return -5;
@@ -380,6 +385,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 		be.free(cnt); be.free(pos);
 	}
 
+	pi.stage_peak[4] = be.peak_mark();
 	// ---- 5. rows of the BWT matrix.  Rows 0 .. n_uni-1: the terminators; then k-mers and padded suffixes in one order -- the
 	// rows of a range of prefixes are consecutive
 	const uint64_t n_sp = 30 * n_uni;
@@ -486,6 +492,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 	}
 	for (void *p : {(void *)cposS, (void *)S_g, (void *)S_uid, (void *)ulen, (void *)uend}) be.free(p);
 	out.t_rows = be.now() - t0; t0 = be.now();
+	pi.stage_peak[5] = be.peak_mark();
 
 	// ---- 6. checkpointed 4-bit BWT from the finished symbols, a stretch of blocks at a time, the counts carried over
 	const uint64_t n_blk = (n_rows + 255) / 256;
@@ -537,6 +544,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 		}
 	}
 	{ std::vector<uint8_t>().swap(hbw); }
+	pi.stage_peak[6] = be.peak_mark();
 
 	// ---- 7. exist-k-mer filter tables (get_EXIST_kmer, src/idx.c:986-1026): every k-mer of every unitig = every k-mer that lies inside
 	// a 31-mer window of the text; one table, or one stretch of its hash space, at a time
@@ -596,6 +604,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 	be.free(code);
 	dsb_build_finish_host(in, out, hs, hc, h_ulen, h_ru_u, h_ru_g);
 	out.t_tables = be.now() - t0;
+	pi.stage_peak[7] = be.peak_mark();
 	pi.peak = be.peak_bytes();
 	if (pinfo) *pinfo = pi;
 	return 0;

@@ -13,6 +13,7 @@ struct HostBE {
 	template <class T> T *alloc(size_t n) { const size_t b = (n ? n : 1) * sizeof(T); void *p = malloc(b); live[p] = b; live_b += b; if (live_b > peak_b) peak_b = live_b; return (T *)p; }
 	void free(void *p) { auto it = live.find(p); if (it != live.end()) { live_b -= it->second; live.erase(it); } ::free(p); }
 	size_t peak_bytes() const { return peak_b; }
+	size_t peak_mark() { return peak_b; }
 	void zero(void *p, size_t bytes) { memset(p, 0, bytes); }
 	void fill_ff(void *p, size_t bytes) { memset(p, 0xff, bytes); }
 	void to_dev(void *d, const void *s, size_t bytes) { memcpy(d, s, bytes); }
