@@ -324,7 +324,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 			be.free(flag); be.free(rk); be.free(pk.kv); be.free(pk.pre);
 		}
 	}
-	if (n_uni == 0 || n_uni * 30 >= 0xfffffff0ULL) return -4;
+	if (n_uni == 0 || n_uni >= 0xfffffff0ULL) return -4;                 // (the file format's 32-bit unitig numbers; dsb_build_run stops at 2^32 / 30)
 	out.n_uni = n_uni;
 	out.t_graph = be.now() - t0; t0 = be.now();
 	pi.stage_peak[2] = be.peak_mark();
@@ -413,7 +413,8 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 		const uint64_t n_jc = (n_sp + DSB_SCH - 1) / DSB_SCH;
 		uint32_t *jcnt = be.template alloc<uint32_t>(n_jc + 1); uint64_t *jpos = be.template alloc<uint64_t>(n_jc + 1);
 		// per k-mer: list 8 + row 4 + symbol 1 (+ sample 1); per padded suffix: pair 12 + the sort's second buffers 12 + symbol 1 (+ sample 1)
-		auto w5 = [&](uint64_t p) { return 14 * (hpre[p + 1] - hpre[p]) + 26 * (uint64_t)hsp[p] + 20; };     // + per prefix: prefix table 8, first row 8, count 4
+		// (a padded suffix is known by its number j = (length - 1) * n_uni + unitig, 37 bits: the sort carries its place in the range's list)
+		auto w5 = [&](uint64_t p) { return 14 * (hpre[p + 1] - hpre[p]) + 34 * (uint64_t)hsp[p] + 20; };     // + per prefix: prefix table 8, first row 8, count 4
 		const uint64_t cap = cap_for(resident + n_jc * 12, sum_ranges(dsb_make_ranges(w5, ~0ULL)));
 		std::vector<DsbRange> ranges = dsb_make_ranges(w5, cap);
 		pi.parts_rows = (uint32_t)ranges.size();
@@ -426,6 +427,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 			if (m + nsp_r >= 0xffffffffULL) return -5;
 			DsbPartKv pk = dsb_part_load(be, hkv, hpre, plo, phi);
 			uint64_t *spk = be.template alloc<uint64_t>(nsp_r + 1); uint32_t *spi = be.template alloc<uint32_t>(nsp_r + 1);
+			uint64_t *spj = be.template alloc<uint64_t>(nsp_r + 1);
 			// the padded suffixes of the range in generation order (suffix length, unitig), then sorted stably by value
 			be.for_n(n_jc, DSB_LAMBDA(uint64_t c) {
 				const uint64_t j0 = c * DSB_SCH, j1 = j0 + DSB_SCH < n_sp ? j0 + DSB_SCH : n_sp; uint32_t k = 0;
@@ -442,7 +444,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 				for (uint64_t j = j0; j < j1; j++) {
 					const uint32_t s = (uint32_t)(j / n_uni) + 1; const uint64_t u = j % n_uni;
 					const uint64_t key = (uend[u] & ((1ULL << (2 * s)) - 1)) << (2 * (DSB_BK - s)), p = key >> DSB_PRE_SHIFT;
-					if (p >= plo && p < phi) { spk[o] = key; spi[o] = (uint32_t)j; o++; }
+					if (p >= plo && p < phi) { spk[o] = key; spi[o] = (uint32_t)o; spj[o] = j; o++; }
 				}
 			});
 			be.sort_pairs_u64(spk, spi, nsp_r, 62);
@@ -454,7 +456,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 			uint32_t *rowof = be.template alloc<uint32_t>(m + 1);
 			be.fill_ff(hstart, (phi - plo) * 8); be.zero(hcnt, (phi - plo) * 4);
 			be.for_n(nsp_r, DSB_LAMBDA(uint64_t t) {
-				const uint64_t key = spk[t], j = spi[t];
+				const uint64_t key = spk[t], j = spj[spi[t]];
 				const uint32_t s = (uint32_t)(j / n_uni) + 1; const uint64_t u = j % n_uni;
 				const uint64_t lrow = t + b_part_rank(pk, key), row = row0 + lrow;
 				bw[lrow] = (uint8_t)((uend[u] >> (2 * s)) & 3u);
@@ -484,7 +486,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 			be.to_host(hbw.data() + row0, bw, nrow_r);
 			if (ns) be.to_host(&out.sa[2 * s0], sa, ns * 8);
 			be.to_host(&hs[plo], hstart, (phi - plo) * 8); be.to_host(&hc[plo], hcnt, (phi - plo) * 4);
-			for (void *p : {(void *)pk.kv, (void *)pk.pre, (void *)spk, (void *)spi, (void *)bw, (void *)sa, (void *)hstart, (void *)hcnt, (void *)rowof}) be.free(p);
+			for (void *p : {(void *)pk.kv, (void *)pk.pre, (void *)spk, (void *)spi, (void *)spj, (void *)bw, (void *)sa, (void *)hstart, (void *)hcnt, (void *)rowof}) be.free(p);
 			T += nsp_r;
 		}
 		be.free(jcnt); be.free(jpos);

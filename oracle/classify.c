@@ -324,6 +324,17 @@ static int32_t lv_extd(uint8_t *ref, int32_t ref_length, uint8_t *query, int32_t
 #undef LV_RET
 }
 
+/* stage access for tests/test_stage_lv_extd.py: both strings arrive with LVPAD bytes in front of them (what the callers' local buffers,
+ * or the bases in front of a string inside the read, hold there) */
+int32_t ora_lv_extd(const uint8_t *ref_padded, int32_t ref_length, const uint8_t *query_padded, int32_t query_length)
+{
+	uint8_t r[LVPAD + 32], q[LVPAD + 32];
+	if (ref_length < 0 || ref_length > 16 || query_length < 0 || query_length > 16) return -1;
+	memcpy(r, ref_padded, (size_t)(LVPAD + ref_length)); memcpy(q, query_padded, (size_t)(LVPAD + query_length));
+	r[LVPAD + ref_length] = 0; q[LVPAD + query_length] = 0;
+	return lv_extd(r + LVPAD, ref_length, q + LVPAD, query_length);
+}
+
 /* ---- FM index search, src/cly.c:1286-1447 --------------------------------------------- */
 static inline int sp_set_insert(uint64_t node, spset_t *s)
 {
@@ -761,6 +772,32 @@ static bool combine_chain(chain_t *c_st, int chain_ID, sch_t *sc, int dis, bool 
 		key = sc[key].next;
 	}
 	return false;
+}
+
+/* stage access for tests/test_stage_combine_chain.py: n chains as rows of 9 u32 (ref_ID, direction, sum_score, anchor_number, indel, t_st,
+ * t_ed, q_st, q_ed; changed in place), sc_hash_idx over them, then n_q queries of 4 i32 (chain_ID, dis, isleft, c_q_pos) in order:
+ * out[i] = index of the chain combine_chain merged into chain_ID, or -1 */
+void ora_combine_stage(uint32_t *chains, uint32_t n, const int32_t *queries, uint32_t n_q, int32_t *out)
+{
+	chain_t *H = calloc(n + 1, sizeof(chain_t));
+	sch_t *sc = calloc(256 + 2 * (size_t)n + 8, sizeof(sch_t));
+	for (uint32_t i = 0; i < n; i++) {
+		const uint32_t *r = chains + 9 * i;
+		H[i].ref_ID = r[0]; H[i].direction = (uint8_t)r[1]; H[i].sum_score = r[2]; H[i].anchor_number = r[3]; H[i].indel = r[4];
+		H[i].t_st = r[5]; H[i].t_ed = r[6]; H[i].q_st = r[7]; H[i].q_ed = r[8];
+	}
+	sc_hash_idx(sc, H, n);
+	for (uint32_t i = 0; i < n_q; i++) {
+		chain_t *combined = NULL;
+		const int32_t *q = queries + 4 * i;
+		out[i] = combine_chain(H, q[0], sc, q[1], q[2] != 0, q[3], &combined) ? (int32_t)(combined - H) : -1;
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		uint32_t *r = chains + 9 * i;
+		r[0] = H[i].ref_ID; r[1] = H[i].direction; r[2] = H[i].sum_score; r[3] = H[i].anchor_number; r[4] = H[i].indel;
+		r[5] = H[i].t_st; r[6] = H[i].t_ed; r[7] = H[i].q_st; r[8] = H[i].q_ed;
+	}
+	free(H); free(sc);
 }
 
 /* ---- a-12 sparse approximate match scoring, src/cly.c:2173-2849 ------------------------ */

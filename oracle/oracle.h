@@ -95,6 +95,10 @@ void ora_write_sam(FILE *f, const ora_idx_t *idx, const char *name, const char *
 long ora_classify_file(const ora_idx_t *idx, const char *reads_path, const char *out_path,
                        int max_sec, int full, int n_threads, uint64_t *bases);
 uint64_t ora_occ(const ora_idx_t *idx, uint64_t r, uint8_t *c);
+/* a-9 on its own (tests/test_stage_lv_extd.py): the strings with the 8 bytes in front of them that the callers' buffers hold */
+int32_t ora_lv_extd(const uint8_t *ref_padded, int32_t ref_length, const uint8_t *query_padded, int32_t query_length);
+/* a-11 on its own (tests/test_stage_combine_chain.py) */
+void ora_combine_stage(uint32_t *chains, uint32_t n, const int32_t *queries, uint32_t n_q, int32_t *out);
 #ifdef __cplusplus
 }
 #endif

@@ -257,6 +257,40 @@ extern "C" int emu_scan_seeds(void *p, int strand, DsbSeed *out, int max_out, ui
 	return (int)s.ns;
 }
 // loop budget of the following reads (DSB_STEP_LIMIT by default); steps the last read charged
+// a-9 on its own: the device's register-packed lv_extd on two strings that arrive with 8 bytes in front of them (as its callers' local
+// arrays hold them); the end marks go where the callers put them
+extern "C" int32_t emu_lv_extd(const uint8_t *ref_padded, int32_t ref_length, const uint8_t *query_padded, int32_t query_length)
+{
+	uint8_t r[8 + 32], q[8 + 32];
+	if (ref_length < 0 || ref_length > 12 || query_length != ref_length) return -1;
+	memcpy(r, ref_padded, (size_t)(8 + ref_length)); memcpy(q, query_padded, (size_t)(8 + query_length));
+	r[8 + ref_length] = '#'; q[8 + query_length] = '$';
+	return lv_extd(r + 8, ref_length, q + 8, query_length);
+}
+// a-11 on its own: the device's sc_hash_idx / combine_test / combine_chain on chains given as rows of 9 u32 (layout: oracle/oracle.h
+// ora_combine_stage); test_out[i] = what combine_test said right before combine_chain was asked
+extern "C" void emu_combine_stage(uint32_t *chains, uint32_t n, const int32_t *queries, uint32_t n_q, int32_t *out, int32_t *test_out)
+{
+	std::vector<DsbChain> H(n + 1); std::vector<DsbScHash> sc(256 + 2 * (size_t)n + 8);
+	memset(H.data(), 0, H.size() * sizeof(DsbChain)); memset(sc.data(), 0, sc.size() * sizeof(DsbScHash));
+	for (uint32_t i = 0; i < n; i++) {
+		const uint32_t *r = chains + 9 * i;
+		H[i].ref_ID = r[0]; H[i].direction = (uint8_t)r[1]; H[i].sum_score = r[2]; H[i].anchor_number = r[3]; H[i].indel = r[4];
+		H[i].t_st = r[5]; H[i].t_ed = r[6]; H[i].q_st = r[7]; H[i].q_ed = r[8];
+	}
+	sc_hash_idx(sc.data(), H.data(), n);
+	for (uint32_t i = 0; i < n_q; i++) {
+		DsbChain *combined = nullptr;
+		const int32_t *q = queries + 4 * i;
+		test_out[i] = combine_test(H.data(), q[0], sc.data(), q[1], q[2] != 0, q[3]) ? 1 : 0;
+		out[i] = combine_chain(H.data(), q[0], sc.data(), q[1], q[2] != 0, q[3], &combined) ? (int32_t)(combined - H.data()) : -1;
+	}
+	for (uint32_t i = 0; i < n; i++) {
+		uint32_t *r = chains + 9 * i;
+		r[0] = H[i].ref_ID; r[1] = H[i].direction; r[2] = H[i].sum_score; r[3] = H[i].anchor_number; r[4] = H[i].indel;
+		r[5] = H[i].t_st; r[6] = H[i].t_ed; r[7] = H[i].q_st; r[8] = H[i].q_ed;
+	}
+}
 extern "C" void emu_set_step_limit(void *p, uint32_t v) { ((EmuCtx *)p)->w.step_limit = v; ((EmuCtx *)p)->limit_set = v; }
 extern "C" void emu_steps(void *p, uint32_t out[2]) { out[0] = ((EmuCtx *)p)->w.steps; out[1] = ((EmuCtx *)p)->w.lsteps; }
 // work counters of the last read: occ, MEM searches, SA lookups, reference bases fetched
