@@ -348,11 +348,17 @@ DV uint64_t lv_pack(const uint8_t *s, int32_t len, bool query)
 DV uint32_t lv_sym(uint64_t s, int32_t p) { return (uint32_t)(s >> (3 * (p + 5))) & 7u; }
 DV int32_t lv_get(uint64_t tab, int32_t d) { return (int32_t)((tab >> (4 * (d + 5))) & 15u); }
 DV void lv_put(uint64_t &tab, int32_t d, int32_t v) { const int sh = 4 * (d + 5); tab = (tab & ~(15ULL << sh)) | ((uint64_t)(uint32_t)v << sh); }
-DN int32_t lv_extd(const uint8_t *ref, int32_t ref_length, const uint8_t *query, int32_t query_length)
+DN int32_t lv_extd_w(const uint64_t R, const uint64_t Q, const int32_t len);
+// the form on byte strings (the stage test of a-9 enters here; map_seed / get_new_ed build the packed words themselves, below)
+DV int32_t lv_extd(const uint8_t *ref, int32_t ref_length, const uint8_t *query, int32_t query_length)
 {
 	const int32_t len = ref_length;                     // (all callers pass two strings of one length)
 	if (len == 0 && query_length == 0) return 0;
-	const uint64_t R = lv_pack(ref, len, false), Q = lv_pack(query, len, true);
+	return lv_extd_w(lv_pack(ref, len, false), lv_pack(query, len, true), len);
+}
+DN int32_t lv_extd_w(const uint64_t R, const uint64_t Q, const int32_t len)
+{
+	if (len == 0) return 0;
 	// reach[d] = furthest query position on diagonal d, + 1 (0 = nothing yet); spent[d] = errors behind it; d = -5 .. 6
 	uint64_t reach = 0, spent = 0;
 	for (int32_t d = -5; d <= 6; d++) lv_put(spent, d, d > 0 ? d : -d);
@@ -386,6 +392,78 @@ DN int32_t lv_extd(const uint8_t *ref, int32_t ref_length, const uint8_t *query,
 		}
 	}
 	return best;
+}
+
+// ---- the strings of map_seed / get_new_ed (<= 12 symbols) in registers.  "Body" words hold symbol k at bits 3k; lv_word_r / lv_word_q put a
+// body into lv_extd's frame (position p at bits 3 (p + 5)): the end mark at position len, the never-matching fill everywhere else (what
+// lv_pack makes of the callers' byte arrays: 8 pad bytes in front of every local string, oracle U5), and for a query that lies inside the
+// read the real base in front of it.
+DV uint64_t lv_spread8(uint64_t x)
+{	// 8 bytes (each already a 3-bit symbol) -> 24 bits: byte k to bits 3k
+	x = (x | (x >> 5)) & 0x003F003F003F003FULL;
+	x = (x | (x >> 10)) & 0x00000FFF00000FFFULL;
+	return (x | (x >> 20)) & 0xFFFFFFULL;
+}
+DV uint64_t lv_qmap8(uint64_t x)
+{	// query bytes -> symbols: 0..3 stay, anything else is 6 (lv_pack: never equal to a reference symbol)
+	const uint64_t hi = x & 0xFCFCFCFCFCFCFCFCULL;
+	const uint64_t nz = ((((hi & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | hi) & 0x8080808080808080ULL) >> 7;      // 1 in every byte that is not a base
+	const uint64_t sel = nz * 0xFFULL;
+	return ((x & 0x0303030303030303ULL) & ~sel) | (0x0606060606060606ULL & sel);
+}
+DV uint64_t lv_mask3(uint32_t n) { return n >= 21u ? ~0ULL : ((1ULL << (3u * n)) - 1ULL); }
+// q[k] = p[k], k < n <= 12 (bytes behind the string are read and dropped: the strands carry pads)
+DV uint64_t lv_q_fwd(const uint8_t *p, uint32_t n)
+{
+	const uint64_t a = lv_qmap8(dsb_g64u(p)), b = lv_qmap8(dsb_g64u(p + 8));
+	return (lv_spread8(a) | (lv_spread8(b) << 24)) & lv_mask3(n);
+}
+// q[k] = p[-k], k < n <= 12
+DV uint64_t lv_q_rev(const uint8_t *p, uint32_t n)
+{
+	const uint64_t a = lv_qmap8(__builtin_bswap64(dsb_g64u(p - 7))), b = lv_qmap8(__builtin_bswap64(dsb_g64u(p - 15)));
+	return (lv_spread8(a) | (lv_spread8(b) << 24)) & lv_mask3(n);
+}
+DV uint64_t lv_spread2to3(uint64_t x)
+{	// 12 two-bit fields (field k at bits 2k) -> three-bit fields (field k at bits 3k)
+	x = (x & 0xFFFULL) | ((x & 0xFFF000ULL) << 6);
+	x = (x & 0x00000FC003FULL) | ((x & 0x0003F000FC0ULL) << 3);
+	const uint64_t m0 = 0x08040201ULL * 3ULL;                           // field 0 of every group of three (9 bits)
+	return (x & m0) | ((x & (m0 << 2)) << 1) | ((x & (m0 << 4)) << 2);
+}
+// the `length` (<= 12) bases of the 2-bit text from `off` on (fwd) or from `off` down (!fwd) as a body word -- get_ref (src/cly.c:611-627)
+// with the oracle's U6 (a start offset at or beyond `lim` reads as all 0); positions before the text read as 0
+DV uint64_t lv_ref12(const uint8_t *txt, uint64_t lim, int64_t off, int32_t length, bool fwd)
+{
+	if (off < 0) off = 0;
+	if (length <= 0 || (uint64_t)off >= lim) return 0;
+	uint64_t two;                                                       // base k at bits 2k
+	if (fwd) {
+		const uint64_t v = __builtin_bswap64(dsb_g64u(txt + ((uint64_t)off >> 2))) << (2u * ((uint32_t)off & 3u));    // base 0 in the top bits
+		uint64_t r = dsb_brev64(v);                                  // base k at bits 2k, its two bits swapped
+		r = ((r & 0x5555555555555555ULL) << 1) | ((r >> 1) & 0x5555555555555555ULL);
+		two = r & ((1ULL << (2 * length)) - 1ULL);
+	} else {
+		const int64_t lo = off - (length - 1) > 0 ? off - (length - 1) : 0;
+		const uint32_t n = (uint32_t)(off - lo) + 1u;                    // bases that exist: lo .. off
+		const uint64_t b0 = (uint64_t)lo >> 2;
+		const uint64_t v = __builtin_bswap64(dsb_g64u(txt + b0)) << (2u * ((uint32_t)lo & 3u));    // base lo in the top bits
+		two = v >> (64u - 2u * n);                                       // base off - k at bits 2k
+	}
+	return lv_spread2to3(two);
+}
+// how many leading symbols of two bodies agree, at most len
+DV int32_t lv_common(uint64_t T, uint64_t Q, uint32_t len) { return (int32_t)((uint32_t)__builtin_ctzll((T ^ Q) | (1ULL << (3u * len))) / 3u); }
+DV uint64_t lv_word_r(uint64_t body, int32_t len)
+{
+	const uint64_t in = lv_mask3((uint32_t)len) << 15;
+	return ((body << 15) & in) | (4ULL << (3 * (len + 5))) | (0x7FFFFFFFFFFFFFFFULL & ~in & ~(7ULL << (3 * (len + 5))));
+}
+DV uint64_t lv_word_q(uint64_t body, int32_t len, uint32_t before)     // before: the symbol at position -1 (6: a local copy, nothing in front)
+{
+	const uint64_t in = lv_mask3((uint32_t)len) << 15;
+	const uint64_t fixed = in | (7ULL << (3 * (len + 5))) | (7ULL << 12);
+	return ((body << 15) & in) | (5ULL << (3 * (len + 5))) | ((uint64_t)before << 12) | (0x6DB6DB6DB6DB6DB6ULL & ~fixed);
 }
 
 // ---- FM search (src/cly.c:1286-1447) --------------------------------------------------------
@@ -486,53 +564,41 @@ DV uint64_t prefix13(const uint8_t *bin, int string_index)
 
 struct AMap { uint16_t mtch_len; int16_t score; uint8_t left_len, left_ED, rigt_len, rigt_ED; };
 
-#define LVPAD 8
-#define LVPAD_Q 0xF1
-#define LVPAD_T 0xF2
-struct LvBuf { uint8_t b[LVPAD + 16]; };
-DV void lvbuf_init(LvBuf &v, uint8_t pad) {
-#pragma unroll
-	for (int i = 0; i < LVPAD; i++) v.b[i] = pad;
-}
-
 // get_new_ed (src/cly.c:629-694).  The right-side query is copied out of the read (with its
 // preceding byte) so that lv_extd works on local strings only; the reference's in-place
 // sentinel write is restored before it returns, so this is equivalent.
 DV void get_new_ed(DsbXP x, const Cnt &k, uint32_t *e_d, uint32_t *len_, uint32_t *l_mem_ext,
                    int32_t q_off, uint64_t t_off, uint32_t l_read, const uint8_t *q_b, bool is_FWD)
 {
-	LvBuf qb, tb; lvbuf_init(qb, LVPAD_Q); lvbuf_init(tb, LVPAD_T);
-	uint8_t *q = qb.b + LVPAD, *t = tb.b + LVPAD;
 	uint32_t len, max_len;
 	const uint8_t *t_b = x->refbin;
 	const uint8_t *qp = q_b;   // right side: current query pointer inside the read
+	uint64_t Qb, Tb;           // the two strings (<= 12 symbols) as body words: registers, not byte arrays in scratch memory
 	if (is_FWD) {
 		if (q_off < 0) q_off = 0;
 		max_len = q_off; len = MINV(12, max_len);
-		for (uint32_t k = 0; k < len; k++) q[k] = q_b[q_off - k];
+		Qb = lv_q_rev(q_b + q_off, len);
 	} else {
 		max_len = l_read - q_off; len = MINV(12, max_len);
 		qp = q_b + q_off;
-		for (uint32_t k = 0; k < len; k++) q[k] = qp[k];
+		Qb = lv_q_fwd(qp, len);
 	}
 	uint32_t n_rw = len;
-	get_ref_small(t_b, x->ref_bases, t, t_off, len, !is_FWD);
-	if (len > 0 && t[0] == q[0]) {
+	Tb = lv_ref12(t_b, x->ref_bases, (int64_t)t_off, (int32_t)len, !is_FWD);
+	if (len > 0) {
 		int mtc;
-		do {
-			for (mtc = 0; mtc < len; mtc++) if (t[mtc] != q[mtc]) break;
-			if (mtc > 0) {
-				*l_mem_ext += mtc; max_len -= mtc; len = MINV(12, max_len);
-				if (is_FWD) { q_off -= mtc; t_off -= mtc; for (uint32_t k = 0; k < len; k++) q[k] = q_b[q_off - k]; }
-				else { t_off += mtc; qp += mtc; for (uint32_t k = 0; k < len; k++) q[k] = qp[k]; }
-				get_ref_small(t_b, x->ref_bases, t, t_off, len, !is_FWD); n_rw += len;
-			}
-		} while (mtc > 0);
+		while ((mtc = lv_common(Tb, Qb, len)) > 0) {
+			*l_mem_ext += mtc; max_len -= mtc; len = MINV(12, max_len);
+			if (is_FWD) { q_off -= mtc; t_off -= mtc; Qb = lv_q_rev(q_b + q_off, len); }
+			else { t_off += mtc; qp += mtc; Qb = lv_q_fwd(qp, len); }
+			Tb = lv_ref12(t_b, x->ref_bases, (int64_t)t_off, (int32_t)len, !is_FWD); n_rw += len;
+			if (len == 0) break;
+		}
 	}
 	cnt_add(k, 3, n_rw);
-	if (!is_FWD) q[-1] = qp[-1];          // the byte in front of a string inside the read is a real base
-	t[len] = '#'; q[len] = '$';
-	*e_d = lv_extd(t, len, q, len);
+	// the byte in front of a string inside the read is a real base (right side); a left-side string is a reversed copy with nothing in front
+	const uint32_t before = is_FWD ? 6u : (uint32_t)(lv_qmap8((uint64_t)qp[-1]) & 7u);
+	*e_d = (uint32_t)lv_extd_w(lv_word_r(Tb, (int32_t)len), lv_word_q(Qb, (int32_t)len, before), (int32_t)len);
 	*len_ = len;
 }
 
@@ -552,11 +618,11 @@ DV int32_t map_seed(DsbXP x, LCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t 
 	const int *Q_MEM = x->qmem; const int *Q_LV = x->qlv;
 	const Cnt k = WK(w); uint32_t n_occ = 0, n_rw = 0;
 	do {
-		LvBuf qpre, tpre, qsuf, tsuf;
-		lvbuf_init(qpre, LVPAD_Q); lvbuf_init(tpre, LVPAD_T); lvbuf_init(tsuf, LVPAD_T);
-		uint8_t *q_pre = qpre.b + LVPAD, *t_pre = tpre.b + LVPAD, *t_suf = tsuf.b + LVPAD, *q_sufb = qsuf.b + LVPAD;
+		// the four strings (<= 12 symbols each) as body words in registers (lv_q_rev / lv_q_fwd / lv_ref12): rounds 1-3 kept them as byte
+		// arrays, i.e. in scratch memory, filled and re-read byte by byte
 		l_pre = MINV(q_off + 1, 12);
-		for (uint32_t k = 0; k < l_pre; k++) q_pre[k] = q_b[q_off - (int)k];
+		const uint64_t Qpre = lv_q_rev(q_b + q_off, l_pre);
+		uint64_t Tpre = 0;
 		int s_l = 0;
 		if (m_r.sa_sp != D_U64MAX) uni = get_uni(x, k, m_r.sa_sp, m_r.sa_sp_l, &t_off, &u_off);
 		else {
@@ -566,7 +632,7 @@ DV int32_t map_seed(DsbXP x, LCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t 
 				ch = 0xff;
 				new_sp = fm_occ(x, b_p, ch); new_sp += x->rank[ch]; n_occ++;
 				if (ch == 4) break;
-				t_pre[s_l++] = ch; b_p = new_sp;
+				Tpre |= (uint64_t)(ch < 4u ? ch : 7u) << (3 * s_l); s_l++; b_p = new_sp;
 				if (s_l >= l_pre) break;
 			}
 			if ((b_p & 7) == 0) uni = get_uni(x, k, b_p, s_l, &t_off, &u_off);
@@ -575,10 +641,9 @@ DV int32_t map_seed(DsbXP x, LCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t 
 		if (uni >= 0) {
 			if (DSB_G32(x->uni, 2 * uni + 1) < 35) break;
 			l_pre = MINV(l_pre, u_off);
-			get_ref_small(t_b, x->ref_bases, t_pre, t_off - 1, l_pre, false); n_rw += l_pre;
+			Tpre = lv_ref12(t_b, x->ref_bases, (int64_t)t_off - 1, (int32_t)l_pre, false); n_rw += l_pre;
 		}
-		t_pre[l_pre] = '#'; q_pre[l_pre] = '$';
-		d_pre = lv_extd(t_pre, l_pre, q_pre, l_pre);
+		d_pre = (uint32_t)lv_extd_w(lv_word_r(Tpre, (int32_t)l_pre), lv_word_q(Qpre, (int32_t)l_pre, 6u), (int32_t)l_pre);
 		s = Q_MEM[l_m] + Q_LV[d_pre * 20 + l_pre];
 		if (s < 12 && l_pre == 12 && uni < 0) { s = 0; break; }
 		if (uni < 0) {
@@ -591,22 +656,15 @@ DV int32_t map_seed(DsbXP x, LCtx &w, DsbMem &m_r, const uint8_t *q_b, uint32_t 
 		if (l_max_suf != 0) {
 			l_suf = MINV(l_max_suf, 12);
 			const uint8_t *q_suf = q_b + q_off_r;
-			get_ref_small(t_b, x->ref_bases, t_suf, t_off + l_m, l_suf, true); n_rw += l_suf;
-			if (t_suf[0] == q_suf[0]) {
-				int mtc;
-				do {
-					for (mtc = 0; mtc < l_suf; mtc++) if (t_suf[mtc] != q_suf[mtc]) break;
-					if (mtc > 0) {
-						l_m += mtc;
-						s = Q_MEM[l_m] + Q_LV[d_pre * 20 + l_pre];
-						l_max_suf -= mtc; l_suf = MINV(l_max_suf, 12); q_suf += mtc;
-						get_ref_small(t_b, x->ref_bases, t_suf, t_off + l_m, l_suf, true); n_rw += l_suf;
-					}
-				} while (mtc > 0);
+			uint64_t Tsuf = lv_ref12(t_b, x->ref_bases, (int64_t)(t_off + l_m), (int32_t)l_suf, true), Qsuf = lv_q_fwd(q_suf, l_suf); n_rw += l_suf;
+			int mtc;
+			while ((mtc = lv_common(Tsuf, Qsuf, l_suf)) > 0) {
+				l_m += mtc;
+				s = Q_MEM[l_m] + Q_LV[d_pre * 20 + l_pre];
+				l_max_suf -= mtc; l_suf = MINV(l_max_suf, 12); q_suf += mtc;
+				Tsuf = lv_ref12(t_b, x->ref_bases, (int64_t)(t_off + l_m), (int32_t)l_suf, true); Qsuf = lv_q_fwd(q_suf, l_suf); n_rw += l_suf;
 			}
-			for (int k = -1; k < (int)l_suf; k++) q_sufb[k] = q_suf[k];
-			t_suf[l_suf] = '#'; q_sufb[l_suf] = '$';
-			d_suf = lv_extd(t_suf, l_suf, q_sufb, l_suf);
+			d_suf = (uint32_t)lv_extd_w(lv_word_r(Tsuf, (int32_t)l_suf), lv_word_q(Qsuf, (int32_t)l_suf, (uint32_t)(lv_qmap8((uint64_t)q_suf[-1]) & 7u)), (int32_t)l_suf);
 			s += Q_LV[d_suf * 20 + l_suf];
 		} else l_suf = d_suf = 0;
 		if (s <= 20 && l_suf == 12) { s = 0; break; }

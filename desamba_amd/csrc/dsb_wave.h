@@ -100,6 +100,7 @@ typedef uint64_t dsb_u64u __attribute__((aligned(1)));
 typedef uint32_t dsb_u32u __attribute__((aligned(1)));
 DV uint64_t dsb_g64u(const uint8_t *p) { return *(const __attribute__((address_space(1))) dsb_u64u *)p; }      // unaligned
 DV uint32_t dsb_g32u(const uint8_t *p) { return *(const __attribute__((address_space(1))) dsb_u32u *)p; }
+DV uint64_t dsb_brev64(uint64_t x) { return __builtin_bitreverse64(x); }                       // v_bfrev_b32 x 2
 // the four 16-byte quarters of one 64-byte rank line
 DV void dsb_ld_line(const DsbFmBlock *b, uint4 (&a)[4])
 {

@@ -88,4 +88,11 @@ DV void ring_st(uint4 *ring, uint32_t i, uint4 v) { ring[i] = v; }
 #define DSB_G32(p, i) (((const uint32_t *)(p))[i])
 static inline uint64_t dsb_g64u(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 static inline uint32_t dsb_g32u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+static inline uint64_t dsb_brev64(uint64_t x)
+{
+	x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+	x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+	x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+	return __builtin_bswap64(x);
+}
 DV void dsb_ld_line(const DsbFmBlock *b, uint4 (&a)[4]) { __builtin_memcpy(a, b, 64); }
