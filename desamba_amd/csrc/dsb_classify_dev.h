@@ -505,7 +505,10 @@ DV void bwt_single_search(DsbXP x, const Cnt &k, uint64_t sp, const uint8_t *str
 	m.sp = sp; m.match_len = match_len; m.sa_sp = sa_sp; m.sa_sp_l = sa_sp_l;
 }
 
-DV int bwt_MEM_search(DsbXP x, const Cnt &k, const uint8_t *string, uint64_t pre_v, int max_rst, int l_min_mth, int l_max_mth, SpSet &sp_set, DsbMem *mem)
+// put(i, m): keeps result i.  fast_island's two results live in registers (a result array indexed by a run-time count is scratch memory:
+// a dozen stores and loads per search in per-lane code), slow_classify's list is in the arena.
+template <class Put>
+DV int bwt_MEM_search_t(DsbXP x, const Cnt &k, const uint8_t *string, uint64_t pre_v, int max_rst, int l_min_mth, int l_max_mth, SpSet &sp_set, Put put)
 {
 	int n_rst = 0; uint32_t n_occ = 0;
 	cnt_add(k, 1, 1u);
@@ -532,20 +535,25 @@ DV int bwt_MEM_search(DsbXP x, const Cnt &k, const uint8_t *string, uint64_t pre
 	}
 	cnt_add(k, 0, n_occ);
 	if (new_sp >= new_ep) return 0;
+	DsbMem cur; cur.read_offset = 0; cur.pad = 0; cur.sp = cur.sa_sp = 0; cur.sa_sp_l = 0;
 	if (new_sp + 1 == new_ep) {
 		if (sp_set_insert(new_sp, sp_set) == 0) return 0;
-		bwt_single_search(x, k, new_sp, string, MAXV(0, l_max_mth - match_len), sp_set, mem[n_rst]);
-		mem[n_rst].match_len += match_len + 1;
-		if (mem[n_rst].match_len >= l_min_mth) n_rst++;
+		bwt_single_search(x, k, new_sp, string, MAXV(0, l_max_mth - match_len), sp_set, cur);
+		cur.match_len += match_len + 1;
+		if (cur.match_len >= l_min_mth) { put(n_rst, cur); n_rst++; }
 	} else {
 		for (uint64_t c_sp = new_sp; c_sp < new_ep; c_sp++) {
 			if (sp_set_insert(c_sp, sp_set) == 0) continue;
-			bwt_single_search(x, k, c_sp, string, MAXV(0, l_max_mth - match_len), sp_set, mem[n_rst]);
-			mem[n_rst].match_len += match_len + 1;
-			if (mem[n_rst].match_len >= l_min_mth) n_rst++;
+			bwt_single_search(x, k, c_sp, string, MAXV(0, l_max_mth - match_len), sp_set, cur);
+			cur.match_len += match_len + 1;
+			if (cur.match_len >= l_min_mth) { put(n_rst, cur); n_rst++; }
 		}
 	}
 	return n_rst;
+}
+DV int bwt_MEM_search(DsbXP x, const Cnt &k, const uint8_t *string, uint64_t pre_v, int max_rst, int l_min_mth, int l_max_mth, SpSet &sp_set, DsbMem *mem)
+{
+	return bwt_MEM_search_t(x, k, string, pre_v, max_rst, l_min_mth, l_max_mth, sp_set, [&](int i, const DsbMem &m) { mem[i] = m; });
 }
 
 // 13-base prefix value of the k-mer window ending at string_index (= kmer[kmer_index] & PRE_IDX_MASK,
@@ -837,7 +845,7 @@ DV int fast_island(DsbXP x, LCtx &w, const SDirV s_d, uint32_t read_len, uint32_
 	uint8_t *bin_read = s_d.bin_read;
 	SpSet sp_set = {w.spset, 0, DSB_SPSET_CAP, w.sp_gen};
 	sp_set_reset(sp_set);
-	DsbMem m_r[2];
+	DsbMem m_r0, m_r1;                                                   // (at most two results per search: registers)
 	DsbSeed sv = s_d.seed_v[seed_idx];
 	int skip_next = 0;
 	uint32_t a_b_idx = w.n_anc;
@@ -850,7 +858,7 @@ DV int fast_island(DsbXP x, LCtx &w, const SDirV s_d, uint32_t read_len, uint32_
 			int kmer_index = sv.offset + j;
 			string_index = kmer_index + l_ek - 1;
 			uint64_t prefixValue = prefix13(bin_read, string_index);
-			n = bwt_MEM_search(x, w.k, bin_read + string_index, prefixValue, 2, 21 - 1, string_index, sp_set, m_r);
+			n = bwt_MEM_search_t(x, w.k, bin_read + string_index, prefixValue, 2, 21 - 1, string_index, sp_set, [&](int i, const DsbMem &m) { if (i == 0) m_r0 = m; else m_r1 = m; });
 			if (n == 0) { j -= 2; continue; }
 			j -= 3;
 			break;
@@ -858,8 +866,9 @@ DV int fast_island(DsbXP x, LCtx &w, const SDirV s_d, uint32_t read_len, uint32_
 		if (n == 0) break;
 		int max_score = 0;
 		for (int q = 0; q < n; ++q) {
-			m_r[q].read_offset = string_index - m_r[q].match_len;
-			int sc = map_seed(x, w, m_r[q], bin_read, read_len, (uint16_t)seed_idx, (uint8_t)s_d.direction);
+			DsbMem cur = q == 0 ? m_r0 : m_r1;
+			cur.read_offset = string_index - cur.match_len;
+			int sc = map_seed(x, w, cur, bin_read, read_len, (uint16_t)seed_idx, (uint8_t)s_d.direction);
 			max_score = MAXV(sc, max_score);
 		}
 		if (max_score > 35) j -= 7;

@@ -45,6 +45,20 @@ struct DsbReadDesc {
 };
 struct DsbWordDesc { uint32_t read; uint32_t word; };   // word: bit 31 = strand R, low bits = word index
 
+// Compilation units.  k_classify inlines every stage function (dsb_wave.h: a callee would save ~64 callee-saved vector registers per call and
+// lane -- 58 GB written per launch in round 3 -- and pin local state in scratch memory), which makes it, its two siblings and k_classify_heavy
+// a minute of compile time EACH.  -DDSB_KUNIT=n compiles this file as one of five units that are built side by side and linked into the
+// library: 0 = the host side and the small kernels (the four big ones only declared), 1 .. 4 = one big kernel each and nothing else.
+// Without DSB_KUNIT the file is one unit, as before (tools/kernel_resources.sh, experiments).
+#if !defined(DSB_KUNIT)
+#define DSB_UNIT_HAS(n) 1
+#define DSB_UNIT_HOST 1
+#else
+#define DSB_UNIT_HAS(n) (DSB_KUNIT == (n))
+#define DSB_UNIT_HOST (DSB_KUNIT == 0)
+#endif
+
+#if DSB_UNIT_HOST
 __device__ __forceinline__ uint32_t d_code(uint8_t ch)
 {	// CLY_Bit, src/cly.c:17-35: anything that is not A/G/T is C
 	return (ch == 'A' || ch == 'a') ? 0u : (ch == 'G' || ch == 'g') ? 2u : (ch == 'T' || ch == 't') ? 3u : 1u;
@@ -420,6 +434,8 @@ __global__ void __launch_bounds__(1024) k_order(const uint32_t *score, uint32_t 
 	for (uint32_t i = threadIdx.x; i < n; i += 1024) order[atomicAdd(&start[order_bucket(score[i])], 1u)] = i;
 }
 
+#endif  // DSB_UNIT_HOST (the small kernels)
+
 // ---- classify kernel: persistent waves, one read each ------------------------------------------
 struct DsbSlotArena {
 	uint8_t *base; size_t stride;                 // per-slot bytes
@@ -437,6 +453,7 @@ struct DsbSlotArena {
 #endif
 // One kernel body for the three launches of a batch (main, early, second run): a device function, instantiated by three thin kernels
 // so that profiles list the launches apart.  One wavefront per workgroup.
+#if DSB_UNIT_HAS(1) || DSB_UNIT_HAS(2) || DSB_UNIT_HAS(3)
 __device__ __forceinline__ void classify_kernel_body(const DsbDevIndex &x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,
         const uint32_t *list, uint8_t *bin, const uint64_t *bits, const DsbSlotArena &ar, unsigned int *work_counter, DsbReadOut *rout,
         DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg, uint32_t item_base, uint32_t slot_base, unsigned long long *work_cnt, DsbSeed *seed_blob, const DsbSeedInfo *sinfo, const uint64_t *pk, uint32_t group_mode)
@@ -556,17 +573,29 @@ __device__ __forceinline__ void classify_kernel_body(const DsbDevIndex &x, const
 		}
 	}
 }
-
+#endif
 
 #define DSB_CLASSIFY_ARGS DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr, const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, \
         unsigned int *work_counter, DsbReadOut *rout, DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t *dbg, uint32_t item_base, uint32_t slot_base, unsigned long long *work_cnt, \
         DsbSeed *seed_blob, const DsbSeedInfo *sinfo, const uint64_t *pk, uint32_t group_mode
 #define DSB_CLASSIFY_PASS x, rd, n_fixed, n_ptr, list, bin, bits, ar, work_counter, rout, hout, hout_counter, hout_cap, dbg, item_base, slot_base, work_cnt, seed_blob, sinfo, pk, group_mode
+#if DSB_UNIT_HAS(1)
 __global__ void __launch_bounds__(64, DSB_WAVES_PER_EU) k_classify(DSB_CLASSIFY_ARGS) { classify_kernel_body(DSB_CLASSIFY_PASS); }
+#else
+__global__ void k_classify(DSB_CLASSIFY_ARGS);
+#endif
 // the same under a second name for the early launch of the heaviest reads, so that profiles list the two apart
+#if DSB_UNIT_HAS(2)
 __global__ void __launch_bounds__(64, DSB_WAVES_PER_EU) k_classify_early(DSB_CLASSIFY_ARGS) { classify_kernel_body(DSB_CLASSIFY_PASS); }
+#else
+__global__ void k_classify_early(DSB_CLASSIFY_ARGS);
+#endif
 // ... and a third one for the second run of reads whose match-node arena overflowed (usually an empty launch)
+#if DSB_UNIT_HAS(3)
 __global__ void __launch_bounds__(64, DSB_WAVES_PER_EU) k_classify_second(DSB_CLASSIFY_ARGS) { classify_kernel_body(DSB_CLASSIFY_PASS); }
+#else
+__global__ void k_classify_second(DSB_CLASSIFY_ARGS);
+#endif
 
 
 
@@ -577,6 +606,7 @@ __global__ void __launch_bounds__(64, DSB_WAVES_PER_EU) k_classify_second(DSB_CL
 // k_classify (atomic counter over the LPT order); every wave reaches every barrier, so the grid drains.
 // MWW wavefronts per read (8 in both uses: the 16 heaviest reads of the order from the start, beside the main launch --
 // their helper waves hold 112 wave slots the whole time (32 reads: +1 % on the bench workload, -15 % on the tandem-repeat strain index) -- and the pass over the reads given up as heavy)
+#if DSB_UNIT_HAS(4)
 template <int MWW>
 __global__ void __launch_bounds__(64 * MWW, DSB_WAVES_PER_EU) k_classify_heavy(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,
         const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout,
@@ -667,7 +697,18 @@ __global__ void __launch_bounds__(64 * MWW, DSB_WAVES_PER_EU) k_classify_heavy(D
 		}
 	}
 }
+#if defined(DSB_KUNIT)
+template __global__ void k_classify_heavy<8>(DsbDevIndex, const DsbReadDesc *, uint32_t, const unsigned int *, const uint32_t *, uint8_t *, const uint64_t *, DsbSlotArena, unsigned int *, DsbReadOut *, DsbHitOut *, unsigned int *, uint32_t, uint32_t, unsigned long long *, const uint64_t *, DsbSeed *, const DsbSeedInfo *);
+#endif
+#else
+template <int MWW>
+__global__ void k_classify_heavy(DsbDevIndex x, const DsbReadDesc *rd, uint32_t n_fixed, const unsigned int *n_ptr,
+        const uint32_t *list, uint8_t *bin, const uint64_t *bits, DsbSlotArena ar, unsigned int *work_counter, DsbReadOut *rout,
+        DsbHitOut *hout, unsigned int *hout_counter, uint32_t hout_cap, uint32_t slot_base, unsigned long long *work_cnt, const uint64_t *pk,
+        DsbSeed *seed_blob, const DsbSeedInfo *sinfo);
+#endif
 
+#if DSB_UNIT_HOST
 // reads of a finished launch whose status has one of the `mask` bits are listed for another run
 __global__ void k_collect_retry(const DsbReadOut *rout, uint32_t n, uint32_t *list, unsigned int *count, int mask, int clear_n)
 {
@@ -801,6 +842,7 @@ struct DsbKnobs {
 	long hout_cap = 0, sms_cap = 0, anc_cap_rt = 0, upload_chunk_kb = 0, step_limit_rt = 0, group_head = -1;
 	int upload_threads = 0, seed_scan = -1, heavy_mw = -1, heavy_first = 0;
 	bool heavy_preds_set = false; uint32_t heavy_preds = 0;
+	bool scan_look_set = false; DsbScanLook scan_look;   // DSB_SCAN_LOOK=after_seed,back_fwd,fwd_n,stride_n: k_seed_scan's look-ahead (experiments; default dsb_scan_look_for)
 	std::string order_file;
 };
 static bool g_upload_trace = false;           // (the buffer helpers below have no context at hand: DSB_UPLOAD_TRACE of the last knobs_read)
@@ -821,6 +863,13 @@ static void knobs_read(DsbKnobs &k)
 	k.heavy_first_set = getenv("DSB_HEAVY_FIRST") != nullptr; k.heavy_first = (int)num("DSB_HEAVY_FIRST", 0);
 	if (const char *e = getenv("DSB_HEAVY_PREDS")) { k.heavy_preds_set = true; k.heavy_preds = (uint32_t)strtoul(e, nullptr, 10); }
 	if (const char *e = getenv("DSB_ORDER_FILE")) k.order_file = e;
+	k.scan_look_set = false;
+	if (const char *e = getenv("DSB_SCAN_LOOK")) {
+		int a = 0, b = 0, f = 0, st = 0;
+		if (sscanf(e, "%d,%d,%d,%d", &a, &b, &f, &st) == 4 && a >= 1 && a <= DSB_SCAN_W && b >= 1 && b <= DSB_SCAN_W - 2 && f >= 1 && f <= DSB_SCAN_W && st >= 1 && st <= DSB_SCAN_W) {
+			k.scan_look.after_seed = (uint8_t)a; k.scan_look.back_fwd = (uint8_t)b; k.scan_look.fwd_n = (uint8_t)f; k.scan_look.stride_n = (uint8_t)st; k.scan_look_set = true;
+		}
+	}
 	g_upload_trace = k.upload_trace;
 }
 
@@ -1516,7 +1565,7 @@ static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn)
 	if (use_scan) {
 		hipLaunchKernelGGL(k_seed_scan, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const uint32_t *)(s.ragged ? s.d_scan_order : nullptr),
 		                   (uint32_t)n, (const uint64_t *)c->d_pk, c->d_seeds, c->d_sinfo, (const uint8_t *)c->d_summ, c->summ_shift, (unsigned long long *)(c->d_counters + 40),
-		                   dsb_scan_look_for((c->dx.ek_mask + 1) / 8));
+		                   c->knobs.scan_look_set ? c->knobs.scan_look : dsb_scan_look_for((c->dx.ek_mask + 1) / 8));
 	} else if (s.n_words_total) {
 		uint64_t waves = (s.n_words_total + DSB_PROBE_UN - 1) / DSB_PROBE_UN; unsigned blocks = (unsigned)((waves + 3) / 4);
 		if (blocks > 256u * 32u) blocks = 256u * 32u;       // >= 8 blocks of 4 waves per CU, grid-stride beyond
@@ -1897,3 +1946,4 @@ extern "C" int dsb_multi_classify_batch(dsb_multi *m, const dsb_read *reads, siz
 	out->reads = m->reads.data(); out->hits = m->hits.data(); out->n_hits = m->hits.size();
 	return worst;
 }
+#endif  // DSB_UNIT_HOST

@@ -45,10 +45,10 @@
 //     the demo index (1 % full: a hit is a true seed and goes on) is unchanged, 52.1 / 52.6 ms;
 //   * multi-GiB tables in HBM (2 x 2 GiB synthetic, 20 % full): the same 80 ms either way -- there the lanes' round trips are the limit
 //     (131072 strands, a round trip of 2-3 us), so the longer look-ahead stays: it keeps the kernel at 0.96 of the random-gather ceiling.
-struct DsbScanLook { uint8_t after_seed, back_fwd, fwd_n, pad; };
+struct DsbScanLook { uint8_t after_seed, back_fwd, fwd_n, stride_n; };   // stride_n: stride points per round while they miss (<= DSB_SCAN_W)
 static inline DsbScanLook dsb_scan_look_for(uint64_t table_bytes)
 {
-	DsbScanLook k; k.pad = 0;
+	DsbScanLook k; k.stride_n = DSB_SCAN_W;
 	if (table_bytes <= (256ull << 20)) { k.after_seed = 4; k.back_fwd = 2; k.fwd_n = 4; } else { k.after_seed = 8; k.back_fwd = 6; k.fwd_n = 8; }
 	return k;
 }
@@ -68,7 +68,7 @@ DSB_SCAN_FN void dsb_scan_init(DsbScan &s, uint32_t n, DsbScanLook look)
 {
 	s.look = look;
 	s.n = n; s.i = 2; s.mode = n > 2 ? DSB_SCAN_STRIDE : DSB_SCAN_DONE;
-	s.off = s.len = s.j = 0; s.spec = DSB_SCAN_W;
+	s.off = s.len = s.j = 0; s.spec = look.stride_n;
 	s.ns = 0; s.total = 0; s.max_index = 0; s.max_length = 0; s.index_end = 100; s.cur_top = 0;
 }
 
@@ -132,7 +132,7 @@ DSB_SCAN_FN void dsb_scan_consume(DsbScan &s, uint32_t bits, bool rc, Store &sto
 {
 	if (s.mode == DSB_SCAN_STRIDE) {
 		if (bits) { s.i += 3u * (uint32_t)__builtin_ctz(bits); s.mode = DSB_SCAN_BACK; }
-		else { s.i += 3u * s.spec; s.spec = DSB_SCAN_W; if (s.i >= s.n) s.mode = DSB_SCAN_DONE; }
+		else { s.i += 3u * s.spec; s.spec = s.look.stride_n; if (s.i >= s.n) s.mode = DSB_SCAN_DONE; }
 	} else if (s.mode == DSB_SCAN_BACK) {
 		const uint32_t back = (bits & 1u) ? ((bits & 2u) ? 2u : 1u) : 0u;
 		s.off = s.i - back; s.len = 1 + back; s.j = s.i + 1;

@@ -11,10 +11,15 @@
 
 // ---- function qualifiers, group width ----------------------------------------------------------------------------------
 #define DV __device__ __forceinline__
-#ifdef DSB_INLINE_ALL
-#define DN __device__ __forceinline__
-#else
+// DN: the stage functions.  Inlined into the kernels by default: as callees they save the callee-saved vector registers they use (~64 per
+// call and lane: sdp_right / sdp_left / sdp_middle once per chain -- most of the 58 GB a launch wrote in rounds 3-4) and keep what lives
+// across their own calls in scratch memory; inlined, k_classify needs 464 B of scratch per lane instead of 1088.  The price is compile
+// time (a minute per big kernel: dsb_gpu.hip is built as five units side by side, DSB_KUNIT); -DDSB_NO_INLINE gives the quick build
+// (ten seconds, same results, same speed) for work on the device code.
+#ifdef DSB_NO_INLINE
 #define DN __device__ __noinline__
+#else
+#define DN __device__ __forceinline__
 #endif
 #define DSB_WAVE 64
 #define DSB_LANE ((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)))
