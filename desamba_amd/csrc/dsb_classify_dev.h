@@ -2642,8 +2642,11 @@ DN int gap_lane(WCtxL &w, const DsbGap g, const uint64_t *qpk, uint64_t t_offset
 			for (uint32_t j = 0; j <= w1 - w0; j++) lq[j * DSB_WAVE] = DSB_G64(qpk, w0 + j);
 			const uint8_t *txt = x->refbin;
 			const uint32_t hi = q_ed < L - 9 ? q_ed : L - 9;                // last query position with a 9-mer inside the window
+			uint64_t tw_next = gl_tload(txt, ref_offset + 4);
 			for (uint32_t i = 4; i < t_kmer_num; i += 4) {
-				const uint64_t tw = gl_tload(txt, ref_offset + i);
+				// (the next probed position's bases are asked for a step ahead: the load's round trip hides behind this step's compares;
+				// the window lies >= 64 bases inside the text, checked above)
+				const uint64_t tw = tw_next; tw_next = gl_tload(txt, ref_offset + i + 4);
 				uint64_t rep[9];
 #pragma unroll
 				for (int b = 0; b < 9; b++) { const uint32_t v = (uint32_t)(tw >> (62 - 2 * b)); rep[b] = ((v & 1u) ? 0x5555555555555555ULL : 0ULL) | ((v & 2u) ? 0xAAAAAAAAAAAAAAAAULL : 0ULL); }

@@ -730,6 +730,7 @@ struct DsbStaged {
 	DsbDevIndex dx;                                // filter parameters / per-launch fields are filled in by the ctx
 	std::vector<void *> allocs;
 	uint8_t *d_summ; int summ_shift;               // cache-resident summary of exist table 0 (k_ek_summary); null = off
+	bool ek_dense = false;                         // the summary was dropped as useless: the tables are more than ~4 % full (k_seed_scan's look-ahead asks)
 	std::mutex run_mu;                             // the kernels of ONE batch at a time on this device (dsb_batch_run)
 };
 static std::mutex g_stage_mu;
@@ -780,7 +781,7 @@ static int stage_build(dsb_index *idx, int device, DsbStaged **out)
 					std::vector<uint64_t> hs((n_out + 7) / 8, 0);
 					if (hipMemcpy(hs.data(), s->d_summ, n_out, hipMemcpyDeviceToHost) != hipSuccess) rc = DSB_ENODEV;
 					uint64_t ones = 0; for (uint64_t v : hs) ones += (uint64_t)__builtin_popcountll(v);
-					if ((double)ones > 0.9 * 8.0 * (double)n_out) { s->d_summ = nullptr; s->summ_shift = 0; }
+					if ((double)ones > 0.9 * 8.0 * (double)n_out) { s->d_summ = nullptr; s->summ_shift = 0; s->ek_dense = true; }
 				}
 			}
 		}
@@ -874,6 +875,7 @@ static void knobs_read(DsbKnobs &k)
 }
 
 struct dsb_ctx {
+	bool ek_dense = false;                         // filter tables more than ~4 % full (DsbStaged::ek_dense, or the synthetic tables' fill)
 	DsbKnobs knobs;
 	dsb_index *idx = nullptr; int device = 0; hipStream_t stream = nullptr;
 	DsbStaged *staged = nullptr; DsbDevIndex dx;
@@ -984,7 +986,7 @@ extern "C" int dsb_ctx_create(dsb_index *idx, int device_id, const dsb_opts *opt
 	CK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking)); CK(hipEventCreateWithFlags(&c->ev_heavy3, hipEventDisableTiming));
 	if (rc == DSB_OK) rc = stage_acquire(idx, device_id, &c->staged);           // the index goes to HBM once per (index, device)
 	if (rc == DSB_OK) {
-		c->dx = c->staged->dx; c->d_summ = c->staged->d_summ; c->summ_shift = c->staged->summ_shift;
+		c->dx = c->staged->dx; c->d_summ = c->staged->d_summ; c->summ_shift = c->staged->summ_shift; c->ek_dense = c->staged->ek_dense;
 		c->dx.filter_min_length = c->opts.L_min_matching; c->dx.filter_min_score = c->opts.min_score; c->dx.filter_min_score_LV3 = c->opts.min_score + 10;
 		if (hipMalloc((void **)&c->d_counters, 256) != hipSuccess) rc = DSB_ENOMEM;
 	}
@@ -1054,6 +1056,7 @@ extern "C" int dsb_ctx_use_synthetic_filter(dsb_ctx *c, uint64_t table_bytes, do
 	HIPCHK(hipStreamSynchronize(c->stream));
 	c->dx.ek0 = c->syn0; c->dx.ek1 = c->syn1; c->dx.ek_mask = (1ULL << bits) - 1; c->dx.ek_len = k; c->dx.single_base_max = (int)(0.8 * k);
 	c->d_summ = nullptr; c->summ_shift = 0;             // (tables this full answer nothing from a summary)
+	c->ek_dense = fill > 0.04;
 	c->seed_only = true;
 	return DSB_OK;
 }
@@ -1565,7 +1568,7 @@ static int batch_run_locked(dsb_ctx *c, std::unique_lock<std::mutex> *turn)
 	if (use_scan) {
 		hipLaunchKernelGGL(k_seed_scan, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, c->stream, c->dx, (const DsbReadDesc *)s.d_rd, (const uint32_t *)(s.ragged ? s.d_scan_order : nullptr),
 		                   (uint32_t)n, (const uint64_t *)c->d_pk, c->d_seeds, c->d_sinfo, (const uint8_t *)c->d_summ, c->summ_shift, (unsigned long long *)(c->d_counters + 40),
-		                   c->knobs.scan_look_set ? c->knobs.scan_look : dsb_scan_look_for((c->dx.ek_mask + 1) / 8));
+		                   c->knobs.scan_look_set ? c->knobs.scan_look : dsb_scan_look_for((c->dx.ek_mask + 1) / 8, c->ek_dense));
 	} else if (s.n_words_total) {
 		uint64_t waves = (s.n_words_total + DSB_PROBE_UN - 1) / DSB_PROBE_UN; unsigned blocks = (unsigned)((waves + 3) / 4);
 		if (blocks > 256u * 32u) blocks = 256u * 32u;       // >= 8 blocks of 4 waves per CU, grid-stride beyond

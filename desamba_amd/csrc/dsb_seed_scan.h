@@ -35,21 +35,23 @@
 #define DSB_SCAN_DONE 4u
 #define DSB_SCAN_NONE 0xffffffffu
 #define DSB_SCAN_W 8           /* windows a lane asks for per round */
-// How far a lane looks ahead: stride points right behind a seed, forward windows asked for together with the two behind a hit
-// (<= DSB_SCAN_W - 2), windows per round while a run of hits is followed (<= DSB_SCAN_W).  Every window asked for behind the first miss
-// is a probe the reference's scan never makes -- and every window not asked for is a round trip more on the lane's serial chain.
-// Which side wins depends on where the tables live (measured, 65536 x 50 kbp, A/B on one box):
-//   * tables that sit in the Infinity Cache (<= 256 MiB each; a viral-RefSeq-sized index: 2 x 128 MiB, 20 % full, a window in 25 a false
-//     positive, so most runs end after a window or two): the kernel runs at the request rate of the memory system, a probe not made is
-//     time not spent -- (4, 2, 4): 1.31 x the reference's table-0 probes instead of 1.52 x with round 3's (8, 6, 8), 104.0 -> 94.1 ms;
-//     the demo index (1 % full: a hit is a true seed and goes on) is unchanged, 52.1 / 52.6 ms;
-//   * multi-GiB tables in HBM (2 x 2 GiB synthetic, 20 % full): the same 80 ms either way -- there the lanes' round trips are the limit
-//     (131072 strands, a round trip of 2-3 us), so the longer look-ahead stays: it keeps the kernel at 0.96 of the random-gather ceiling.
-struct DsbScanLook { uint8_t after_seed, back_fwd, fwd_n, stride_n; };   // stride_n: stride points per round while they miss (<= DSB_SCAN_W)
-static inline DsbScanLook dsb_scan_look_for(uint64_t table_bytes)
+// How far a lane looks ahead: stride points per round while they miss (stride_n), stride points right behind a seed (after_seed), forward
+// windows asked for together with the two behind a hit (back_fwd <= DSB_SCAN_W - 2), windows per round while a run of hits is followed
+// (fwd_n).  Every window asked for behind the first hit of a stride round, or behind the first miss of a run, is a probe the reference's
+// scan never makes -- and every window not asked for is a round trip more on the lane's serial chain.  Which side wins depends on how
+// full the tables are and where they live (measured, 65536 x 50 kbp, one box, profiles/r04_scan_look_ahead.txt; round 3: 8 / 8, 6, 8 everywhere):
+//   * tables that sit in the Infinity Cache (<= 256 MiB each) and are 20 % full (a viral-RefSeq-sized index: a stride point in nine
+//     hits, most runs end after a window or two): the kernel runs at the request rate of the memory system, a probe not made is time
+//     not spent -- stride_n 8 -> 3 with (4, 2, 4): 94.7 -> 84 ms, 301 -> 272 GB issued (stride_n 2: 83 ms, 1: 88 ms -- the chain gets too long);
+//   * the same size, 1 % full (the demo index: a hit is a true seed, almost every stride point misses): 4: 50.7 ms against 53.1 with 8 and 55.6 with 2;
+//   * multi-GiB tables in HBM, 20 % full (2 x 2 GiB synthetic): (4, 2, 4) with stride_n 4: 66.2 ms against 85.7 with round 3's (8, 6, 8) / 8
+//     (81.6 with (8, 6, 8) / 4, 76.6 with (4, 2, 4) / 2: here a lane's round trips cost more, four stride points per round is the balance).
+struct DsbScanLook { uint8_t after_seed, back_fwd, fwd_n, stride_n; };
+// dense: the tables are more than a few per cent full (the staging code knows: it drops the summary of table 0 when > 90 % of its bits are set)
+static inline DsbScanLook dsb_scan_look_for(uint64_t table_bytes, bool dense = false)
 {
-	DsbScanLook k; k.stride_n = DSB_SCAN_W;
-	if (table_bytes <= (256ull << 20)) { k.after_seed = 4; k.back_fwd = 2; k.fwd_n = 4; } else { k.after_seed = 8; k.back_fwd = 6; k.fwd_n = 8; }
+	DsbScanLook k; k.after_seed = 4; k.back_fwd = 2; k.fwd_n = 4;
+	k.stride_n = (table_bytes <= (256ull << 20) && dense) ? 3 : 4;
 	return k;
 }
 
