@@ -304,7 +304,7 @@ extern "C" const char *dsb_strerror(int code)
 	}
 	return "unknown error";
 }
-extern "C" const char *dsb_version(void) { return "desamba_amd 0.3 (gfx950)"; }
+extern "C" const char *dsb_version(void) { return "desamba_amd 0.4 (gfx950)"; }
 
 // output_one_result_des / output_one_result_full (src/cly_mt.c:158-243; print_hit :60-104).  Anchors are never listed:
 // MAP_opt.show_anchor is false and no option sets it (src/cly_mt.c:486).

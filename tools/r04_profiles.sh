@@ -1,5 +1,5 @@
 #!/bin/bash
-# The rocprofv3 evidence of round 3, on a GPU box: kernel-trace statistics of the bench command on both indexes and of the
+# The rocprofv3 evidence of the round, on a GPU box: kernel-trace statistics of the bench command on both indexes and of the
 # seed lookup on synthetic 2 x 2 GiB / 2 x 8 GiB tables, and PMC passes (FETCH_SIZE and WRITE_SIZE need a pass each; SQ group).
 # Writes gpurun_out/r04_*; the summaries are copied into profiles/ by hand.   tools/r04_profiles.sh
 cd "$(dirname "$0")/.."
