@@ -221,6 +221,20 @@ def test_gpu_build_in_ranges_writes_the_reference_files(name, tmp_path, monkeypa
 
 
 @pytest.mark.gpu
+def test_gpu_build_budget_too_small_is_an_error_code(tmp_path, monkeypatch):
+    """a budget that does not even hold the text and the fixed tables: DSB_ENOMEM (-3), nothing written, and the next build works"""
+    import desamba_amd as D
+    monkeypatch.setenv("DSB_BUILD_BUDGET", "16m")
+    with pytest.raises(D.DsbError) as e:
+        D.build_index(os.path.join(GOLD, "graph3.fa.gz"), str(tmp_path / "a"))
+    assert e.value.code == -3 and not os.path.exists(str(tmp_path / "a" / "deSAMBA.bwt"))
+    monkeypatch.setenv("DSB_BUILD_BUDGET", "2g")
+    st = D.build_index(os.path.join(GOLD, "graph3.fa.gz"), str(tmp_path / "b"))
+    assert st.budget_bytes == 2 << 30 and st.peak_device_bytes <= st.budget_bytes
+    check_case("graph3", str(tmp_path / "b"))
+
+
+@pytest.mark.gpu
 def test_gpu_build_beyond_the_budget_gives_the_same_files(tmp_path, monkeypatch):
     """a 380-Mbp collection (tandem repeats, strains, mobile elements: 4e8 BWT rows) built in one piece and under
     DSB_BUILD_BUDGET = an eighth of what the one-piece build held: the same ten files byte for byte, and the device never held more
