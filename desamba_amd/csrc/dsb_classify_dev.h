@@ -1195,40 +1195,71 @@ DN void chain_unstage_M3(WCtxL &w, P32 L, const uint32_t C)
 }
 // chain_insert_M3's DP (src/cly.c:252-323) on the wavefront.  The reference scans the predecessors of an anchor from the
 // nearest one backwards, skips those that overlap it, stops at the first one more than 1000 bases away, and keeps the
-// first predecessor that strictly improves the running best: lane l takes predecessor hi - l of a chunk of 64, a ballot
-// finds the stop, a wave maximum the best score, and among equal scores the nearest predecessor (lowest lane) wins.
+// first predecessor that strictly improves the running best -- i.e. the best score, and among equal scores the nearest.
+// Rounds 1-3 took the anchors one after the other with the lanes over the predecessors of ONE anchor (a few dozen within
+// reach: most lanes idle, two reductions and a wave_sync per anchor: 49 of resolve_tree's 67 wave-seconds on the headline
+// index).  Round 4: **a block of 64 anchors at a time, one anchor per lane** (the form the extensions' sparse DP took, §2.2 of DESIGN):
+//   * the predecessors in front of the block, nearest first: a chunk of 64 is loaded one per lane and handed round with
+//     v_readlane (a predecessor's terms are scalars), every lane judges it for its own anchor until its own scan stops;
+//   * the predecessors inside the block in ascending order, an anchor's score handed round once it is final.  Scanning
+//     backwards, "stop at the first predecessor that is too far" leaves only the predecessors nearer than it: in ascending order
+//     that is "forget what you have (the older in-block ones and everything in front of the block) when a predecessor is too
+//     far"; and "the nearest among equal scores" is "a later predecessor replaces an equal earlier one" -- but never the
+//     anchor's own score, which only a strictly better predecessor replaces.
 template <class P32>
 DN void chain_dp_M3_wave(WCtxL &w, P32 LQ, const uint32_t C)
 {
-	const int32_t n = w.n_anc; const int lane = DSB_LANE;
+	const int32_t n = (int32_t)DSB_RFL((uint32_t)w.n_anc); const int lane = DSB_LANE;
 	P32 LT = LQ + C, LMS = LQ + 2 * C, LK = LQ + 3 * C, LS = LQ + 4 * C, LP = LQ + 5 * C;
 	for (int32_t st = 0; st < n;) {
 		int32_t ed = st + 1;
 		const uint32_t key = (uint32_t)LK[st] >> 2;
 		for (; ed < n && ((uint32_t)LK[ed] >> 2) == key && (uint32_t)LT[ed] - (uint32_t)LT[ed - 1] < 2000; ed++);
 		if (ed - st > 1024) ed = st + 1024;
+		ed = (int32_t)DSB_RFL((uint32_t)ed);
 		int32_t max_anchor = -1; int max_score = 0;
-		for (int32_t ca = st; ca < ed; ca++) {
-			const uint32_t ms = LMS[ca]; int ams = (int)(int16_t)(ms >> 16); const uint32_t ca_ml = ms & 0xffffu;
-			const uint32_t max_t = (uint32_t)LT[ca] + 3, max_q = (uint32_t)LQ[ca] + 3;
-			int32_t best_pre = -1;
-			for (int32_t hi = ca - 1; hi >= st; hi -= DSB_WAVE) {
-				const int32_t p = hi - lane; const bool valid = p >= st;
-				uint32_t p_q = 0, p_t = 0, p_ml = 0; int p_s = 0;
-				if (valid) { p_q = LQ[p]; p_t = LT[p]; p_ml = (uint32_t)LMS[p] & 0xffffu; p_s = (int)LS[p]; }
-				const bool skip = (p_q + p_ml > max_q) || (p_t + p_ml > max_t);
-				const bool brk = valid && !skip && ((p_q + 1000 < max_q) || (p_t + 1000 < max_t));
-				const int first_brk = grp_first(brk);
-				const int indel = (int)(p_q - p_t - (max_q - max_t)); const int ai = ABSV(indel);
-				const bool ok = valid && !skip && !brk && ai <= 200 && lane < first_brk;
-				const int ns = ok ? (int)(p_s + (int)ca_ml - (ai >> 4) - (int)((max_q - p_q) >> 8)) : (-2147483647 - 1);
-				const int m = grp_max_i(ns);
-				if (m > ams) { ams = m; best_pre = hi - grp_first(ok && ns == m); }
-				if (first_brk < DSB_WAVE) break;
+		for (int32_t b0 = st; b0 < ed; b0 += DSB_WAVE) {
+			const int32_t ca = b0 + lane; const bool mine = ca < ed;
+			const uint32_t ms = mine ? (uint32_t)LMS[ca] : 0u, my_q = mine ? (uint32_t)LQ[ca] : 0u, my_t = mine ? (uint32_t)LT[ca] : 0u;
+			const int own = (int)(int16_t)(ms >> 16); const uint32_t ca_ml = ms & 0xffffu;
+			const uint32_t max_t = my_t + 3, max_q = my_q + 3;
+			int best = own; int32_t best_pre = -1; bool have = false;
+			// the predecessors in front of the block, nearest first
+			bool alive = mine;
+			for (int32_t hi = b0 - 1; hi >= st; hi -= DSB_WAVE) {
+				if (dsb_ballot64(alive) == 0) break;
+				const int32_t pl = hi - lane; const bool pv = pl >= st;
+				const uint32_t c_q = pv ? (uint32_t)LQ[pl] : 0u, c_t = pv ? (uint32_t)LT[pl] : 0u, c_ml = pv ? ((uint32_t)LMS[pl] & 0xffffu) : 0u, c_s = pv ? (uint32_t)LS[pl] : 0u;
+				const int cnt = hi - st + 1 < DSB_WAVE ? hi - st + 1 : DSB_WAVE;
+				for (int l = 0; l < cnt; l++) {
+					const uint32_t p_q = dsb_shfl(c_q, l), p_t = dsb_shfl(c_t, l), p_ml = dsb_shfl(c_ml, l); const int p_s = (int)dsb_shfl(c_s, l);
+					if (alive && !((p_q + p_ml > max_q) || (p_t + p_ml > max_t))) {
+						if ((p_q + 1000 < max_q) || (p_t + 1000 < max_t)) alive = false;
+						else {
+							const int indel = (int)(p_q - p_t - (max_q - max_t)); const int ai = ABSV(indel);
+							const int ns = (int)(p_s + (int)ca_ml - (ai >> 4) - (int)((max_q - p_q) >> 8));
+							if (ai <= 200 && ns > best) { best = ns; best_pre = hi - l; have = true; }
+						}
+					}
+				}
 			}
-			if (lane == 0) { LP[ca] = (uint32_t)best_pre; LS[ca] = (uint32_t)ams; }
+			// the predecessors inside the block, in ascending order
+			const int nb = ed - b0 < DSB_WAVE ? ed - b0 : DSB_WAVE;
+			for (int j = 0; j + 1 < nb; j++) {
+				const uint32_t p_q = dsb_shfl(my_q, j), p_t = dsb_shfl(my_t, j), p_ml = dsb_shfl(ca_ml, j); const int p_s = (int)dsb_shfl((uint32_t)best, j);
+				if (mine && lane > j && !((p_q + p_ml > max_q) || (p_t + p_ml > max_t))) {
+					if ((p_q + 1000 < max_q) || (p_t + 1000 < max_t)) { best = own; best_pre = -1; have = false; }
+					else {
+						const int indel = (int)(p_q - p_t - (max_q - max_t)); const int ai = ABSV(indel);
+						const int ns = (int)(p_s + (int)ca_ml - (ai >> 4) - (int)((max_q - p_q) >> 8));
+						if (ai <= 200 && (ns > best || (ns == best && have))) { best = ns; best_pre = b0 + j; have = true; }
+					}
+				}
+			}
+			if (mine) { LP[ca] = (uint32_t)best_pre; LS[ca] = (uint32_t)best; }
+			const int m = grp_max_i(mine ? best : (-2147483647 - 1));
+			if (m > max_score) { max_score = m; max_anchor = b0 + grp_first(mine && best == m); }
 			wave_sync();
-			if (max_score < ams) { max_score = ams; max_anchor = ca; }
 		}
 		int sum_INDEL = 0, anchor_number = 1; int32_t pre = max_anchor;
 		uint32_t fl = LK[max_anchor];
