@@ -1140,8 +1140,30 @@ DN void chain_sort_M3(WCtxL &w)
 		// the usual size: keys in LDS (the window table is idle), every lane ranks its own anchors against all keys
 		// (stable: ties by index) and moves them straight to their sorted place; the two anchor arrays swap roles
 		lds_u64 *keys = (lds_u64 *)w.wtab;
-		for (int32_t i = lane; i < n; i += DSB_WAVE) keys[i] = ((uint64_t)A[i].ref_ID << 33) | ((uint64_t)A[i].direction << 32) | A[i].ref_offset;
+		uint32_t max_ref = 0;
+		for (int32_t i = lane; i < n; i += DSB_WAVE) { keys[i] = ((uint64_t)A[i].ref_ID << 33) | ((uint64_t)A[i].direction << 32) | A[i].ref_offset; max_ref = MAXV(max_ref, A[i].ref_ID); }
+		max_ref = (uint32_t)grp_max_i((int)max_ref);
 		wave_sync();
+		if (max_ref < (1u << 21) && n <= 1024) {
+			// reference numbers below 2^21 (any index but a collection of millions of sequences): the anchor's index fits under the key, the keys
+			// become distinct, and a rank is a count of smaller keys -- one compare per key instead of the three of "smaller, or equal and earlier"
+			for (int32_t i = lane; i < n; i += DSB_WAVE) { const uint64_t k = keys[i]; keys[i] = ((k >> 32) << 42) | ((k & 0xffffffffULL) << 10) | (uint64_t)(uint32_t)i; }
+			wave_sync();
+			for (int32_t i = lane; i < n; i += DSB_WAVE) {
+				const uint64_t k = keys[i]; const DsbAnchor mine = A[i];
+				uint32_t rank = 0;
+				int32_t j = 0;
+				for (; j + 4 <= n; j += 4) {
+					const uint64_t k0 = keys[j], k1 = keys[j + 1], k2 = keys[j + 2], k3 = keys[j + 3];
+					rank += (uint32_t)(k0 < k) + (uint32_t)(k1 < k) + (uint32_t)(k2 < k) + (uint32_t)(k3 < k);
+				}
+				for (; j < n; j++) rank += (uint32_t)(keys[j] < k);
+				T[rank] = mine;
+			}
+			wave_sync();
+			w.anc = T; w.anc_tmp = A;
+			return;
+		}
 		for (int32_t i = lane; i < n; i += DSB_WAVE) {
 			const uint64_t k = keys[i]; const DsbAnchor mine = A[i];
 			uint32_t rank = 0;
@@ -1211,6 +1233,7 @@ DN void chain_dp_M3_wave(WCtxL &w, P32 LQ, const uint32_t C)
 {
 	const int32_t n = (int32_t)DSB_RFL((uint32_t)w.n_anc); const int lane = DSB_LANE;
 	P32 LT = LQ + C, LMS = LQ + 2 * C, LK = LQ + 3 * C, LS = LQ + 4 * C, LP = LQ + 5 * C;
+	uint32_t *const gbuf = w.sortidx; uint32_t n_grp = 0;      // the best anchor of every group (sortidx is idle: the anchors are sorted)
 	for (int32_t st = 0; st < n;) {
 		int32_t ed = st + 1;
 		const uint32_t key = (uint32_t)LK[st] >> 2;
@@ -1261,8 +1284,21 @@ DN void chain_dp_M3_wave(WCtxL &w, P32 LQ, const uint32_t C)
 			if (m > max_score) { max_score = m; max_anchor = b0 + grp_first(mine && best == m); }
 			wave_sync();
 		}
+		// (the walk back along the chain and the chain's record: afterwards, one group per lane)
+		if (lane == 0) gbuf[n_grp] = (uint32_t)max_anchor;
+		n_grp++;
+		st = ed;
+	}
+	wave_sync();
+	// One chain per group: the walk from its best anchor back to its first (dependent reads, as long as the chain) and the record.
+	// Rounds 1-3 did this group by group on the whole wavefront, every lane the same walk; the groups are independent, so now
+	// every lane walks one.  The records go where push_hit would have put them, in group order.
+	const uint32_t base = DSB_RFL(w.n_hit), cap = DSB_RFL(w.hit_cap), room = base < cap ? cap - base : 0u;
+	for (uint32_t g = (uint32_t)lane; g < n_grp; g += DSB_WAVE) {
+		const int32_t max_anchor = (int32_t)gbuf[g];
 		int sum_INDEL = 0, anchor_number = 1; int32_t pre = max_anchor;
 		uint32_t fl = LK[max_anchor];
+		const uint32_t key = fl >> 2;
 		int sum_score = (fl & 1u) ? 1 : (int)(int16_t)((uint32_t)LMS[max_anchor] >> 16);
 		bool with_top = !(fl & 2u);
 		for (; (int32_t)LP[pre] != -1; anchor_number++) {
@@ -1273,17 +1309,19 @@ DN void chain_dp_M3_wave(WCtxL &w, P32 LQ, const uint32_t C)
 			sum_score += (fl & 1u) ? 1 : (int)(int16_t)((uint32_t)LMS[pre] >> 16);
 			pre = pre_;
 		}
-		DsbChain *nc = push_hit(w);
-		if (lane == 0) {
-			nc->chain_id = w.n_hit - 1; nc->ref_ID = key >> 1; nc->direction = (uint8_t)(key & 1u);
+		if (g < room) {
+			DsbChain *nc = w.hit + base + g;
+			nc->chain_id = base + g; nc->ref_ID = key >> 1; nc->direction = (uint8_t)(key & 1u);
 			nc->q_t_dis = (int32_t)((uint32_t)LT[max_anchor] - (uint32_t)LQ[max_anchor]);
 			nc->t_st = LT[pre]; nc->t_ed = (uint32_t)LT[max_anchor] + ((uint32_t)LMS[max_anchor] & 0xffffu);
 			nc->q_st = LQ[pre]; nc->q_ed = (uint32_t)LQ[max_anchor] + ((uint32_t)LMS[max_anchor] & 0xffffu);
 			nc->with_top_anchor = with_top; nc->anchor_number = anchor_number; nc->sum_score = sum_score;
 			nc->indel = sum_INDEL; nc->cur = max_anchor; nc->primary = 0; nc->pri_index = 0;
 		}
-		st = ed;
 	}
+	wave_sync();
+	w.n_hit = base + (n_grp < room ? n_grp : room);
+	if (n_grp > room) w.status |= DSB_ST_HIT_OVF;               // (a read whose chains do not fit is run again with a larger arena)
 	wave_sync();
 }
 template <bool LDSMODE>
