@@ -2851,19 +2851,36 @@ DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int k
 		wave_sync();
 	}
 	TX1(w, 5, t_gl);
-	// 3. what is left, one gap at a time on the whole wavefront
+	// 3. what is left, one gap at a time on the whole wavefront.  Rounds 2-4 walked the whole list here, a global load and a test per gap,
+	// the scored ones only to add their gain (318 gaps per read on the headline index: 85 of 870 wave-seconds went into this loop).  A gap's gain does not depend
+	// on the score it is added to, so the lanes sum the scored gaps (a prefix sum per chunk of 64: every gap that is left learns what the
+	// gaps in front of it have gained, i.e. the very score the walk would have arrived with) and list the ones that are left.
+	uint32_t *const left = w.sortidx;                                      // (the order of the gap-per-lane phase is not needed any more)
+	uint32_t n_left = 0, lane_gain = 0;
+	for (uint32_t b0 = 0; b0 < n_gap; b0 += DSB_WAVE) {
+		const uint32_t gi = b0 + (uint32_t)lane; const bool valid = gi < n_gap;
+		const int32_t gn = valid ? G[gi].gain : 0; const bool none = valid && gn == DSB_GL_NONE;
+		uint32_t total; const uint32_t off = grp_excl_scan_u((valid && !none) ? (uint32_t)gn : 0u, &total);
+		const uint64_t nm = dsb_ballot64(none);
+		if (none) { G[gi].pad = lane_gain + off; left[n_left + (uint32_t)__popcll(nm & ((1ULL << lane) - 1ULL))] = gi; }
+		n_left += (uint32_t)__popcll(nm); lane_gain += total;
+	}
+	wave_sync();
+	int whole_gain = 0;                                                    // what the gaps of this loop have gained so far
 	uint64_t pf_q = 0; uint32_t pf_t = 0; int32_t pf_qlo = 0; uint64_t pf_toff = ~0ULL; bool pf_has_q = false, pf_has_t = false;
-	for (uint32_t gi = 0; gi < n_gap; gi++) {
+	for (uint32_t k = 0; k < n_left; k++) {
+		const uint32_t gi = left[k];
 		const DsbGap g = G[gi];
-		if (g.gain != DSB_GL_NONE) { score += g.gain; continue; }
+		score = 10000 + (int)g.pad + whole_gain;                            // (= what the walk over the whole list arrives here with)
+		const int score_before = score;
 		// The window of the NEXT gap (read stretch and packed reference words, the first 8 * 64 bytes / bases of each, which is
 		// all of a usual gap) is requested while this gap is worked on: pf_* hold what was asked for during the previous gap.
 		const uint64_t cur_q = pf_q; const uint32_t cur_t = pf_t; const int32_t cur_qlo = pf_qlo; const uint64_t cur_toff = pf_toff; const bool cur_has_q = pf_has_q, cur_has_t = pf_has_t;
 		pf_has_q = pf_has_t = false;
-		if (gi + 1 < n_gap) {
-			const DsbGap n = G[gi + 1];
+		if (k + 1 < n_left) {
+			const DsbGap n = G[left[k + 1]];
 			const int n_mch = (int)n.pl, n_tlen = (int)(n.ct - ((n.pt - 3) + (uint32_t)n_mch) + 3);
-			if (n.gain == DSB_GL_NONE && n_tlen > 12 && n_tlen < 2000) {
+			if (n_tlen > 12 && n_tlen < 2000) {
 				const uint64_t n_toff = (uint64_t)(int64_t)(int)(n.pt - 3) + t_offset + (uint64_t)(int64_t)n_mch;
 				const int32_t n_qlo = (int32_t)(n.pq + (uint32_t)n_mch - 8) - 16, n_qhi = (int32_t)(n.cq - 1) + 80;
 				if ((int64_t)n_toff >= 0 && n_toff < x->ref_bases && 8 * lane < n_tlen) pf_t = dsb_g32u(x->refbin + ((n_toff + (uint32_t)(8 * lane)) >> 2));
@@ -2956,8 +2973,9 @@ DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int k
 				}
 			}
 		}
+		whole_gain += score - score_before;
 	}
-	score += tail_len;
+	score = 10000 + (int)lane_gain + whole_gain + tail_len;
 	w.n_sms = 0;
 	return score - 10000;
 }
