@@ -2938,26 +2938,27 @@ DN int sdp_middle_M2(WCtxL &w, int32_t c_a, const uint8_t *q_str, int tbl, int k
 				const uint32_t nn = n_sms;
 				DsbSms me; me.t_pos = me.q_pos = me.len = 0;
 				if (lane == 0) me = first; else if ((uint32_t)lane == nn - 1) me = last; else if ((uint32_t)lane < nn) { if (mirror) { uint4 r = lnodes[lane]; me.t_pos = r.x; me.q_pos = r.y; me.len = r.z; } else me = S[lane]; }
-				me.score = (lane == 0) ? (uint32_t)score : 0u;
-				for (uint32_t ci = 1; ci < nn; ci++) {
-					DsbSms cs; cs.t_pos = dsb_shfl(me.t_pos, (int)ci); cs.q_pos = dsb_shfl(me.q_pos, (int)ci); cs.len = dsb_shfl(me.len, (int)ci); cs.score = 0;
-					uint32_t lim_q = cs.q_pos + 6, lim_t = cs.t_pos + 6;
-					int cand = (int)cs.len;
-					if ((uint32_t)lane < ci) {
-						int pre_q_ed = me.q_pos + me.len + 9 - 1, pre_t_ed = me.t_pos + me.len + 9 - 1;
+				// Every lane keeps the best score of its OWN node (at least its length: a node with no predecessor) and learns of the nodes in
+				// front of it in ascending order, each handed round once it is final: the maximum over all predecessors needs no order and
+				// no reduction per node (rounds 2-4: lanes as predecessors of one node at a time, a wave maximum per node).
+				int mine = (lane == 0) ? score : (int)me.len;
+				const uint32_t lim_q = me.q_pos + 6, lim_t = me.t_pos + 6;
+				for (uint32_t pj = 0; pj + 1 < nn; pj++) {
+					const uint32_t p_t = dsb_shfl(me.t_pos, (int)pj), p_q = dsb_shfl(me.q_pos, (int)pj), p_l = dsb_shfl(me.len, (int)pj); const int p_s = (int)dsb_shfl((uint32_t)mine, (int)pj);
+					if ((uint32_t)lane > pj && (uint32_t)lane < nn) {
+						const int pre_q_ed = (int)(p_q + p_l + 9 - 1), pre_t_ed = (int)(p_t + p_l + 9 - 1);
 						if (!((uint32_t)pre_q_ed > lim_q) && !((uint32_t)pre_t_ed > lim_t)) {
-							int indel = me.q_pos - me.t_pos - (lim_q - lim_t); int ai = ABSV(indel);
+							const int indel = (int)(p_q - p_t - (lim_q - lim_t)); const int ai = ABSV(indel);
 							if (ai <= 200) {
-								int ns = me.score + cs.len - (ai >> 3);
-								if ((uint32_t)pre_q_ed > cs.q_pos || (uint32_t)pre_t_ed > cs.t_pos) { int oq = pre_q_ed - cs.q_pos, ot = pre_t_ed - cs.t_pos; ns -= MAXV(oq, ot); }
-								cand = MAXV(cand, ns);
+								int ns = p_s + (int)me.len - (ai >> 3);
+								if ((uint32_t)pre_q_ed > me.q_pos || (uint32_t)pre_t_ed > me.t_pos) { const int oq = pre_q_ed - (int)me.q_pos, ot = pre_t_ed - (int)me.t_pos; ns -= MAXV(oq, ot); }
+								mine = MAXV(mine, ns);
 							}
 						}
 					}
-					int max_score = grp_max_i(cand);
-					if ((uint32_t)lane == ci) me.score = (uint32_t)max_score;
-					score = MAXV(max_score, score);
 				}
+				const int all_max = grp_max_i(((uint32_t)lane >= 1 && (uint32_t)lane < nn) ? mine : (-2147483647 - 1));
+				score = MAXV(all_max, score);
 			} else
 			{
 				S[0] = first; S[n_sms - 1].q_pos = last.q_pos; S[n_sms - 1].t_pos = last.t_pos; S[n_sms - 1].len = last.len;
