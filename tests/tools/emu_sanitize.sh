@@ -5,7 +5,7 @@
 set -e -o pipefail
 cd "$(dirname "$0")/../.."
 tmp=$(mktemp -d); trap 'rm -rf "$tmp"' EXIT
-g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-strict-aliasing -fPIC -shared -DDSB_HOST_EMU -Idesamba_amd/csrc -Iinclude \
+g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-strict-aliasing -fPIC -shared -DDSB_HOST_EMU -Idesamba_amd/csrc -Iinclude -Itests/emu \
 	-o "$tmp/libdsbemu.so" tests/emu/emu_classify.cpp desamba_amd/csrc/dsb_index.cpp
 LD_PRELOAD="$(g++ -print-file-name=libasan.so):$(g++ -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 \
 	DSB_EMU_LIB="$tmp/libdsbemu.so" python3 tests/tools/emu_sanitize.py 2>&1 | tee "$tmp/log"
