@@ -101,7 +101,7 @@ def test_emulated_stages_rebuild_the_demo_index(tmp_path):
 
 # ---- the builder in ranges of k-mer prefixes (dsb_build_parts.h): what a build beyond the device's memory runs ---------------------
 
-@pytest.mark.parametrize("name,parts", [("graph1", 3), ("graph2", 5), ("graph3", 7), ("reader", 2)])
+@pytest.mark.parametrize("name,parts", [("graph2", 5), ("graph3", 7)])       # (graph1 in ranges: the supplied-list test below; all four cases in 3 ranges: the GPU tests)
 def test_build_in_ranges_writes_the_reference_files(name, parts, tmp_path):
     """dsb_build_run_parts on the host: the k-mer, unitig-number and BWT-row stages each in `parts` ranges of 13-mer prefixes (the
     golden references have unitigs that start in one range and end in another, k-mers whose neighbours lie in other ranges, padded
