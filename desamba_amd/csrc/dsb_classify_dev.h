@@ -2665,17 +2665,25 @@ DV void fill_window(const WCtxL &w, uint8_t *win, int n)
 // query window (32 query positions per step: nine shifted XORs accumulate the mismatches of all alignments), the two
 // exact-match extensions on packed words (XOR + count leading zeros), the node DP of src/cly.c:2495-2517 over <= 14 nodes.
 // Per lane in LDS (the window table's 12 KB): 12 packed query words and 12 match nodes.  Gaps that do not fit (window
-// > ~220 query positions or > 320 reference bases, > 12 match nodes, windows touching the ends of the read or of the
+// > ~220 query positions or > DSB_GL_MAXT reference bases, > 12 match nodes, windows touching the ends of the read or of the
 // reference text: 10-20 % of the gaps) are left to the cooperative form.
 #ifdef DSB_LDS_DIET
 #define DSB_GL_QW 9
 #define DSB_GL_NODES 8
 #else
+#ifndef DSB_GL_QW
 #define DSB_GL_QW 12
 #define DSB_GL_NODES 12
 #endif
+#endif
 static_assert((DSB_GL_QW + DSB_GL_NODES) * 64u * 8u <= 4u * DSB_WTAB_SLOTS, "gap_lane: its per-lane words live in the window table's LDS");
-#define DSB_GL_MAXT 320
+// DSB_GL_MAXT: reference bases of a gap beyond which it is left to the cooperative form.  The lanes of a round wait for its most expensive gap and the
+// all-against-all compare of a lane grows with (reference bases x query words), the hashed cooperative form with their sum: measured on one box
+// (profiles/r04_gap_lane_limit.txt; the answers do not depend on the limit), headline index / demo index: 512 (with 18 query words) 344 / 85.5 ms,
+// 448 332 / 80.5, 384 321 / 78.1, 320 (rounds 2-4) 312.2 / 77.4, 256 309.8 / 77.1, 224 305.5 / 77.0, **192 304.6 / 77.5**, 160 305.1 / 79.0, 128 305.7 / 82.0.
+#ifndef DSB_GL_MAXT
+#define DSB_GL_MAXT 192
+#endif
 #define DSB_GL_NONE (-2147483647 - 1)
 #define DSB_GL_K 10000
 struct DsbGap { uint32_t pq, pt, pl, cq, ct, cl; int32_t gain; uint32_t pad; };   // previous / current anchor: index_in_read, ref_offset, mtch_len
