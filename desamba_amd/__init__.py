@@ -57,7 +57,8 @@ class DsbBuildStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_bases", "n_refs", "n_kmer", "n_unitig", "n_rows")] + \
                [(n, C.c_double) for n in ("parse_s", "sort_s", "graph_s", "walk_s", "rows_s", "tables_s", "write_s", "total_s")] + \
                [(n, C.c_uint64) for n in ("budget_bytes", "peak_device_bytes")] + \
-               [(n, C.c_uint32) for n in ("ranges_kmers", "ranges_unitig_numbers", "ranges_rows", "ranges_exist")]
+               [(n, C.c_uint32) for n in ("ranges_kmers", "ranges_unitig_numbers", "ranges_rows", "ranges_exist")] + \
+               [("spilled_bytes", C.c_uint64)]
 
 
 class DsbChunk(C.Structure):

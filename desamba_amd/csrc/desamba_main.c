@@ -974,7 +974,7 @@ static int index_main(int argc, char **argv)
 		fprintf(stderr, "    [SortedKmer]  FILE   sorted kmers file \"kmer.srt\" generated by \"kmersort\"; without it the 31-mers are taken from the reference\n");
 		fprintf(stderr, "    <Reference>   FILE   one fasta REF file, multiple files need to be combined\n");
 		fprintf(stderr, "    <IndexDir>    FOLDER the directory to store deSAMBA index\n  Options:\n    -g INT        GPU device id [0]\n    -h            help\n");
-		fprintf(stderr, "  Environment:\n    DSB_BUILD_BUDGET=<bytes>[k|m|g]  device memory the build may hold (default: in one piece if ~64 bytes per base fit, else 85 %% of the free memory)\n\n");
+		fprintf(stderr, "  Environment:\n    DSB_BUILD_BUDGET=<bytes>[k|m|g]  device memory the build may hold (default: in one piece if ~64 bytes per base fit, else 85 %% of the free memory)\n    DSB_BUILD_SPILL=1                a build in ranges keeps its k-mer list (8 bytes per 31-mer) in a temporary file of <IndexDir>, not in host memory\n\n");
 		return 0;
 	}
 	const char *srt = optind + 3 <= argc ? argv[optind++] : NULL;

@@ -170,6 +170,10 @@ extern "C" int dsb_index_build(const char *kmer_srt, const char *fasta, const ch
 		if (v >= 1.0) budget = (uint64_t)v;
 	}
 	if (const char *e = getenv("DSB_BUILD_PARTS")) pi.force_parts = (uint32_t)atoi(e);
+	// DSB_BUILD_SPILL=1: the k-mer list of a build in ranges (8 bytes per 31-mer: 190 GB for a 35-Gbp collection) goes to <out_dir>/deSAMBA.kmers.tmp
+	// instead of host memory: written once, read twice in order, removed at the end
+	std::string spill_file;
+	if (const char *e = getenv("DSB_BUILD_SPILL")) if (*e && *e != '0') { if (mkdir(out_dir, 0777) != 0 && errno != EEXIST) return DSB_EIO; spill_file = std::string(out_dir) + "/deSAMBA.kmers.tmp"; pi.spill_path = spill_file.c_str(); }
 	size_t mem_free = 0, mem_total = 0;
 	if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) return DSB_ENODEV;
 	const uint64_t in_one_piece = 64 * (uint64_t)in.code.size() + (3ULL << 30);
@@ -177,6 +181,7 @@ extern "C" int dsb_index_build(const char *kmer_srt, const char *fasta, const ch
 	if (parts && !budget) budget = (uint64_t)(0.85 * (double)mem_free);
 	const int rc = parts ? dsb_build_run_parts(be, in, out, budget, &pi) : dsb_build_run(be, in, out);
 	if (be.failed) return DSB_ENODEV;
+	if (rc == -6) return DSB_EIO;
 	if (rc == -5) { fprintf(stderr, "desamba_amd: a budget of %llu bytes of device memory does not hold what an index of %llu bases keeps resident\n", (unsigned long long)budget, (unsigned long long)in.code.size()); return DSB_ENOMEM; }
 	if (rc) return rc;
 	if (parts && getenv("DSB_BUILD_TRACE"))
@@ -190,7 +195,7 @@ extern "C" int dsb_index_build(const char *kmer_srt, const char *fasta, const ch
 		stats->parse_s = t_parse; stats->sort_s = out.t_sort; stats->graph_s = out.t_graph; stats->walk_s = out.t_walk; stats->rows_s = out.t_rows;
 		stats->tables_s = out.t_tables; stats->write_s = wall() - t0; stats->total_s = wall() - t_all;
 		stats->budget_bytes = parts ? budget : 0; stats->peak_device_bytes = be.peak_bytes();
-		stats->ranges_kmers = pi.parts_kmers; stats->ranges_unitig_numbers = pi.parts_uid; stats->ranges_rows = pi.parts_rows; stats->ranges_exist = pi.parts_exist;
+		stats->ranges_kmers = pi.parts_kmers; stats->ranges_unitig_numbers = pi.parts_uid; stats->ranges_rows = pi.parts_rows; stats->ranges_exist = pi.parts_exist; stats->spilled_bytes = pi.spilled_bytes;
 	}
 	return DSB_OK;
 }

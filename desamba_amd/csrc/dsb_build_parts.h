@@ -30,6 +30,9 @@
 // holds the k-mer list (8 bytes per k-mer) and the finished files.  Every allocation goes through the backend, which
 // counts: `peak` of DsbPartsInfo is what the build really held.
 #pragma once
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/mman.h>
 #include "dsb_build_impl.h"
 
 #define DSB_C_IN    0x10u       /* text-window flags in the spare bits of the text codes */
@@ -41,6 +44,9 @@
 struct DsbPartsInfo {
 	uint64_t budget = 0, peak = 0, resident = 0;
 	uint32_t force_parts = 0;      // tests on small references: this many ranges per stage whatever the budget (DSB_BUILD_PARTS)
+	const char *spill_path = nullptr;   // the k-mer list goes to this file instead of host memory (DSB_BUILD_SPILL: written once range by range, then mapped
+	                                    // and read in order by the two later stages; removed at the end): 8 bytes per k-mer less on the host
+	uint64_t spilled_bytes = 0;
 	uint32_t parts_kmers = 0, parts_uid = 0, parts_rows = 0, parts_refpos = 0, parts_exist = 0, parts_blocks = 0;
 	uint64_t n_start_windows = 0, max_part_windows = 0;
 	uint64_t stage_peak[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // bytes held at most in: prefix histogram, k-mers, unitig numbers, unitig walk, positions, rows, blocks, tables + text
@@ -131,7 +137,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 	if (N < DSB_BK) return -4;
 	const uint64_t n_chunk = (N + DSB_BCHUNK - 1) / DSB_BCHUNK;
 	const uint64_t P = DSB_PRE_N - 1;
-	DsbPartsInfo pi; pi.budget = budget;
+	DsbPartsInfo pi; pi.budget = budget; pi.spill_path = pinfo ? pinfo->spill_path : nullptr;
 	double t0 = be.now();
 
 	uint8_t *code = be.template alloc<uint8_t>(N + 1);
@@ -167,7 +173,13 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 
 	// ---- 1. + 2a. per range: the sorted k-mers, the bases around them, the two condition bits of every window of the range
 	const bool have_list = !in.kmers.empty();
-	std::vector<uint64_t> hkv_own;                              // the k-mer list on the host (8 bytes per k-mer) when none was supplied
+	std::vector<uint64_t> hkv_own;                              // the k-mer list on the host (8 bytes per k-mer) when none was supplied ...
+	uint64_t hkv_n = 0;                                         // ... or, with a spill file, in that file: appended range by range, mapped when complete
+	const char *spill = (pinfo && pinfo->spill_path && in.kmers.empty()) ? pinfo->spill_path : nullptr;
+	int spill_fd = -1; void *spill_map = nullptr; size_t spill_len = 0;
+	struct SpillGuard { int &fd; void *&map; size_t &len; const char *path; ~SpillGuard() { if (map) munmap(map, len); if (fd >= 0) close(fd); if (path) unlink(path); } } spill_guard{spill_fd, spill_map, spill_len, spill};
+	if (spill) { spill_fd = open(spill, O_RDWR | O_CREAT | O_TRUNC, 0600); if (spill_fd < 0) return -6; }
+	std::vector<uint64_t> spill_buf;
 	std::vector<uint64_t> hpre(P + 1, 0);                       // first index of every prefix in it
 	if (have_list) {
 		uint64_t i = 0; const uint64_t nk = in.kmers.size();
@@ -191,7 +203,7 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 			DsbPartKv pk; pk.plo = plo; pk.phi = phi;
 			if (have_list) pk = dsb_part_load(be, in.kmers.data(), hpre, plo, phi);
 			else {
-				if (Mr == 0) { for (uint64_t p = plo; p < phi; p++) hpre[p] = hkv_own.size(); continue; }
+				if (Mr == 0) { for (uint64_t p = plo; p < phi; p++) hpre[p] = hkv_n; continue; }
 				uint64_t *keys = be.template alloc<uint64_t>(Mr);
 				be.zero(ctr, 16);
 				be.for_n(n_chunk, DSB_LAMBDA(uint64_t ch) {
@@ -222,9 +234,15 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 				pk.pre = be.template alloc<uint64_t>(phi - plo + 1);
 				dsb_part_pre(be, pk);
 				// to the host's list
-				const uint64_t K = hkv_own.size();
-				hkv_own.resize(K + pk.m);
-				if (pk.m) be.to_host(hkv_own.data() + K, pk.kv, pk.m * 8);
+				const uint64_t K = hkv_n;
+				if (spill) {
+					spill_buf.resize(pk.m);
+					if (pk.m) { be.to_host(spill_buf.data(), pk.kv, pk.m * 8); if (pwrite(spill_fd, spill_buf.data(), pk.m * 8, (off_t)(K * 8)) != (ssize_t)(pk.m * 8)) return -6; }
+				} else {
+					hkv_own.resize(K + pk.m);
+					if (pk.m) be.to_host(hkv_own.data() + K, pk.kv, pk.m * 8);
+				}
+				hkv_n = K + pk.m;
 				std::vector<uint64_t> lp(phi - plo + 1);
 				be.to_host(lp.data(), pk.pre, (phi - plo + 1) * 8);
 				for (uint64_t p = plo; p < phi; p++) hpre[p] = K + lp[p - plo];
@@ -259,10 +277,16 @@ int dsb_build_run_parts(B &be, const DsbBuildIn &in, DsbBuildOut &out, uint64_t 
 			});
 			be.free(info); be.free(pk.kv); be.free(pk.pre);
 		}
-		if (!have_list) hpre[P] = hkv_own.size();
+		if (!have_list) hpre[P] = hkv_n;
 		be.free(miss); be.free(ctr);
 	}
-	const uint64_t *hkv = have_list ? in.kmers.data() : hkv_own.data();
+	if (spill) {
+		std::vector<uint64_t>().swap(spill_buf);
+		spill_len = (size_t)hkv_n * 8;
+		if (spill_len) { spill_map = mmap(nullptr, spill_len, PROT_READ, MAP_SHARED, spill_fd, 0); if (spill_map == MAP_FAILED) { spill_map = nullptr; return -6; } madvise(spill_map, spill_len, MADV_SEQUENTIAL); }
+		pi.spilled_bytes = spill_len;
+	}
+	const uint64_t *hkv = have_list ? in.kmers.data() : spill ? (const uint64_t *)spill_map : hkv_own.data();
 	const uint64_t n = hpre[P];
 	if (n == 0) return -4;
 	out.n_kmer = n;

@@ -113,7 +113,8 @@ typedef struct {
  * its working set (~60 bytes per reference base) fits the free device memory, and otherwise -- or when the environment says
  * DSB_BUILD_BUDGET=<bytes>[k|m|g] -- in passes over ranges of 13-mer prefixes (dsb_build_parts.h; the reference's bucket-by-bucket
  * construction, src/idx_sort.c:298-401, src/idx.c:884-1026): the device then holds the text (1 byte per base), ~12 bytes per unitig
- * occurrence and unitig, and one range; host memory holds the k-mer list (8 bytes per k-mer) and the files.  Same files either way.
+ * occurrence and unitig, and one range; host memory holds the k-mer list (8 bytes per k-mer; with DSB_BUILD_SPILL=1 a temporary file in
+ * out_dir holds it instead) and the files.  Same files either way.
  * DSB_ENOMEM: the budget does not hold what stays resident.  DSB_EINVAL: reference shorter than 31 bases, a k-mer of the text missing from kmer_srt or a
  * k-mer of kmer_srt missing from the text, or a unitig cycle the reference's builder does not handle either. */
 typedef struct {
@@ -122,6 +123,7 @@ typedef struct {
 	uint64_t budget_bytes;        /* 0: built in one piece; else the device memory the passes were planned for */
 	uint64_t peak_device_bytes;   /* the most the build held at once (every allocation of the build is counted) */
 	uint32_t ranges_kmers, ranges_unitig_numbers, ranges_rows, ranges_exist;   /* passes of the k-mer / unitig-number / BWT-row / filter-table stages */
+	uint64_t spilled_bytes;       /* DSB_BUILD_SPILL=1: bytes of the k-mer list that went through <out_dir>/deSAMBA.kmers.tmp instead of host memory */
 } dsb_build_stats;
 int  dsb_index_build(const char *kmer_srt, const char *fasta, const char *out_dir, int device, dsb_build_stats *stats);
 

@@ -36,11 +36,11 @@ def emu_build_parts(fasta, out_dir, kmer_srt=None, budget=1 << 40, parts=0):
     """the same through dsb_build_run_parts (dsb_build_parts.h): `parts` ranges of prefixes per stage, or as many as `budget` bytes ask
     for; returns a dict with the counts, the peak bytes the backend held and the number of ranges of each stage"""
     _load_emu()
-    st = (C.c_uint64 * 10)()
+    st = (C.c_uint64 * 11)()
     rc = _emu.dsb_emu_index_build_parts(kmer_srt.encode() if kmer_srt else None, fasta.encode(), out_dir.encode(), budget, parts, st)
     if rc:
         raise RuntimeError("dsb_emu_index_build_parts(%s) = %d" % (fasta, rc))
-    return dict(zip(("n_kmer", "n_unitig", "n_rows", "n_refs", "peak", "parts_kmers", "parts_uid", "parts_rows", "start_windows", "parts_exist"), st))
+    return dict(zip(("n_kmer", "n_unitig", "n_rows", "n_refs", "peak", "parts_kmers", "parts_uid", "parts_rows", "start_windows", "parts_exist", "spilled_bytes"), st))
 
 
 def n_rows_of(d):

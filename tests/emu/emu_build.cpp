@@ -57,11 +57,13 @@ extern "C" int dsb_emu_index_build_parts(const char *kmer_srt, const char *fasta
 	HostBE be;
 	if (const char *e = getenv("DSB_FORCE_EK_LEVEL")) in.force_ek_level = atoi(e);
 	DsbPartsInfo pi; pi.force_parts = parts;
+	std::string spill_file;
+	if (const char *e = getenv("DSB_BUILD_SPILL")) if (*e && *e != '0') { mkdir(out_dir, 0777); spill_file = std::string(out_dir) + "/deSAMBA.kmers.tmp"; pi.spill_path = spill_file.c_str(); }
 	const int rc = dsb_build_run_parts(be, in, out, budget, &pi);
 	if (rc) return rc;
 	if (stats) {
 		stats[0] = out.n_kmer; stats[1] = out.n_uni; stats[2] = out.n_rows; stats[3] = in.refs.size();
-		stats[4] = pi.peak; stats[5] = pi.parts_kmers; stats[6] = pi.parts_uid; stats[7] = pi.parts_rows; stats[8] = pi.n_start_windows; stats[9] = pi.parts_exist;
+		stats[4] = pi.peak; stats[5] = pi.parts_kmers; stats[6] = pi.parts_uid; stats[7] = pi.parts_rows; stats[8] = pi.n_start_windows; stats[9] = pi.parts_exist; stats[10] = pi.spilled_bytes;
 	}
 	return dsb_build_write(in, out, out_dir);
 }

@@ -113,6 +113,16 @@ def test_build_in_ranges_writes_the_reference_files(name, parts, tmp_path):
     check_case(name, out)
 
 
+def test_build_in_ranges_with_the_kmer_list_in_a_file(tmp_path, monkeypatch):
+    """DSB_BUILD_SPILL=1: the k-mer list of the ranges (8 bytes per 31-mer: what a 35-Gbp build would otherwise hold in host memory) is appended
+    to <IndexDir>/deSAMBA.kmers.tmp range by range, mapped for the later stages and removed at the end: the same files"""
+    monkeypatch.setenv("DSB_BUILD_SPILL", "1")
+    out = str(tmp_path / "idx")
+    st = build_lib.emu_build_parts(os.path.join(GOLD, "graph3.fa.gz"), out, parts=5)
+    assert st["spilled_bytes"] == 8 * st["n_kmer"] and not os.path.exists(os.path.join(out, "deSAMBA.kmers.tmp"))
+    check_case("graph3", out)
+
+
 def test_build_in_ranges_with_a_supplied_kmer_list(tmp_path):
     """`index kmer.srt ref.fa dir` in ranges: the list is cut at the prefixes, a k-mer of the text that the list lacks is an error"""
     text = gzip.open(os.path.join(GOLD, "graph1.fa.gz")).read()
@@ -249,8 +259,10 @@ def test_gpu_build_beyond_the_budget_gives_the_same_files(tmp_path, monkeypatch)
     assert s1.budget_bytes == 0 and s1.peak_device_bytes > 30 * s1.n_bases
     budget = s1.peak_device_bytes // 8
     monkeypatch.setenv("DSB_BUILD_BUDGET", str(budget))
+    monkeypatch.setenv("DSB_BUILD_SPILL", "1")              # ... and the k-mer list through a file instead of host memory
     s2 = D.build_index(fa, b)
-    monkeypatch.delenv("DSB_BUILD_BUDGET")
+    monkeypatch.delenv("DSB_BUILD_BUDGET"); monkeypatch.delenv("DSB_BUILD_SPILL")
+    assert s2.spilled_bytes == 8 * s2.n_kmer and not os.path.exists(os.path.join(b, "deSAMBA.kmers.tmp"))
     print("380 Mbp: one piece %.1f s holding %.2f GiB; budget %.2f GiB: %.1f s holding %.2f GiB in %d / %d / %d / %d passes (k-mers / unitig numbers / rows / filter tables)" %
           (s1.total_s, s1.peak_device_bytes / 2**30, budget / 2**30, s2.total_s, s2.peak_device_bytes / 2**30, s2.ranges_kmers, s2.ranges_unitig_numbers, s2.ranges_rows, s2.ranges_exist))
     assert s2.budget_bytes == budget and s2.peak_device_bytes <= budget and s2.ranges_kmers >= 4
