@@ -532,12 +532,34 @@ def strain_index(a, D, rank, local, barrier):
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "synth_ref.py"), fa, str(a.index_mbp), "11", "3", "60", "12"], check=True, stderr=subprocess.DEVNULL)
         t_syn = time.perf_counter() - t0
         st = D.build_index(fa, idxd, device=local)
-        os.remove(fa)
         files = sum(os.path.getsize(os.path.join(idxd, f)) for f in os.listdir(idxd))
+        # the same index once more within an eighth of the device memory the one-piece build held (passes over ranges of k-mer prefixes,
+        # the k-mer list in a temporary file): the ten files must come out byte for byte
+        budget_info = None
+        if not a.no_budget_build:
+            d2 = os.path.join(d, "index_budget"); budget = st.peak_device_bytes // 8
+            os.environ["DSB_BUILD_BUDGET"] = str(budget); os.environ["DSB_BUILD_SPILL"] = "1"
+            try:
+                s2 = D.build_index(fa, d2, device=local)
+            finally:
+                del os.environ["DSB_BUILD_BUDGET"]; del os.environ["DSB_BUILD_SPILL"]
+
+            def md5(p_):
+                h = hashlib.md5()
+                with open(p_, "rb") as f_:
+                    for blk in iter(lambda: f_.read(1 << 24), b""):
+                        h.update(blk)
+                return h.hexdigest()
+            same = sorted(os.listdir(idxd)) == sorted(os.listdir(d2)) and all(md5(os.path.join(idxd, f)) == md5(os.path.join(d2, f)) for f in os.listdir(idxd))
+            budget_info = {"seconds": s2.total_s, "budget_bytes": s2.budget_bytes, "peak_device_bytes": s2.peak_device_bytes, "one_piece_peak_device_bytes": st.peak_device_bytes,
+                           "passes": {"kmers": s2.ranges_kmers, "unitig_numbers": s2.ranges_unitig_numbers, "bwt_rows": s2.ranges_rows, "filter_tables": s2.ranges_exist},
+                           "kmer_list_spilled_bytes": s2.spilled_bytes, "files_identical_to_the_one_piece_build": bool(same)}
+            shutil.rmtree(d2, ignore_errors=True)
+        os.remove(fa)
         info = {"seconds": st.total_s, "stages_s": {"read_fasta": st.parse_s, "kmers_sort": st.sort_s, "graph": st.graph_s, "unitigs": st.walk_s, "bwt_rows": st.rows_s,
                                                     "tables_and_copy": st.tables_s, "write_files": st.write_s},
                 "bases": st.n_bases, "sequences": st.n_refs, "kmers_31": st.n_kmer, "unitigs": st.n_unitig, "bwt_rows": st.n_rows, "mbp_per_s": st.n_bases / 1e6 / st.total_s,
-                "index_files_bytes": files, "reference_generation_s": t_syn}
+                "index_files_bytes": files, "reference_generation_s": t_syn, "peak_device_bytes": st.peak_device_bytes, "within_an_eighth_of_the_memory": budget_info}
     barrier()
     return idxd, info
 
@@ -565,6 +587,7 @@ def main():
     ap.add_argument("--no-short-reads", action="store_true", help="skip the 1 M x 150 bp measurement (BASELINE configs[2] shape)")
     ap.add_argument("--no-seed-hbm", action="store_true", help="skip the seed-lookup measurement on synthetic multi-GiB filter tables")
     ap.add_argument("--seed-hbm-mib", type=int, default=2048, help="size of each synthetic filter table (MiB, power of two 128 .. 16384)")
+    ap.add_argument("--no-budget-build", action="store_true", help="skip building the headline index a second time within an eighth of the device memory (files compared)")
     ap.add_argument("--no-proxy", action="store_true", help="skip the BASELINE configs[4] proxy (a >= 1-Gbp index built in the run, PacBio-mixed reads)")
     ap.add_argument("--proxy-mbp", type=int, default=1000)
     ap.add_argument("--proxy-reads", type=int, default=65536)

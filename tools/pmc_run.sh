@@ -16,7 +16,7 @@ for grp in "$@"; do
 	if [ -n "$PMC_SEED_HBM_MIB" ]; then
 		(cd /tmp && timeout -k 10 300 rocprofv3 --pmc $grp -d "$out" -o run --output-format csv -- python3 "$ROOT/tools/seed_hbm_only.py" "$reads" "$PMC_SEED_HBM_MIB" > "$out.log" 2>&1) || { echo "pass $i ($grp) failed"; tail -5 "$out.log"; }
 	else
-		(cd /tmp && timeout -k 10 300 rocprofv3 --pmc $grp -d "$out" -o run --output-format csv -- python3 "$ROOT/bench.py" --headline "${PMC_HEADLINE:-strain}" --no-cpu-baseline --no-end-to-end --no-cli --no-demo-index --no-proxy --no-short-reads --steps 2 --warmup 0 --batches 1 --reads-per-gpu "$reads" > "$out.log" 2>&1) || { echo "pass $i ($grp) failed"; tail -5 "$out.log"; }
+		(cd /tmp && timeout -k 10 300 rocprofv3 --pmc $grp -d "$out" -o run --output-format csv -- python3 "$ROOT/bench.py" --headline "${PMC_HEADLINE:-strain}" --no-cpu-baseline --no-end-to-end --no-cli --no-demo-index --no-proxy --no-short-reads --no-budget-build --steps 2 --warmup 0 --batches 1 --reads-per-gpu "$reads" > "$out.log" 2>&1) || { echo "pass $i ($grp) failed"; tail -5 "$out.log"; }
 	fi
 	i=$((i+1))
 done
